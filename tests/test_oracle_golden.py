@@ -1,0 +1,216 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  CPU-only; this is what makes the oracle trustworthy as the checker
+for the HIP kernels."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import oracle
+from util import close, load_golden
+
+STATS = ("MIN", "MAX", "MED", "AVG", "STD", "NUM")
+
+
+def _cases():
+    return {c["name"]: c["values"] for c in synth.section_stat_cases()}
+
+
+def test_inputs_regenerate_bit_exactly():
+    g = load_golden("section_stats.json")
+    cases = _cases()
+    for rec in g["cases"]:
+        v = np.asarray(cases[rec["name"]], dtype=np.float32)
+        assert hashlib.sha256(v.tobytes()).hexdigest() == rec["sha256"], rec["name"]
+
+
+def test_section_stats_match_reference_detector():
+    """oracle_section_stats == reference Detector._get_section_summaries (straggler.py:172-197)."""
+    g = load_golden("section_stats.json")
+    cases = _cases()
+    for rec in g["cases"]:
+        kept = synth.retained(cases[rec["name"]], rec["ring_capacity"])
+        got = oracle.section_stats(kept.astype(np.float64))
+        exp = rec["expected"]
+        for i, k in enumerate(STATS):
+            if k in ("MIN", "MAX", "MED", "NUM"):
+                assert got[i] == exp[k], (rec["name"], k, got[i], exp[k])  # selections are exact
+            else:
+                assert close(got[i], exp[k], rel=1e-12), (rec["name"], k, got[i], exp[k])
+
+
+def test_kernel_stats_match_reference_computeStats_golden():
+    """oracle_kernel_stats == reference computeStats (CuptiProfiler.cpp:44-74), bit for bit."""
+    g = load_golden("native.json")
+    cases = _cases()
+    for rec in g["compute_stats"]:
+        got = oracle.kernel_stats(cases[rec["name"]])
+        for i in range(6):
+            a, b = got[i], rec["expected"][i]
+            assert (np.isnan(a) and np.isnan(b)) or a == b, (rec["name"], i, a, b)
+
+
+def test_kernel_stats_match_live_reference_build():
+    """Same, against oracle/_ref built from the reference sources (when available here)."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this box)")
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 2, 3, 10, 11, 1000, 8192):
+        x = rng.lognormal(2.0, 1.0, n).astype(np.float32)
+        a, b = oracle.kernel_stats(x), oracle.ref_kernel_stats(x)
+        assert np.array_equal(a, b, equal_nan=True), (n, a, b)
+
+
+def test_ring_matches_reference_circular_buffer():
+    g = load_golden("native.json")
+    for rec in g["ring"]:
+        vals = np.arange(rec["n"], dtype=np.float32) * 0.5 + 1.0
+        lin = oracle.ring_run(vals, rec["capacity"])
+        assert lin.size == rec["size"]
+        assert hashlib.sha256(lin.tobytes()).hexdigest() == rec["sha256"]
+        if oracle.ref_lib() is not None:
+            assert np.array_equal(lin, oracle.ref_ring_run(vals, rec["capacity"]))
+
+
+def _summ(d):
+    return {n: {k: v for k, v in s.items()} for n, s in d.items()}
+
+
+@pytest.mark.parametrize("idx", range(11))
+def test_ref_port_scoring_matches_reference_report_generator(idx):
+    """RefPortReportGenerator (dict-level port) == reference ReportGenerator on gloo ranks."""
+    g = load_golden("scoring.json")["scenarios"][idx]
+    sc = g["scenario"]
+    W = sc["world_size"]
+    port = oracle.RefPortReportGenerator(W, sc["scores_to_compute"], sc["gather_on_rank0"])
+    for t, step in enumerate(sc["steps"]):
+        res = port.generate_reports([_summ(step[r][0]) for r in range(W)], [_summ(step[r][1]) for r in range(W)])
+        if sc["gather_on_rank0"]:
+            exp = g["per_rank"][0]["reports"][t]
+            for r in range(W):
+                for mine, key in ((res["gpu_rel"], "gpu_relative_perf_scores"), (res["gpu_indiv"], "gpu_individual_perf_scores")):
+                    if exp[key]:
+                        assert close(mine[r], exp[key][str(r)], rel=1e-7), (sc["name"], t, r, key)
+                    else:
+                        assert not mine
+                for mine, key in ((res["sec_rel"], "section_relative_perf_scores"), (res["sec_indiv"], "section_individual_perf_scores")):
+                    assert set(mine.keys()) == set(exp[key].keys()), (sc["name"], t, key)
+                    for n in mine:
+                        assert close(mine[n][r], exp[key][n][str(r)], rel=1e-7), (sc["name"], t, r, key, n)
+            for r in range(1, W):
+                assert g["per_rank"][r]["reports"][t] is None
+        else:
+            for r in range(W):
+                exp = g["per_rank"][r]["reports"][t]
+                if exp["gpu_relative_perf_scores"]:
+                    assert close(res["gpu_rel"][r], exp["gpu_relative_perf_scores"][str(r)], rel=1e-12)
+                if exp["gpu_individual_perf_scores"]:
+                    assert close(res["gpu_indiv"][r], exp["gpu_individual_perf_scores"][str(r)], rel=1e-12)
+                for n, v in exp["section_relative_perf_scores"].items():
+                    assert close(res["sec_rel"][r][n], v[str(r)], rel=1e-12)
+                for n, v in exp["section_individual_perf_scores"].items():
+                    assert close(res["sec_indiv"][r][n], v[str(r)], rel=1e-12)
+    # name -> id agreement (name_mapper.py:54-81)
+    if sc["gather_on_rank0"] or "relative_perf_scores" in sc["scores_to_compute"]:
+        assert port.section_ids == g["per_rank"][0]["ids"]["sections"]
+        assert port.kernel_ids == g["per_rank"][0]["ids"]["kernels"]
+
+
+def _table_from_step(step, W, kid, sid, hist):
+    """Build the [R, L] exchange table (layout: oracle/straggler_oracle.c) from per-rank summaries."""
+    K, S = len(kid), len(sid)
+    L = oracle.table_len(K, S)
+    T = np.zeros((W, L), dtype=np.float32)
+    T[:, : K + S] = -1.0
+    T[:, K + S : 2 * (K + S)] = np.nan
+    for r in range(W):
+        sec, ker = step[r]
+        for k, s in ker.items():
+            if "ncclDev" in k:
+                continue
+            j = kid[k]
+            T[r, j] = s["MED"]
+            hist[r][("k", k)] = min(hist[r].get(("k", k), np.inf), np.float32(s["MED"]))
+            T[r, K + S + j] = hist[r][("k", k)]
+            T[r, 2 * (K + S) + j] = np.float32(s["NUM"]) * np.float32(s["AVG"])
+        for n, s in sec.items():
+            j = K + sid[n]
+            T[r, j] = s["MED"]
+            hist[r][("s", n)] = min(hist[r].get(("s", n), np.inf), np.float32(s["MED"]))
+            T[r, K + S + j] = hist[r][("s", n)]
+        T[r, L - 1] = 1.0
+    return T
+
+
+@pytest.mark.parametrize("idx", [i for i in range(11)])
+def test_table_scoring_matches_reference(idx):
+    """oracle_score_table (array form, what the HIP score kernel is checked against) reproduces the
+    reference's gathered scores within f32 rounding (contract: 1e-4; observed <= 1e-6)."""
+    g = load_golden("scoring.json")["scenarios"][idx]
+    sc = g["scenario"]
+    if not sc["gather_on_rank0"]:
+        pytest.skip("gathered form only")
+    W = sc["world_size"]
+    do_rel = "relative_perf_scores" in sc["scores_to_compute"]
+    do_ind = "individual_perf_scores" in sc["scores_to_compute"]
+    port = oracle.RefPortReportGenerator(W, sc["scores_to_compute"], True)
+    hist = [dict() for _ in range(W)]
+    for t, step in enumerate(sc["steps"]):
+        port._gather_and_assign_ids(
+            [[k for k in step[r][1] if "ncclDev" not in k] for r in range(W)], [list(step[r][0]) for r in range(W)]
+        )
+        kid, sid = port.kernel_ids, port.section_ids
+        K, S = len(kid), len(sid)
+        T = _table_from_step(step, W, kid, sid, hist)
+        sc_out = oracle.score_table(T, K, S, do_ind, do_rel)
+        exp = g["per_rank"][0]["reports"][t]
+        for r in range(W):
+            if do_ind:
+                assert close(sc_out[r, 0], exp["gpu_individual_perf_scores"][str(r)], rel=1e-6), (t, r)
+            if do_rel:
+                assert close(sc_out[r, 1], exp["gpu_relative_perf_scores"][str(r)], rel=1e-6), (t, r)
+            for n, j in sid.items():
+                if do_ind:
+                    assert close(sc_out[r, 2 + j], exp["section_individual_perf_scores"][n][str(r)], rel=1e-6), (t, r, n)
+                if do_rel:
+                    assert close(sc_out[r, 2 + S + j], exp["section_relative_perf_scores"][n][str(r)], rel=1e-6), (t, r, n)
+
+
+def test_stress_golden_vs_oracle():
+    """8 ranks x 64 sections x 10k samples through the reference Detector (configs #3/#5):
+    the oracle reproduces summaries, scores and flagged sets from the regenerated inputs."""
+    g = load_golden("stress.json")
+    W = 8
+    hist = [dict() for _ in range(W)]
+    sid = {synth.section_name(s): s for s in range(64)}
+    for var in g["variants"]:
+        exp = g["rank0"][var["name"]]
+        h = hashlib.sha256()
+        step = []
+        for r in range(W):
+            x = synth.stress_samples(r, var["S"], var["n"], var["slow_rank"], var["slow_factor"])
+            h.update(x.tobytes())
+            kept = x[:, -synth.RING_CAPACITY:]
+            st = oracle.rows_stats(kept, np.full(var["S"], kept.shape[1], dtype=np.uint32))
+            step.append(({synth.section_name(s): dict(zip(STATS, st[s])) for s in range(var["S"])}, {}))
+            if r == 0:
+                for s in range(var["S"]):
+                    e = exp["local_section_summaries"][synth.section_name(s)]
+                    for i, k in enumerate(STATS):
+                        assert close(st[s, i], e[k], rel=1e-12), (var["name"], s, k)
+        assert h.hexdigest() == g["input_sha256"][var["name"]]
+        T = _table_from_step(step, W, {}, sid, hist)
+        out = oracle.score_table(T, 0, 64, True, True)
+        for r in range(W):
+            assert np.isnan(out[r, 0]) and np.isnan(out[r, 1])
+            for n, j in sid.items():
+                assert close(out[r, 2 + j], exp["section_individual_perf_scores"][n][str(r)], rel=1e-6)
+                assert close(out[r, 2 + 64 + j], exp["section_relative_perf_scores"][n][str(r)], rel=1e-6)
+        for thr in ("0.75", "0.9"):
+            flagged_rel = {n: sorted(int(r) for r in range(W) if out[r, 2 + 64 + j] < float(thr)) for n, j in sid.items()}
+            flagged_rel = {n: v for n, v in flagged_rel.items() if v}
+            assert flagged_rel == exp["stragglers"][thr]["straggler_sections_relative"], (var["name"], thr)
+            flagged_ind = {n: sorted(int(r) for r in range(W) if out[r, 2 + j] < float(thr)) for n, j in sid.items()}
+            flagged_ind = {n: v for n, v in flagged_ind.items() if v}
+            assert flagged_ind == exp["stragglers"][thr]["straggler_sections_individual"], (var["name"], thr)
