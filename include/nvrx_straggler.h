@@ -1,0 +1,188 @@
+/*
+ * nvrx_straggler.h -- C ABI of libnvrx_straggler_hip.so, the MI355X-native (gfx950 HIP) engine behind
+ * the straggler-detection scoring hot path of nvidia-resiliency-ext.
+ *
+ * The reference has NO C/FFI operator interface for this path: its boundary is (1) the public Python
+ * API (straggler.Detector / ReportGenerator / Report) and (2) the pybind11 native module
+ * `nvrx_cupti_module` (cupti_src/cupti_module_py.cpp:33-55).  This library sits below both; the Python
+ * package in nvidia-resiliency-ext_amd/ keeps (1) and (2) intact and calls the entry points below via
+ * ctypes.  Each entry point cites the reference code it replaces; paths are relative to
+ * /root/reference/src/nvidia_resiliency_ext/attribution/straggler/ .
+ *
+ * Conventions: plain C, no exceptions across the ABI, no Python/torch types.  Every function returns
+ * 0 (NVRX_OK) or a negative errno-style code; nvrx_last_error() returns the calling thread's last
+ * message.  Device buffers named d_* are caller-owned HIP device pointers (e.g. tensor.data_ptr());
+ * `stream` is a hipStream_t passed as void* (0 = the null stream).  A context is thread-compatible:
+ * calls on one context must be serialised by the caller (the Python layer holds a lock, as the
+ * reference's CuptiManager does, cupti.py:44).
+ */
+#ifndef NVRX_STRAGGLER_H
+#define NVRX_STRAGGLER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVRX_ABI_VERSION 1
+
+#define NVRX_OK 0
+#define NVRX_ERR_INVALID (-22) /* bad argument (EINVAL) */
+#define NVRX_ERR_NOMEM (-12)   /* host or device allocation failed (ENOMEM) */
+#define NVRX_ERR_HIP (-5)      /* a HIP runtime call failed (EIO); see nvrx_last_error() */
+#define NVRX_ERR_STATE (-1)    /* call not valid in the current state (EPERM) */
+#define NVRX_ERR_RANGE (-34)   /* size outside what the kernels support (ERANGE) */
+#define NVRX_ERR_TIMEOUT (-62) /* wait timed out (ETIME) */
+
+/* Row statistics layout: NVRX_STATS_STRIDE floats per row.
+ * Mirrors the Statistic enum (statistics.py:19-35) + the kernel weight NUM*AVG (reporting.py:246). */
+#define NVRX_STATS_STRIDE 8
+#define NVRX_STAT_MIN 0
+#define NVRX_STAT_MAX 1
+#define NVRX_STAT_MED 2
+#define NVRX_STAT_AVG 3
+#define NVRX_STAT_STD 4
+#define NVRX_STAT_NUM 5
+#define NVRX_STAT_WEIGHT 6
+
+/* Row kinds select which of the reference's two statistics conventions applies. */
+#define NVRX_KIND_SECTION 0 /* straggler.py:185-195: LOWER median, UNBIASED std (NaN if n==1) */
+#define NVRX_KIND_KERNEL 1  /* CuptiProfiler.cpp:44-74: mean-of-middles median, POPULATION std */
+
+/* Largest row (samples per ring) the statistics kernel keeps resident in registers. */
+#define NVRX_MAX_RING_CAP 65536
+#define NVRX_MAX_ROWS 65536
+
+/* Exchange-table row length for K kernel ids and S section ids (see nvrx_score). */
+#define NVRX_TABLE_LEN(K, S) (2 * ((K) + (S)) + (K) + 1)
+/* Score row length: {gpu_indiv, gpu_rel, indiv[S], rel[S]}  (reporting.py:353-360). */
+#define NVRX_SCORE_LEN(S) (2 + 2 * (S))
+/* Number of uint32 words of score-kernel metadata. */
+#define NVRX_META_WORDS 4
+
+typedef struct nvrx_ctx nvrx_ctx;
+
+/* ------------------------------------------------------------------------------------------------
+ * Library
+ * ---------------------------------------------------------------------------------------------- */
+int nvrx_abi_version(void);
+/* Message of the last failing call made by the calling thread ("" if none). */
+const char *nvrx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stateless operators (caller-owned device buffers).  These are the kernels; the context API below
+ * only adds ring storage, staging and event timing around them.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Per-row statistics of `rows` timing rows, one workgroup per row.
+ *   d_samples [rows][row_stride] f32, row_stride % 4 == 0 and base 16-byte aligned;
+ *   d_counts  [rows] valid samples per row (clamped to row_stride; 0 => NaN stats, NUM 0);
+ *   d_kinds   [rows] NVRX_KIND_* per row, or NULL for all-section;
+ *   d_stats   [rows][NVRX_STATS_STRIDE] f32 out.
+ * Replaces Detector._get_section_summaries (straggler.py:172-197: torch.tensor(deque) + min/max/
+ * median/mean/std per section) and computeStats (CuptiProfiler.cpp:44-74: std::sort + stats per
+ * kernel).  MIN/MAX/MED/NUM are exact; AVG/STD are accumulated in f64 and rounded to f32. */
+int nvrx_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8_t *d_kinds, int rows,
+                   int row_stride, float *d_stats, void *stream);
+
+/* Cross-rank scoring of the exchanged table, for all R ranks at once.
+ *   d_table [R][L] f32, L = NVRX_TABLE_LEN(K,S); per rank r:
+ *      med  [0, K+S)            MED per id (kernel ids first, then section ids); -1 = no stats
+ *      hmin [K+S, 2(K+S))       running minimum of MED on rank r (individual-score reference)
+ *      w    [2(K+S), 2(K+S)+K)  kernel weights NUM*AVG
+ *      flag [L-1]               1.0 if rank r has ids for all its names, else 0.0
+ *   thresholds[4] = {gpu_rel, section_rel, gpu_indiv, section_indiv} (Report.identify_stragglers
+ *      argument order, reporting.py:84-90); NULL => 0.75 each;
+ *   d_scores [R][NVRX_SCORE_LEN(S)] f32 out, NaN where the reference reports NaN / nothing;
+ *   d_flags  [R][NVRX_SCORE_LEN(S)] u8 out, 1 where score < threshold (strict; NaN never flagged);
+ *   d_meta   [NVRX_META_WORDS] u32 out: {all ranks' name flags set, R, K, S}.
+ * Replaces _all_reduce_times (reporting.py:255-296), _compute_sections_perf_scores (:196-217),
+ * _compute_gpu_perf_score (:219-253), _get_tensor_from_scores/_get_scores_from_tensor (:338-380) and
+ * the thresholding of Report.identify_stragglers (:84-151). */
+int nvrx_score(const float *d_table, int R, int K, int S, int do_indiv, int do_rel,
+               const double *thresholds, float *d_scores, uint8_t *d_flags, uint32_t *d_meta,
+               void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Context: device ring buffers + pinned staging + hipEvent timing for `local_ranks` logical ranks
+ * of `rows_per_rank` rows each (one logical rank per GPU in production; several per GPU only when a
+ * whole job is folded onto fewer GPUs for benchmarking).
+ * Replaces CustomSection.cpu_elapsed_times deques (straggler.py:66-83), the native
+ * unordered_map<string, CircularBuffer<float>> (CuptiProfiler.h:66, CircularBuffer.h:22-70) and the
+ * CUPTI activity machinery (CuptiProfiler.cpp:96-207, BufferPool.cpp).
+ * ---------------------------------------------------------------------------------------------- */
+int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap, nvrx_ctx **out);
+int nvrx_ctx_destroy(nvrx_ctx *ctx);
+/* Stream used for flushes triggered implicitly by a full staging buffer (default: null stream). */
+int nvrx_ctx_set_stream(nvrx_ctx *ctx, void *stream);
+/* Geometry queries: 0 local_ranks, 1 rows_per_rank, 2 ring_cap, 3 row_stride, 4 device. */
+int nvrx_ctx_info(const nvrx_ctx *ctx, int what);
+
+/* Row metadata: kind (NVRX_KIND_*) and position `gid` in the exchange table (-1 = not exchanged).
+ * `row` indexes [0, local_ranks*rows_per_rank). Takes effect at the next flush. */
+int nvrx_row_configure(nvrx_ctx *ctx, int row, int kind, int gid);
+
+/* Append one sample (overwrite-oldest beyond ring_cap): deque.append (straggler.py:343) /
+ * CircularBuffer::push_back (CircularBuffer.h:53-61).  Staged in pinned host memory; reaches the
+ * device ring at the next flush.  O(1), no HIP call unless the staging buffer is full. */
+int nvrx_ring_push(nvrx_ctx *ctx, int row, float value);
+int nvrx_ring_push_many(nvrx_ctx *ctx, int row, const float *values, int n);
+/* Append n samples that already live in device memory (device-to-device, wraps as needed). */
+int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, void *stream);
+/* Declare that `row` currently holds n valid samples in its device ring (no data movement). */
+int nvrx_ring_set_count(nvrx_ctx *ctx, int row, int n);
+/* Valid samples in `row` (including staged ones), min(total pushed, ring_cap). */
+int nvrx_ring_count(const nvrx_ctx *ctx, int row);
+/* Drop all samples of every row: deque.clear (straggler.py:223-225) / reset (CuptiProfiler.cpp:148-152).
+ * History minima and row configuration are kept, as in the reference (reporting.py:186-191). */
+int nvrx_ring_reset(nvrx_ctx *ctx);
+/* Forget the history minima too (new Detector.initialize). */
+int nvrx_history_reset(nvrx_ctx *ctx, void *stream);
+/* Push staged samples + row metadata to the device (one kernel reading pinned memory). */
+int nvrx_ring_flush(nvrx_ctx *ctx, void *stream);
+/* Debug/test: copy a row's ring storage (row_stride floats) to host after a flush. */
+int nvrx_ring_read(nvrx_ctx *ctx, int row, float *out, int n, void *stream);
+
+/* GPU timing of a code region with a hipEvent pair on `stream`: the MI355X replacement for the
+ * CUPTI activity records (CuptiProfiler.cpp:116-133,168-207).  Elapsed time is appended to `row`
+ * in MICROSECONDS f32 (CuptiProfiler.cpp:191) when harvested.  begin/end may nest. */
+int nvrx_event_begin(nvrx_ctx *ctx, int row, void *stream);
+int nvrx_event_end(nvrx_ctx *ctx, int row, void *stream);
+/* Move completed event pairs into their rows.  wait!=0 blocks until every ended pair completes
+ * (the role of torch.cuda.synchronize() in straggler.py:234, without a device-wide sync).
+ * Returns the number of pairs still pending (>=0) or a negative error. */
+int nvrx_event_harvest(nvrx_ctx *ctx, int wait);
+
+/* Local half of a report: flush -> row statistics for every row -> write this GPU's
+ * `local_ranks` exchange rows.
+ *   d_stats [local_ranks*rows_per_rank][NVRX_STATS_STRIDE] out
+ *   d_send  [local_ranks][L] out, L = NVRX_TABLE_LEN(K,S) (rows without a gid are not exchanged);
+ *           NULL = statistics only: nothing is exchanged and the history minima are left alone
+ *   names_ok: value of the flag word for these ranks (has ids for all names);
+ *   rows_active: only rows [0, rows_active) of every logical rank are processed (0 = all).
+ * Replaces straggler.py:236-237 + the packing loops of reporting.py:273-279. Also folds in
+ * _update_local_min_times (reporting.py:298-314): hmin[row] = min(hmin[row], MED). */
+int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok,
+                      int rows_active, void *stream);
+/* Re-initialise an exchange buffer with the "no stats" sentinels (call when ids change). */
+int nvrx_send_init(float *d_send, int rows, int K, int S, void *stream);
+
+/* Kernel-time instrumentation for the benchmark: when enabled, nvrx_report_local brackets its
+ * statistics kernel with a hipEvent pair on the launch stream; totals are read back here
+ * (blocks until the recorded events complete). */
+int nvrx_timing_enable(nvrx_ctx *ctx, int on);
+int nvrx_timing_read(nvrx_ctx *ctx, double *total_us, int *launches, int reset);
+
+/* Small asynchronous D2H into pinned memory + completion tracking for the report results. */
+int nvrx_host_alloc(void **out, size_t bytes); /* pinned, device-visible */
+int nvrx_host_free(void *p);
+int nvrx_copy_to_host(nvrx_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
+/* Block (spin) until the last nvrx_copy_to_host on this context has landed. */
+int nvrx_wait(nvrx_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVRX_STRAGGLER_H */

@@ -1,0 +1,1216 @@
+// nvrx_straggler.hip -- gfx950 (MI355X / CDNA4) implementation of include/nvrx_straggler.h.
+//
+// The straggler-scoring hot path is a streaming reduction + an exact selection, not a contraction:
+// no MFMA anywhere.  What matters on CDNA4 is (1) each timing row is read from HBM exactly once with
+// coalesced 16-byte loads, (2) the row then stays in VGPRs (10 000 f32 = 40 KB spread over 512-1024
+// lanes) while min / max / mean / std are reduced with wave64 shuffles and the median is found by an
+// LDS-histogram radix select on order-preserving integer keys, (3) one workgroup per row so that a
+// folded 8-rank x 64-section job (512 rows) puts two workgroups on every one of the 256 CUs.
+//
+// Reference semantics reproduced here (paths relative to
+// /root/reference/src/nvidia_resiliency_ext/attribution/straggler/):
+//   section rows : straggler.py:185-195   torch.min/max/median(LOWER)/mean/std(unbiased), f64
+//   kernel rows  : cupti_src/CuptiProfiler.cpp:44-74  sort, mean-of-middles median, population std
+//   rings        : straggler.py:80-83 deque(maxlen) / cupti_src/CircularBuffer.h:53-69
+//   scoring      : reporting.py:196-296,338-380   (see k_score)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "nvrx_straggler.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(NVRX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+// Order-preserving float <-> uint32 map: a < b  <=>  f2key(a) < f2key(b) (with -0.0 < +0.0).
+__device__ __forceinline__ uint32_t f2key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+struct Epilogue {
+    const int32_t *gid;  // [rows] position in the exchange row, -1 = not exchanged; may be null
+    float *hist_min;     // [rows] running minimum of MED; may be null
+    float *send;         // [local_ranks][L]; may be null
+    int rows_per_rank;
+    int rows_active;  // blocks per logical rank (0: blockIdx.x is the row)
+    int K;
+    int KS;
+    int L;
+    float names_ok;
+};
+
+constexpr int HIST_BITS = 11;
+constexpr int HIST_BINS = 1 << HIST_BITS;
+
+// ------------------------------------------------------------------------------------------------
+// k_row_stats: one workgroup per timing row.
+//   HBM: the row is read once, 16 B per lane per load, VPT independent loads in flight per lane.
+//   Registers: the row lives in VPT*4 order-preserving keys per lane for the rest of the kernel.
+//   LDS: 8 KB histogram + a few words of reduction scratch.
+// ------------------------------------------------------------------------------------------------
+template <int THREADS, int VPT>
+__global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__ samples,
+                                                       const uint32_t *__restrict__ counts,
+                                                       const uint8_t *__restrict__ kinds, int row_stride,
+                                                       float *__restrict__ stats, Epilogue ep) {
+    constexpr int WAVES = THREADS / 64;
+    constexpr int PER = HIST_BINS / THREADS;  // histogram bins scanned per thread
+    static_assert(HIST_BINS % THREADS == 0, "THREADS must divide the histogram size");
+
+    __shared__ uint32_t s_hist[HIST_BINS];
+    __shared__ double s_d[WAVES];
+    __shared__ uint32_t s_u[2 * WAVES];
+    __shared__ uint32_t s_bc[2];
+
+    const int row = ep.rows_active ? (int)(blockIdx.x / ep.rows_active) * ep.rows_per_rank + (int)(blockIdx.x % ep.rows_active)
+                                   : (int)blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    uint32_t n = counts[row];
+    if (n > (uint32_t)row_stride) n = (uint32_t)row_stride;
+    const int kind = kinds ? kinds[row] : NVRX_KIND_SECTION;
+
+    float r_min, r_max, r_med, r_avg, r_std;
+
+    if (n == 0) {
+        r_min = r_max = r_med = r_avg = r_std = __builtin_nanf("");
+    } else {
+        const float4 *__restrict__ src = reinterpret_cast<const float4 *>(samples + (size_t)row * (size_t)row_stride);
+        uint32_t key[VPT * 4];
+
+        // ---- load (HBM -> VGPR), local min/max/sum ------------------------------------------------
+        float4 x[VPT];
+#pragma unroll
+        for (int i = 0; i < VPT; i++) {
+            const int v = i * THREADS + tid;
+            x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((uint32_t)(v * 4) < n) x[i] = src[v];
+        }
+        uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < VPT; i++) {
+            const uint32_t e = (uint32_t)(i * THREADS + tid) * 4u;
+            const float xs[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t k = f2key(xs[c]);
+                key[i * 4 + c] = k;
+                if (e + c < n) {
+                    kmn = min(kmn, k);
+                    kmx = max(kmx, k);
+                    sum += (double)xs[c];
+                }
+            }
+        }
+        kmn = wave_min_u32(kmn);
+        kmx = wave_max_u32(kmx);
+        sum = wave_sum_f64(sum);
+        if (lane == 0) {
+            s_u[wave] = kmn;
+            s_u[WAVES + wave] = kmx;
+            s_d[wave] = sum;
+        }
+        __syncthreads();
+        kmn = s_u[0];
+        kmx = s_u[WAVES];
+        sum = s_d[0];
+#pragma unroll
+        for (int w = 1; w < WAVES; w++) {
+            kmn = min(kmn, s_u[w]);
+            kmx = max(kmx, s_u[WAVES + w]);
+            sum += s_d[w];
+        }
+        __syncthreads();
+        const double mean = sum / (double)n;
+
+        // ---- sum of squared deviations (two-pass, f64), pad invalid slots with the max key ----------
+        double ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < VPT; i++) {
+            const uint32_t e = (uint32_t)(i * THREADS + tid) * 4u;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (e + c < n) {
+                    const double d = (double)key2f(key[i * 4 + c]) - mean;
+                    ss += d * d;
+                } else {
+                    key[i * 4 + c] = kmx;  // padding sorts last, never changes rank k < n
+                }
+            }
+        }
+        ss = wave_sum_f64(ss);
+        if (lane == 0) s_d[wave] = ss;
+        __syncthreads();
+        ss = s_d[0];
+#pragma unroll
+        for (int w = 1; w < WAVES; w++) ss += s_d[w];
+        __syncthreads();
+
+        // ---- exact selection of rank k = (n-1)/2 by radix select on d = key - kmin ---------------------
+        // Only the bits below the top set bit of (kmax - kmin) can differ, so well-clustered timing
+        // data needs two 11-bit passes, and the first histogram is spread over the data's own range
+        // (no hot bin for the shared exponent bits).
+        const uint32_t k_rank = (n - 1u) >> 1;
+        const uint32_t range = kmx - kmn;
+        int hi = 32 - __clz((int)range);  // __clz(0) == 32 -> hi = 0: all samples equal
+        uint32_t prefix = 0u;
+        uint32_t k = k_rank;
+        while (hi > 0) {
+            const int lo = hi > HIST_BITS ? hi - HIST_BITS : 0;
+            const int nb = 1 << (hi - lo);
+            const uint32_t bmask = (uint32_t)nb - 1u;
+            const uint32_t mask_hi = hi >= 32 ? 0u : (0xFFFFFFFFu << hi);
+            for (int b = tid; b < nb; b += THREADS) s_hist[b] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < VPT * 4; j++) {
+                const uint32_t d = key[j] - kmn;
+                if ((d & mask_hi) == prefix) atomicAdd(&s_hist[(d >> lo) & bmask], 1u);
+            }
+            __syncthreads();
+            // block-wide exclusive scan of the histogram, PER consecutive bins per thread
+            uint32_t c[PER];
+            uint32_t local = 0u;
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                const int b = tid * PER + j;
+                c[j] = b < nb ? s_hist[b] : 0u;
+                local += c[j];
+            }
+            uint32_t incl = local;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) s_u[wave] = incl;
+            __syncthreads();
+            uint32_t base = 0u;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++)
+                if (w < wave) base += s_u[w];
+            uint32_t excl = base + incl - local;
+            if (k >= excl && k < excl + local) {
+                uint32_t b = (uint32_t)tid * PER;
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    if (k >= excl + c[j]) {
+                        excl += c[j];
+                        b++;
+                    } else {
+                        break;
+                    }
+                }
+                s_bc[0] = b;
+                s_bc[1] = k - excl;
+            }
+            __syncthreads();
+            prefix |= s_bc[0] << lo;
+            k = s_bc[1];
+            hi = lo;
+            __syncthreads();
+        }
+        const uint32_t dsel = prefix;
+        float med = key2f(kmn + dsel);
+
+        if (kind == NVRX_KIND_KERNEL && (n & 1u) == 0u) {
+            // mean of the two middle order statistics (CuptiProfiler.cpp:57-59): also need rank k+1
+            uint32_t cnt_le = 0u, mn_gt = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < VPT * 4; j++) {
+                const uint32_t d = key[j] - kmn;
+                cnt_le += (d <= dsel) ? 1u : 0u;
+                if (d > dsel) mn_gt = min(mn_gt, d);
+            }
+            cnt_le = wave_sum_u32(cnt_le);
+            mn_gt = wave_min_u32(mn_gt);
+            if (lane == 0) {
+                s_u[wave] = cnt_le;
+                s_u[WAVES + wave] = mn_gt;
+            }
+            __syncthreads();
+            cnt_le = s_u[0];
+            mn_gt = s_u[WAVES];
+#pragma unroll
+            for (int w = 1; w < WAVES; w++) {
+                cnt_le += s_u[w];
+                mn_gt = min(mn_gt, s_u[WAVES + w]);
+            }
+            const uint32_t dnext = (cnt_le >= k_rank + 2u) ? dsel : mn_gt;
+            med = (med + key2f(kmn + dnext)) / 2.0f;
+        }
+
+        r_min = key2f(kmn);
+        r_max = key2f(kmx);
+        r_med = med;
+        r_avg = (float)mean;
+        if (kind == NVRX_KIND_KERNEL) {
+            r_std = (float)sqrt(ss / (double)n);
+        } else {
+            r_std = n > 1u ? (float)sqrt(ss / (double)(n - 1u)) : __builtin_nanf("");
+        }
+    }
+
+    if (tid == 0) {
+        float *o = stats + (size_t)row * NVRX_STATS_STRIDE;
+        const float weight = n ? (float)n * r_avg : 0.0f;
+        o[NVRX_STAT_MIN] = r_min;
+        o[NVRX_STAT_MAX] = r_max;
+        o[NVRX_STAT_MED] = r_med;
+        o[NVRX_STAT_AVG] = r_avg;
+        o[NVRX_STAT_STD] = r_std;
+        o[NVRX_STAT_NUM] = (float)n;
+        o[NVRX_STAT_WEIGHT] = weight;
+        o[7] = 0.0f;
+        float h = __builtin_nanf("");
+        if (ep.hist_min) {
+            // _update_local_min_times (reporting.py:298-314): history is never reset by a report
+            h = ep.hist_min[row];
+            if (n && r_med < h) {
+                h = r_med;
+                ep.hist_min[row] = h;
+            }
+        }
+        if (ep.send) {
+            const int lr = row / ep.rows_per_rank;
+            float *s = ep.send + (size_t)lr * ep.L;
+            const int g = ep.gid ? ep.gid[row] : -1;
+            if (g >= 0 && g < ep.KS) {
+                s[g] = n ? r_med : -1.0f;  // -1 = "no stats on this rank" (reporting.py:273)
+                s[ep.KS + g] = n ? h : __builtin_nanf("");
+                if (g < ep.K) s[2 * ep.KS + g] = weight;
+            }
+            if (row - lr * ep.rows_per_rank == 0) s[ep.L - 1] = ep.names_ok;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scatter: staged (row, slot, value) samples + row metadata from pinned host memory -> device.
+// ------------------------------------------------------------------------------------------------
+struct StagedSample {
+    uint32_t row_slot;  // row << 16 | slot
+    float value;
+};
+
+__global__ void k_scatter(const uint32_t *__restrict__ h_counts, const StagedSample *__restrict__ h_entries,
+                          int n_entries, float *__restrict__ samples, int row_stride,
+                          uint32_t *__restrict__ d_counts, int rows, const uint8_t *__restrict__ h_kinds,
+                          uint8_t *__restrict__ d_kinds, const int32_t *__restrict__ h_gid,
+                          int32_t *__restrict__ d_gid) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_entries) {
+        const StagedSample e = h_entries[i];
+        samples[(size_t)(e.row_slot >> 16) * (size_t)row_stride + (e.row_slot & 0xFFFFu)] = e.value;
+    }
+    if (i < rows) {
+        d_counts[i] = h_counts[i];
+        if (h_kinds) {
+            d_kinds[i] = h_kinds[i];
+            d_gid[i] = h_gid[i];
+        }
+    }
+}
+
+__global__ void k_fill_f32(float *p, size_t n, float v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void k_send_init(float *send, int rows, int K, int S) {
+    const int KS = K + S;
+    const int L = NVRX_TABLE_LEN(K, S);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * L) return;
+    const int j = (int)(i % L);
+    float v;
+    if (j < KS)
+        v = -1.0f;
+    else if (j < 2 * KS)
+        v = __builtin_nanf("");
+    else
+        v = 0.0f;
+    send[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_colmin / k_score: cross-rank scoring on the exchanged table (layout in nvrx_straggler.h).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_colmin(const float *__restrict__ table, int R, int KS, int L, float *__restrict__ minmed) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= KS) return;
+    float m = INFINITY;
+    for (int r = 0; r < R; r++) {
+        const float v = table[(size_t)r * L + j];
+        if (v < m) m = v;
+    }
+    minmed[j] = m >= 0.0f ? m : __builtin_nanf("");  // reporting.py:289,295
+}
+
+struct ScoreArgs {
+    const float *table;
+    const float *minmed_pre;  // null: compute column minima in LDS
+    int R, K, S;
+    int do_indiv, do_rel;
+    double thr[4];  // gpu_rel, section_rel, gpu_indiv, section_indiv
+    float *scores;
+    uint8_t *flags;
+    uint32_t *meta;
+};
+
+constexpr int SCORE_THREADS = 256;
+
+__global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_min[];  // [KS] when minmed_pre == null
+    __shared__ double s_red[4][SCORE_THREADS / 64];
+    __shared__ uint32_t s_cnt[2][SCORE_THREADS / 64];
+
+    const int K = a.K, S = a.S, KS = K + S;
+    const int L = NVRX_TABLE_LEN(K, S);
+    const int W = NVRX_SCORE_LEN(S);
+    const int r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float *__restrict__ row = a.table + (size_t)r * L;
+    float *__restrict__ out = a.scores + (size_t)r * W;
+    uint8_t *__restrict__ fl = a.flags ? a.flags + (size_t)r * W : nullptr;
+    const float NaN = __builtin_nanf("");
+
+    const float *minmed = a.minmed_pre;
+    if (!minmed) {
+        // all_reduce(MIN) of the f32 MED tensor with -1 sentinels (reporting.py:273-295)
+        for (int j = tid; j < KS; j += SCORE_THREADS) {
+            float m = INFINITY;
+            for (int q = 0; q < a.R; q++) {
+                const float v = a.table[(size_t)q * L + j];
+                if (v < m) m = v;
+            }
+            s_min[j] = m >= 0.0f ? m : NaN;
+        }
+        __syncthreads();
+        minmed = s_min;
+    }
+
+    // section scores: reference / MED (reporting.py:196-217), rounded to f32 (reporting.py:352)
+    for (int s = tid; s < S; s += SCORE_THREADS) {
+        const float med = row[K + s];
+        float si = NaN, sr = NaN;
+        if (med >= 0.0f) {
+            if (a.do_indiv) si = (float)((double)row[KS + K + s] / (double)med);
+            if (a.do_rel) sr = (float)((double)minmed[K + s] / (double)med);
+        }
+        out[2 + s] = si;
+        out[2 + S + s] = sr;
+        if (fl) {
+            fl[2 + s] = ((double)si < a.thr[3]) ? 1 : 0;
+            fl[2 + S + s] = ((double)sr < a.thr[1]) ? 1 : 0;
+        }
+    }
+
+    // GPU score: weighted mean of per-kernel ratios (reporting.py:219-253)
+    double wi = 0.0, si = 0.0, wr = 0.0, sr = 0.0;
+    uint32_t nk = 0, ncommon = 0;
+    for (int k = tid; k < K; k += SCORE_THREADS) {
+        const float medf = row[k];
+        if (!(medf >= 0.0f)) continue;
+        const double med = (double)medf;
+        const double w = (double)row[2 * KS + k];
+        nk++;
+        si += ((double)row[KS + k] / med) * w;
+        wi += w;
+        const float mm = minmed[k];
+        if (mm == mm) {
+            ncommon++;
+            sr += ((double)mm / med) * w;
+            wr += w;
+        }
+    }
+    wi = wave_sum_f64(wi);
+    si = wave_sum_f64(si);
+    wr = wave_sum_f64(wr);
+    sr = wave_sum_f64(sr);
+    nk = wave_sum_u32(nk);
+    ncommon = wave_sum_u32(ncommon);
+    if (lane == 0) {
+        s_red[0][wave] = wi;
+        s_red[1][wave] = si;
+        s_red[2][wave] = wr;
+        s_red[3][wave] = sr;
+        s_cnt[0][wave] = nk;
+        s_cnt[1][wave] = ncommon;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        wi = si = wr = sr = 0.0;
+        nk = ncommon = 0;
+        for (int w = 0; w < SCORE_THREADS / 64; w++) {
+            wi += s_red[0][w];
+            si += s_red[1][w];
+            wr += s_red[2][w];
+            sr += s_red[3][w];
+            nk += s_cnt[0][w];
+            ncommon += s_cnt[1][w];
+        }
+        const float gi = (a.do_indiv && nk > 0) ? (float)(si / wi) : NaN;
+        const float gr = (a.do_rel && ncommon > 0) ? (float)(sr / wr) : NaN;
+        out[0] = gi;
+        out[1] = gr;
+        if (fl) {
+            fl[0] = ((double)gi < a.thr[2]) ? 1 : 0;
+            fl[1] = ((double)gr < a.thr[0]) ? 1 : 0;
+        }
+    }
+
+    if (r == 0 && a.meta && wave == 1) {
+        // is_all_true(has_all_names) (name_mapper.py:68-69, dist_utils.py:107-115) folded into the table
+        uint32_t bad = 0;
+        for (int q = lane; q < a.R; q += 64) bad += (a.table[(size_t)q * L + (L - 1)] > 0.0f) ? 0u : 1u;
+        bad = wave_sum_u32(bad);
+        if (lane == 0) {
+            a.meta[0] = bad ? 0u : 1u;
+            a.meta[1] = (uint32_t)a.R;
+            a.meta[2] = (uint32_t)K;
+            a.meta[3] = (uint32_t)S;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch-shape selection for k_row_stats
+// ------------------------------------------------------------------------------------------------
+using StatsKernel = void (*)(const float *, const uint32_t *, const uint8_t *, int, float *, Epilogue);
+
+struct StatsVariant {
+    int threads;
+    int vpt;
+    StatsKernel fn;
+};
+
+#define SV(T, V) \
+    { T, V, k_row_stats<T, V> }
+const StatsVariant kVariants[] = {
+    SV(256, 1),  SV(256, 2),  SV(256, 3),  SV(256, 4),  SV(256, 5),   SV(256, 6),  SV(256, 8),  SV(256, 10),
+    SV(256, 12), SV(256, 16), SV(512, 1),  SV(512, 2),  SV(512, 3),   SV(512, 4),  SV(512, 5),  SV(512, 6),
+    SV(512, 8),  SV(512, 10), SV(512, 12), SV(512, 16), SV(1024, 1),  SV(1024, 2), SV(1024, 3), SV(1024, 4),
+    SV(1024, 5), SV(1024, 6), SV(1024, 8), SV(1024, 10), SV(1024, 12), SV(1024, 16),
+};
+#undef SV
+
+// Smallest variant of the preferred width that holds a whole row in registers.
+const StatsVariant *pick_variant(int row_stride) {
+    static int forced_threads = -1;
+    if (forced_threads < 0) {
+        const char *e = getenv("NVRX_STATS_THREADS");
+        forced_threads = e ? atoi(e) : 0;
+    }
+    const int prefs_default[3] = {512, 1024, 256};
+    int prefs[3] = {prefs_default[0], prefs_default[1], prefs_default[2]};
+    if (forced_threads == 256 || forced_threads == 512 || forced_threads == 1024) {
+        prefs[0] = forced_threads;
+        int j = 1;
+        for (int t : prefs_default)
+            if (t != forced_threads) prefs[j++] = t;
+    } else if (row_stride <= 256 * 4 * 2) {
+        prefs[0] = 256;
+        prefs[1] = 512;
+        prefs[2] = 1024;
+    }
+    for (int p = 0; p < 3; p++) {
+        const StatsVariant *best = nullptr;
+        for (const StatsVariant &v : kVariants) {
+            if (v.threads != prefs[p]) continue;
+            if (v.threads * v.vpt * 4 >= row_stride && (!best || v.vpt < best->vpt)) best = &v;
+        }
+        if (best) return best;
+    }
+    return nullptr;
+}
+
+int launch_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8_t *d_kinds, int rows,
+                     int row_stride, float *d_stats, const Epilogue &ep, hipStream_t stream) {
+    if (rows == 0) return NVRX_OK;
+    const StatsVariant *v = pick_variant(row_stride);
+    if (!v)
+        return fail(NVRX_ERR_RANGE, "row_stride %d exceeds the register-resident limit %d", row_stride,
+                    NVRX_MAX_RING_CAP);
+    hipLaunchKernelGGL(v->fn, dim3(rows), dim3(v->threads), 0, stream, d_samples, d_counts, d_kinds, row_stride,
+                       d_stats, ep);
+    HIP_TRY(hipGetLastError());
+    return NVRX_OK;
+}
+
+// scratch for the two-kernel scoring path (large R or K+S)
+std::mutex g_scratch_mu;
+float *g_scratch = nullptr;
+size_t g_scratch_elems = 0;
+
+}  // namespace
+
+// ================================================================================================
+// context
+// ================================================================================================
+struct EventPair {
+    hipEvent_t start = nullptr;
+    hipEvent_t end = nullptr;
+};
+
+struct StageBuf {
+    uint32_t *h_counts = nullptr;     // [rows]
+    StagedSample *h_entries = nullptr;  // [stage_cap]
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
+struct nvrx_ctx {
+    int device = 0;
+    int local_ranks = 1;
+    int rows_per_rank = 0;
+    int rows = 0;
+    int ring_cap = 0;
+    int row_stride = 0;
+    int stage_cap = 0;
+
+    float *d_samples = nullptr;
+    uint32_t *d_counts = nullptr;
+    uint8_t *d_kinds = nullptr;
+    int32_t *d_gid = nullptr;
+    float *d_hist_min = nullptr;
+
+    std::vector<uint64_t> total;  // samples ever pushed per row since the last reset
+    uint8_t *h_kinds = nullptr;   // pinned
+    int32_t *h_gid = nullptr;     // pinned
+    bool meta_dirty = true;
+    bool counts_dirty = true;
+
+    static constexpr int NBUF = 4;
+    StageBuf buf[NBUF];
+    int cur = 0;
+    int n_staged = 0;
+
+    hipStream_t default_stream = nullptr;
+
+    // hipEvent timing of code regions
+    std::vector<EventPair> pool;
+    std::vector<int> free_pairs;
+    struct Open {
+        int row;
+        int pair;
+    };
+    std::vector<Open> open;
+    std::deque<Open> pending;
+
+    // benchmark instrumentation
+    bool timing = false;
+    std::vector<EventPair> timing_pairs;
+    std::vector<int> timing_free;
+    std::vector<int> timing_used;
+    double timing_total_us = 0.0;
+    int timing_launches = 0;
+
+    hipEvent_t copy_done = nullptr;
+    bool copy_pending = false;
+
+    std::mutex mu;
+};
+
+namespace {
+
+int ctx_set_device(const nvrx_ctx *ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return NVRX_OK;
+}
+
+int flush_locked(nvrx_ctx *ctx, hipStream_t stream) {
+    if (ctx->n_staged == 0 && !ctx->meta_dirty && !ctx->counts_dirty) return NVRX_OK;
+    StageBuf &b = ctx->buf[ctx->cur];
+    for (int r = 0; r < ctx->rows; r++)
+        b.h_counts[r] = (uint32_t)std::min<uint64_t>(ctx->total[r], (uint64_t)ctx->ring_cap);
+    const int work = std::max(ctx->n_staged, ctx->rows);
+    const int threads = 256;
+    const int blocks = (work + threads - 1) / threads;
+    hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(threads), 0, stream, b.h_counts, b.h_entries, ctx->n_staged,
+                       ctx->d_samples, ctx->row_stride, ctx->d_counts, ctx->rows,
+                       ctx->meta_dirty ? ctx->h_kinds : nullptr, ctx->d_kinds,
+                       ctx->meta_dirty ? ctx->h_gid : nullptr, ctx->d_gid);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b.done, stream));
+    b.in_flight = true;
+    if (ctx->meta_dirty) {
+        // h_kinds/h_gid are read by the kernel just launched: do not let the host modify them until
+        // it has run.  Metadata changes are cold (new names only), so a blocking wait is fine.
+        HIP_TRY(hipEventSynchronize(b.done));
+        b.in_flight = false;
+    }
+    ctx->meta_dirty = false;
+    ctx->counts_dirty = false;
+    ctx->n_staged = 0;
+    ctx->cur = (ctx->cur + 1) % nvrx_ctx::NBUF;
+    StageBuf &nb = ctx->buf[ctx->cur];
+    if (nb.in_flight) {
+        HIP_TRY(hipEventSynchronize(nb.done));
+        nb.in_flight = false;
+    }
+    return NVRX_OK;
+}
+
+inline int push_locked(nvrx_ctx *ctx, int row, float value) {
+    if (ctx->n_staged == ctx->stage_cap) {
+        int rc = flush_locked(ctx, ctx->default_stream);
+        if (rc) return rc;
+    }
+    const uint32_t slot = (uint32_t)(ctx->total[row] % (uint64_t)ctx->ring_cap);
+    StagedSample &e = ctx->buf[ctx->cur].h_entries[ctx->n_staged++];
+    e.row_slot = ((uint32_t)row << 16) | slot;
+    e.value = value;
+    ctx->total[row]++;
+    ctx->counts_dirty = true;
+    return NVRX_OK;
+}
+
+int get_pair(std::vector<EventPair> &pool, std::vector<int> &free_list, int *out) {
+    if (free_list.empty()) {
+        EventPair p;
+        HIP_TRY(hipEventCreate(&p.start));
+        HIP_TRY(hipEventCreate(&p.end));
+        pool.push_back(p);
+        free_list.push_back((int)pool.size() - 1);
+    }
+    *out = free_list.back();
+    free_list.pop_back();
+    return NVRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nvrx_abi_version(void) { return NVRX_ABI_VERSION; }
+
+const char *nvrx_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// stateless operators
+// ------------------------------------------------------------------------------------------------
+int nvrx_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8_t *d_kinds, int rows,
+                   int row_stride, float *d_stats, void *stream) {
+    if (rows < 0 || row_stride <= 0 || (row_stride & 3)) return fail(NVRX_ERR_INVALID, "row_stride must be a positive multiple of 4 (got %d), rows >= 0", row_stride);
+    if (rows > 0 && (!d_samples || !d_counts || !d_stats)) return fail(NVRX_ERR_INVALID, "null device pointer");
+    if ((reinterpret_cast<uintptr_t>(d_samples) & 15u) != 0) return fail(NVRX_ERR_INVALID, "d_samples must be 16-byte aligned");
+    Epilogue ep{};
+    return launch_row_stats(d_samples, d_counts, d_kinds, rows, row_stride, d_stats, ep, as_stream(stream));
+}
+
+int nvrx_score(const float *d_table, int R, int K, int S, int do_indiv, int do_rel, const double *thresholds,
+               float *d_scores, uint8_t *d_flags, uint32_t *d_meta, void *stream) {
+    if (R <= 0 || K < 0 || S < 0) return fail(NVRX_ERR_INVALID, "bad table shape R=%d K=%d S=%d", R, K, S);
+    if (!d_table || !d_scores) return fail(NVRX_ERR_INVALID, "null device pointer");
+    hipStream_t st = as_stream(stream);
+    ScoreArgs a{};
+    a.table = d_table;
+    a.R = R;
+    a.K = K;
+    a.S = S;
+    a.do_indiv = do_indiv;
+    a.do_rel = do_rel;
+    for (int i = 0; i < 4; i++) a.thr[i] = thresholds ? thresholds[i] : 0.75;
+    a.scores = d_scores;
+    a.flags = d_flags;
+    a.meta = d_meta;
+    const int KS = K + S;
+    size_t lds = (size_t)KS * sizeof(float);
+    if (R > 64 || lds > 48 * 1024) {
+        // large jobs: column minima in their own pass over a coalesced grid
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (g_scratch_elems < (size_t)KS) {
+            if (g_scratch) HIP_TRY(hipFree(g_scratch));
+            g_scratch = nullptr;
+            g_scratch_elems = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_scratch), std::max<size_t>((size_t)KS, 1024) * sizeof(float)));
+            g_scratch_elems = std::max<size_t>((size_t)KS, 1024);
+        }
+        if (KS > 0) {
+            hipLaunchKernelGGL(k_colmin, dim3((KS + 255) / 256), dim3(256), 0, st, d_table, R, KS,
+                               NVRX_TABLE_LEN(K, S), g_scratch);
+            HIP_TRY(hipGetLastError());
+        }
+        a.minmed_pre = g_scratch;
+        lds = 0;
+    }
+    hipLaunchKernelGGL(k_score, dim3(R), dim3(SCORE_THREADS), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return NVRX_OK;
+}
+
+int nvrx_send_init(float *d_send, int rows, int K, int S, void *stream) {
+    if (!d_send || rows <= 0 || K < 0 || S < 0) return fail(NVRX_ERR_INVALID, "bad arguments");
+    const size_t n = (size_t)rows * NVRX_TABLE_LEN(K, S);
+    hipLaunchKernelGGL(k_send_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), d_send, rows, K, S);
+    HIP_TRY(hipGetLastError());
+    return NVRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context lifecycle
+// ------------------------------------------------------------------------------------------------
+int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap, nvrx_ctx **out) {
+    if (!out) return fail(NVRX_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (local_ranks <= 0 || rows_per_rank <= 0 || ring_cap <= 0) return fail(NVRX_ERR_INVALID, "sizes must be positive");
+    if (ring_cap > NVRX_MAX_RING_CAP) return fail(NVRX_ERR_RANGE, "ring_cap %d > %d", ring_cap, NVRX_MAX_RING_CAP);
+    if ((long long)local_ranks * rows_per_rank > NVRX_MAX_ROWS) return fail(NVRX_ERR_RANGE, "too many rows");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(NVRX_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    nvrx_ctx *ctx = new (std::nothrow) nvrx_ctx();
+    if (!ctx) return fail(NVRX_ERR_NOMEM, "host allocation failed");
+    ctx->device = device;
+    ctx->local_ranks = local_ranks;
+    ctx->rows_per_rank = rows_per_rank;
+    ctx->rows = local_ranks * rows_per_rank;
+    ctx->ring_cap = ring_cap;
+    ctx->row_stride = (ring_cap + 3) & ~3;
+    ctx->stage_cap = std::min(4096, ring_cap);
+    ctx->total.assign((size_t)ctx->rows, 0);
+
+#define CTX_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            int rc_ = fail(NVRX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+            nvrx_ctx_destroy(ctx);                                                            \
+            return rc_;                                                                       \
+        }                                                                                     \
+    } while (0)
+
+    const size_t nsamp = (size_t)ctx->rows * (size_t)ctx->row_stride;
+    CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_samples), nsamp * sizeof(float)));
+    CTX_TRY(hipMemset(ctx->d_samples, 0, nsamp * sizeof(float)));
+    CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_counts), (size_t)ctx->rows * sizeof(uint32_t)));
+    CTX_TRY(hipMemset(ctx->d_counts, 0, (size_t)ctx->rows * sizeof(uint32_t)));
+    CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_kinds), (size_t)ctx->rows));
+    CTX_TRY(hipMemset(ctx->d_kinds, 0, (size_t)ctx->rows));
+    CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_gid), (size_t)ctx->rows * sizeof(int32_t)));
+    CTX_TRY(hipMemset(ctx->d_gid, 0xFF, (size_t)ctx->rows * sizeof(int32_t)));
+    CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hist_min), (size_t)ctx->rows * sizeof(float)));
+    hipLaunchKernelGGL(k_fill_f32, dim3((ctx->rows + 255) / 256), dim3(256), 0, nullptr, ctx->d_hist_min, (size_t)ctx->rows, INFINITY);
+    CTX_TRY(hipGetLastError());
+    CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_kinds), (size_t)ctx->rows, hipHostMallocDefault));
+    CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_gid), (size_t)ctx->rows * sizeof(int32_t), hipHostMallocDefault));
+    memset(ctx->h_kinds, 0, (size_t)ctx->rows);
+    for (int r = 0; r < ctx->rows; r++) ctx->h_gid[r] = -1;
+    for (StageBuf &b : ctx->buf) {
+        CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&b.h_counts), (size_t)ctx->rows * sizeof(uint32_t), hipHostMallocDefault));
+        CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&b.h_entries), (size_t)ctx->stage_cap * sizeof(StagedSample), hipHostMallocDefault));
+        CTX_TRY(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+    }
+    CTX_TRY(hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
+    CTX_TRY(hipDeviceSynchronize());
+#undef CTX_TRY
+    *out = ctx;
+    return NVRX_OK;
+}
+
+int nvrx_ctx_destroy(nvrx_ctx *ctx) {
+    if (!ctx) return NVRX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    if (ctx->d_kinds) (void)hipFree(ctx->d_kinds);
+    if (ctx->d_gid) (void)hipFree(ctx->d_gid);
+    if (ctx->d_hist_min) (void)hipFree(ctx->d_hist_min);
+    if (ctx->h_kinds) (void)hipHostFree(ctx->h_kinds);
+    if (ctx->h_gid) (void)hipHostFree(ctx->h_gid);
+    for (StageBuf &b : ctx->buf) {
+        if (b.h_counts) (void)hipHostFree(b.h_counts);
+        if (b.h_entries) (void)hipHostFree(b.h_entries);
+        if (b.done) (void)hipEventDestroy(b.done);
+    }
+    for (EventPair &p : ctx->pool) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.end);
+    }
+    for (EventPair &p : ctx->timing_pairs) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.end);
+    }
+    if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
+    delete ctx;
+    return NVRX_OK;
+}
+
+int nvrx_ctx_set_stream(nvrx_ctx *ctx, void *stream) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->default_stream = as_stream(stream);
+    return NVRX_OK;
+}
+
+int nvrx_ctx_info(const nvrx_ctx *ctx, int what) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    switch (what) {
+        case 0: return ctx->local_ranks;
+        case 1: return ctx->rows_per_rank;
+        case 2: return ctx->ring_cap;
+        case 3: return ctx->row_stride;
+        case 4: return ctx->device;
+        default: return fail(NVRX_ERR_INVALID, "unknown info selector %d", what);
+    }
+}
+
+int nvrx_row_configure(nvrx_ctx *ctx, int row, int kind, int gid) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
+    if (kind != NVRX_KIND_SECTION && kind != NVRX_KIND_KERNEL) return fail(NVRX_ERR_INVALID, "bad kind %d", kind);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->h_kinds[row] != (uint8_t)kind || ctx->h_gid[row] != gid) {
+        ctx->h_kinds[row] = (uint8_t)kind;
+        ctx->h_gid[row] = gid;
+        ctx->meta_dirty = true;
+    }
+    return NVRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rings
+// ------------------------------------------------------------------------------------------------
+int nvrx_ring_push(nvrx_ctx *ctx, int row, float value) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return push_locked(ctx, row, value);
+}
+
+int nvrx_ring_push_many(nvrx_ctx *ctx, int row, const float *values, int n) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
+    if (n < 0 || (n > 0 && !values)) return fail(NVRX_ERR_INVALID, "bad values/n");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx_set_device(ctx);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+        rc = push_locked(ctx, row, values[i]);
+        if (rc) return rc;
+    }
+    return NVRX_OK;
+}
+
+int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, void *stream) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
+    if (n < 0 || (n > 0 && !d_values)) return fail(NVRX_ERR_INVALID, "bad d_values/n");
+    if (n == 0) return NVRX_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx_set_device(ctx);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    rc = flush_locked(ctx, st);  // earlier staged samples must land first
+    if (rc) return rc;
+    const int cap = ctx->ring_cap;
+    // only the newest `cap` samples can survive
+    uint64_t first = 0;
+    if (n > cap) first = (uint64_t)(n - cap);
+    uint64_t pos = ctx->total[row] + first;
+    int left = n - (int)first;
+    const float *src = d_values + first;
+    float *base = ctx->d_samples + (size_t)row * (size_t)ctx->row_stride;
+    while (left > 0) {
+        const int slot = (int)(pos % (uint64_t)cap);
+        const int chunk = std::min(left, cap - slot);
+        HIP_TRY(hipMemcpyAsync(base + slot, src, (size_t)chunk * sizeof(float), hipMemcpyDeviceToDevice, st));
+        src += chunk;
+        pos += (uint64_t)chunk;
+        left -= chunk;
+    }
+    ctx->total[row] += (uint64_t)n;
+    ctx->counts_dirty = true;
+    return NVRX_OK;
+}
+
+int nvrx_ring_set_count(nvrx_ctx *ctx, int row, int n) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
+    if (n < 0 || n > ctx->ring_cap) return fail(NVRX_ERR_INVALID, "count %d outside [0,%d]", n, ctx->ring_cap);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->total[row] = (uint64_t)n;
+    ctx->counts_dirty = true;
+    return NVRX_OK;
+}
+
+int nvrx_ring_count(const nvrx_ctx *ctx, int row) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
+    return (int)std::min<uint64_t>(ctx->total[(size_t)row], (uint64_t)ctx->ring_cap);
+}
+
+int nvrx_ring_reset(nvrx_ctx *ctx) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    // staged samples belong to the window being dropped
+    ctx->n_staged = 0;
+    std::fill(ctx->total.begin(), ctx->total.end(), 0);
+    ctx->counts_dirty = true;
+    return NVRX_OK;
+}
+
+int nvrx_history_reset(nvrx_ctx *ctx, void *stream) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx_set_device(ctx);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fill_f32, dim3((ctx->rows + 255) / 256), dim3(256), 0, as_stream(stream), ctx->d_hist_min,
+                       (size_t)ctx->rows, INFINITY);
+    HIP_TRY(hipGetLastError());
+    return NVRX_OK;
+}
+
+int nvrx_ring_flush(nvrx_ctx *ctx, void *stream) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx_set_device(ctx);
+    if (rc) return rc;
+    return flush_locked(ctx, as_stream(stream));
+}
+
+int nvrx_ring_read(nvrx_ctx *ctx, int row, float *out, int n, void *stream) {
+    if (!ctx || !out) return fail(NVRX_ERR_INVALID, "null argument");
+    if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
+    if (n < 0 || n > ctx->row_stride) return fail(NVRX_ERR_INVALID, "n %d outside [0,%d]", n, ctx->row_stride);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx_set_device(ctx);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    rc = flush_locked(ctx, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_samples + (size_t)row * (size_t)ctx->row_stride, (size_t)n * sizeof(float),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NVRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hipEvent region timing
+// ------------------------------------------------------------------------------------------------
+int nvrx_event_begin(nvrx_ctx *ctx, int row, void *stream) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int idx = -1;
+    int rc = get_pair(ctx->pool, ctx->free_pairs, &idx);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->pool[(size_t)idx].start, as_stream(stream)));
+    ctx->open.push_back({row, idx});
+    return NVRX_OK;
+}
+
+int nvrx_event_end(nvrx_ctx *ctx, int row, void *stream) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = (int)ctx->open.size() - 1; i >= 0; i--) {
+        if (ctx->open[(size_t)i].row == row) {
+            const nvrx_ctx::Open o = ctx->open[(size_t)i];
+            ctx->open.erase(ctx->open.begin() + i);
+            HIP_TRY(hipEventRecord(ctx->pool[(size_t)o.pair].end, as_stream(stream)));
+            ctx->pending.push_back(o);
+            return NVRX_OK;
+        }
+    }
+    return fail(NVRX_ERR_STATE, "nvrx_event_end(row=%d) without a matching nvrx_event_begin", row);
+}
+
+int nvrx_event_harvest(nvrx_ctx *ctx, int wait) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    while (!ctx->pending.empty()) {
+        const nvrx_ctx::Open o = ctx->pending.front();
+        EventPair &p = ctx->pool[(size_t)o.pair];
+        if (wait) {
+            HIP_TRY(hipEventSynchronize(p.end));
+        } else {
+            hipError_t q = hipEventQuery(p.end);
+            if (q == hipErrorNotReady) break;
+            if (q != hipSuccess) return fail(NVRX_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        }
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.start, p.end));
+        ctx->pending.pop_front();
+        ctx->free_pairs.push_back(o.pair);
+        int rc = push_locked(ctx, o.row, ms * 1000.0f);  // microseconds, as CuptiProfiler.cpp:191
+        if (rc) return rc;
+    }
+    return (int)ctx->pending.size();
+}
+
+// ------------------------------------------------------------------------------------------------
+// report (local half)
+// ------------------------------------------------------------------------------------------------
+int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
+                      void *stream) {
+    if (!ctx || !d_stats) return fail(NVRX_ERR_INVALID, "null argument");
+    if (K < 0 || S < 0) return fail(NVRX_ERR_INVALID, "bad K/S");
+    if (rows_active < 0 || rows_active > ctx->rows_per_rank) return fail(NVRX_ERR_INVALID, "rows_active %d outside [0,%d]", rows_active, ctx->rows_per_rank);
+    if (rows_active == 0) rows_active = ctx->rows_per_rank;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx_set_device(ctx);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    rc = flush_locked(ctx, st);
+    if (rc) return rc;
+    Epilogue ep{};
+    ep.gid = ctx->d_gid;
+    // history minima only advance on a real report (d_send given), not on a statistics peek
+    ep.hist_min = d_send ? ctx->d_hist_min : nullptr;
+    ep.send = d_send;
+    ep.rows_per_rank = ctx->rows_per_rank;
+    ep.rows_active = rows_active;
+    ep.K = K;
+    ep.KS = K + S;
+    ep.L = NVRX_TABLE_LEN(K, S);
+    ep.names_ok = names_ok ? 1.0f : 0.0f;
+    int pair = -1;
+    if (ctx->timing) {
+        rc = get_pair(ctx->timing_pairs, ctx->timing_free, &pair);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ctx->timing_pairs[(size_t)pair].start, st));
+    }
+    rc = launch_row_stats(ctx->d_samples, ctx->d_counts, ctx->d_kinds, ctx->local_ranks * rows_active, ctx->row_stride,
+                          d_stats, ep, st);
+    if (rc) return rc;
+    if (pair >= 0) {
+        HIP_TRY(hipEventRecord(ctx->timing_pairs[(size_t)pair].end, st));
+        ctx->timing_used.push_back(pair);
+    }
+    return NVRX_OK;
+}
+
+int nvrx_timing_enable(nvrx_ctx *ctx, int on) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->timing = on != 0;
+    return NVRX_OK;
+}
+
+int nvrx_timing_read(nvrx_ctx *ctx, double *total_us, int *launches, int reset) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int idx : ctx->timing_used) {
+        EventPair &p = ctx->timing_pairs[(size_t)idx];
+        HIP_TRY(hipEventSynchronize(p.end));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.start, p.end));
+        ctx->timing_total_us += (double)ms * 1000.0;
+        ctx->timing_launches++;
+        ctx->timing_free.push_back(idx);
+    }
+    ctx->timing_used.clear();
+    if (total_us) *total_us = ctx->timing_total_us;
+    if (launches) *launches = ctx->timing_launches;
+    if (reset) {
+        ctx->timing_total_us = 0.0;
+        ctx->timing_launches = 0;
+    }
+    return NVRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host buffers and completion
+// ------------------------------------------------------------------------------------------------
+int nvrx_host_alloc(void **out, size_t bytes) {
+    if (!out || bytes == 0) return fail(NVRX_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    memset(*out, 0, bytes);
+    return NVRX_OK;
+}
+
+int nvrx_host_free(void *p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return NVRX_OK;
+}
+
+int nvrx_copy_to_host(nvrx_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream) {
+    if (!ctx || !h_dst || !d_src) return fail(NVRX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t st = as_stream(stream);
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(ctx->copy_done, st));
+    ctx->copy_pending = true;
+    return NVRX_OK;
+}
+
+int nvrx_wait(nvrx_ctx *ctx) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->copy_pending) {
+        HIP_TRY(hipEventSynchronize(ctx->copy_done));
+        ctx->copy_pending = false;
+    }
+    return NVRX_OK;
+}
+
+}  // extern "C"

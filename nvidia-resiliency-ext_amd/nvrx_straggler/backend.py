@@ -1,0 +1,310 @@
+"""Compute backend of the straggler path: the HIP engine, and nothing else.
+
+``get_backend()`` returns the process-wide :class:`HipBackend`.  Constructing it requires the in-tree
+``libnvrx_straggler_hip.so`` and a visible MI355X; otherwise it raises -- there is no CPU fallback in
+the product.  ``set_backend()`` exists so the CPU-only unit tests can inject their own checker
+backend (built on ``oracle/``, which lives outside this package) to exercise the host-side logic
+(name mapping, exchange, report assembly, Detector plumbing) on a box without a GPU.
+
+Data layout in HBM (all f32 unless noted; see include/nvrx_straggler.h):
+
+* rings   ``[local_ranks * rows_per_rank][row_stride]``  one timing row per section / GPU-timed region
+* stats   ``[rows][8]``        MIN MAX MED AVG STD NUM WEIGHT pad
+* send    ``[local_ranks][L]`` this GPU's exchange rows, ``L = 2(K+S) + K + 1``
+* table   ``[R][L]``           all ranks' rows after the all-gather
+* scores  ``[R][2+2S]``, flags ``[R][2+2S]`` u8, meta ``[4]`` u32
+
+``meta | scores | flags | stats`` live in ONE device allocation mirrored by ONE pinned host buffer, so
+a report needs a single small D2H copy.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native
+
+DEFAULT_THRESHOLDS = (0.75, 0.75, 0.75, 0.75)  # gpu_rel, section_rel, gpu_indiv, section_indiv
+
+_backend = None
+_backend_lock = threading.Lock()
+
+
+def set_backend(backend) -> None:
+    """Install a backend object (tests only; pass ``None`` to go back to the HIP engine)."""
+    global _backend
+    with _backend_lock:
+        _backend = backend
+
+
+def get_backend():
+    """The active backend; creates the HIP engine on first use and fails loudly if it cannot."""
+    global _backend
+    if _backend is None:
+        with _backend_lock:
+            if _backend is None:
+                _backend = HipBackend()
+    return _backend
+
+
+def _align(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+class Workspace:
+    """Buffers of one report shape (R ranks, K kernel ids, S section ids)."""
+
+    def __init__(self, backend: "HipBackend", R: int, K: int, S: int, local_ranks: int, stats_rows: int):
+        self.R, self.K, self.S = R, K, S
+        self.local_ranks = local_ranks
+        self.stats_rows = stats_rows
+        self.L = _native.table_len(K, S)
+        self.W = _native.score_len(S)
+        dev = backend.device
+        self.send = torch.empty((local_ranks, self.L), dtype=torch.float32, device=dev)
+        self.table = torch.empty((R, self.L), dtype=torch.float32, device=dev) if R != local_ranks else self.send
+        self.send_initialised = False
+        # one result block: meta | scores | flags | stats (stats last: only the used rows are copied)
+        self._off_meta = 0
+        self._off_scores = self._off_meta + _align(_native.META_WORDS * 4)
+        self._off_flags = self._off_scores + _align(R * self.W * 4)
+        self._off_stats = self._off_flags + _align(R * self.W)
+        self.nbytes = self._off_stats + _align(max(stats_rows, 1) * _native.STATS_STRIDE * 4)
+        self.out_dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
+        self.out_host = torch.zeros(self.nbytes, dtype=torch.uint8, pin_memory=True)
+        host = self.out_host.numpy()
+        self.stats = host[self._off_stats : self._off_stats + stats_rows * 32].view(np.float32).reshape(stats_rows, _native.STATS_STRIDE)
+        self.meta = host[self._off_meta : self._off_meta + 16].view(np.uint32)
+        self.scores = host[self._off_scores : self._off_scores + R * self.W * 4].view(np.float32).reshape(R, self.W)
+        self.flags = host[self._off_flags : self._off_flags + R * self.W].reshape(R, self.W)
+        base = self.out_dev.data_ptr()
+        self.d_stats = base + self._off_stats
+        self.d_meta = base + self._off_meta
+        self.d_scores = base + self._off_scores
+        self.d_flags = base + self._off_flags
+
+    def set_send_row(self, lr: int, row: np.ndarray) -> None:
+        """Host-packed exchange row (dict-input path)."""
+        self.send[lr].copy_(torch.from_numpy(row), non_blocking=False)
+        self.send_initialised = True
+
+
+class HipBackend:
+    """MI355X engine: owns the side stream the report runs on and the per-shape workspaces."""
+
+    name = "hip"
+
+    def __init__(self, device: Optional[int] = None):
+        self.lib = _native.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "nvrx_straggler: no HIP device is visible (torch.cuda.is_available() is False). "
+                "The MI355X straggler-scoring path has no CPU fallback."
+            )
+        index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", index)
+        # the report pipeline runs on its own stream so it never serialises with the training stream
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._workspaces = {}
+        self._thr = (ctypes.c_double * 4)(*DEFAULT_THRESHOLDS)
+
+    @property
+    def stream_handle(self) -> int:
+        return self.stream.cuda_stream
+
+    def stream_context(self):
+        return torch.cuda.stream(self.stream)
+
+    @staticmethod
+    def current_stream_handle() -> int:
+        """hipStream_t of the stream user code is currently launching on (for region timing)."""
+        return torch.cuda.current_stream().cuda_stream
+
+    def workspace(self, R: int, K: int, S: int, local_ranks: int = 1, stats_rows: int = 0) -> Workspace:
+        key = (R, K, S, local_ranks, stats_rows)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            if len(self._workspaces) > 8:  # shapes only change when new names appear
+                self._workspaces.clear()
+            with torch.cuda.device(self.device):
+                ws = Workspace(self, R, K, S, local_ranks, stats_rows)
+            self._workspaces[key] = ws
+        return ws
+
+    def make_rings(self, local_ranks: int, rows_per_rank: int, ring_cap: int) -> "HipRings":
+        return HipRings(self, local_ranks, rows_per_rank, ring_cap)
+
+    def send_init(self, ws: Workspace) -> None:
+        _native.check(self.lib.nvrx_send_init(ws.send.data_ptr(), ws.local_ranks, ws.K, ws.S, self.stream_handle))
+        ws.send_initialised = True
+
+    def score(self, ws: Workspace, table: torch.Tensor, do_indiv: bool, do_rel: bool,
+              thresholds: Sequence[float] = DEFAULT_THRESHOLDS, wait: bool = True,
+              stats_rows: Optional[int] = None) -> None:
+        """Score kernel + the one D2H of the result block; on return ``ws.scores/flags/meta/stats``
+        hold this report's values (when ``wait``).  Only the first ``stats_rows`` statistics rows are
+        copied (default: all)."""
+        nrows = ws.stats_rows if stats_rows is None else min(stats_rows, ws.stats_rows)
+        nbytes = ws._off_stats + nrows * _native.STATS_STRIDE * 4
+        for i in range(4):
+            self._thr[i] = float(thresholds[i])
+        with torch.cuda.stream(self.stream):
+            _native.check(
+                self.lib.nvrx_score(table.data_ptr(), ws.R, ws.K, ws.S, int(do_indiv), int(do_rel), self._thr,
+                                    ws.d_scores, ws.d_flags, ws.d_meta, self.stream_handle)
+            )
+            ws.out_host[:nbytes].copy_(ws.out_dev[:nbytes], non_blocking=True)
+        if wait:
+            self.stream.synchronize()
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
+
+    def row_stats(self, samples: torch.Tensor, counts: torch.Tensor, kinds: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Stateless statistics operator on caller tensors ([rows, stride] f32, [rows] u32/i32)."""
+        rows, stride = samples.shape
+        stats = torch.empty((rows, _native.STATS_STRIDE), dtype=torch.float32, device=samples.device)
+        with torch.cuda.stream(self.stream):
+            _native.check(
+                self.lib.nvrx_row_stats(samples.data_ptr(), counts.data_ptr(), kinds.data_ptr() if kinds is not None else None,
+                                        rows, stride, stats.data_ptr(), self.stream_handle)
+            )
+        self.stream.synchronize()
+        return stats
+
+
+class HipRings:
+    """Device ring buffers + pinned staging + hipEvent timing (one ``nvrx_ctx``)."""
+
+    def __init__(self, backend: HipBackend, local_ranks: int, rows_per_rank: int, ring_cap: int):
+        self.backend = backend
+        self.lib = backend.lib
+        self.local_ranks = local_ranks
+        self.rows_per_rank = rows_per_rank
+        self.ring_cap = ring_cap
+        ctx = ctypes.c_void_p()
+        _native.check(self.lib.nvrx_ctx_create(backend.device.index, local_ranks, rows_per_rank, ring_cap, ctypes.byref(ctx)))
+        self.ctx = ctx
+        _native.check(self.lib.nvrx_ctx_set_stream(ctx, backend.stream_handle))
+        self.rows_used = 0
+        #: every name that ever got a ring row (rows are never recycled; a reset only empties them)
+        self.section_row_names = {}
+        self.kernel_row_names = {}
+
+    # ---- lifecycle -----------------------------------------------------------------------------
+    def close(self) -> None:
+        if self.ctx is not None:
+            self.lib.nvrx_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- rows ----------------------------------------------------------------------------------
+    def alloc_row(self) -> int:
+        if self.rows_used >= self.rows_per_rank:
+            raise RuntimeError(
+                f"straggler rings are full: {self.rows_per_rank} timing rows per rank "
+                "(raise max_rows in Detector.initialize)"
+            )
+        self.rows_used += 1
+        return self.rows_used - 1
+
+    def row_for(self, kind: int, name: str) -> int:
+        """Ring row of a section (kind 0) / GPU-timed region (kind 1), allocated on first use."""
+        table = self.kernel_row_names if kind == _native.KIND_KERNEL else self.section_row_names
+        row = table.get(name)
+        if row is None:
+            row = self.alloc_row()
+            table[name] = row
+            self.configure(row, kind, -1)
+        return row
+
+    def configure(self, row: int, kind: int, gid: int, lr: Optional[int] = None) -> None:
+        lrs = range(self.local_ranks) if lr is None else (lr,)
+        for q in lrs:
+            _native.check(self.lib.nvrx_row_configure(self.ctx, q * self.rows_per_rank + row, kind, gid))
+
+    def push(self, row: int, value: float, lr: int = 0) -> None:
+        rc = self.lib.nvrx_ring_push(self.ctx, lr * self.rows_per_rank + row, value)
+        if rc < 0:
+            _native.check(rc)
+
+    def push_many(self, row: int, values, lr: int = 0) -> None:
+        a = np.ascontiguousarray(values, dtype=np.float32)
+        _native.check(self.lib.nvrx_ring_push_many(self.ctx, lr * self.rows_per_rank + row, a.ctypes.data, a.size))
+
+    def push_device(self, row: int, values: torch.Tensor, lr: int = 0) -> None:
+        assert values.dtype == torch.float32 and values.is_contiguous() and values.is_cuda
+        _native.check(self.lib.nvrx_ring_push_device(self.ctx, lr * self.rows_per_rank + row, values.data_ptr(),
+                                                     values.numel(), self.backend.stream_handle))
+
+    def set_count(self, row: int, n: int, lr: int = 0) -> None:
+        _native.check(self.lib.nvrx_ring_set_count(self.ctx, lr * self.rows_per_rank + row, n))
+
+    def count(self, row: int, lr: int = 0) -> int:
+        return _native.check(self.lib.nvrx_ring_count(self.ctx, lr * self.rows_per_rank + row))
+
+    def reset(self) -> None:
+        _native.check(self.lib.nvrx_ring_reset(self.ctx))
+
+    def reset_history(self) -> None:
+        _native.check(self.lib.nvrx_history_reset(self.ctx, self.backend.stream_handle))
+
+    def flush(self) -> None:
+        _native.check(self.lib.nvrx_ring_flush(self.ctx, self.backend.stream_handle))
+
+    def read_row(self, row: int, lr: int = 0) -> np.ndarray:
+        stride = _native.check(self.lib.nvrx_ctx_info(self.ctx, 3))
+        out = np.empty(stride, dtype=np.float32)
+        _native.check(self.lib.nvrx_ring_read(self.ctx, lr * self.rows_per_rank + row, out.ctypes.data, stride,
+                                              self.backend.stream_handle))
+        return out
+
+    # ---- GPU region timing -----------------------------------------------------------------------
+    def event_begin(self, row: int, stream_handle: int, lr: int = 0) -> None:
+        _native.check(self.lib.nvrx_event_begin(self.ctx, lr * self.rows_per_rank + row, stream_handle))
+
+    def event_end(self, row: int, stream_handle: int, lr: int = 0) -> None:
+        _native.check(self.lib.nvrx_event_end(self.ctx, lr * self.rows_per_rank + row, stream_handle))
+
+    def harvest(self, wait: bool) -> int:
+        return _native.check(self.lib.nvrx_event_harvest(self.ctx, int(wait)))
+
+    # ---- report ----------------------------------------------------------------------------------
+    def report_local(self, ws: Workspace, names_ok: bool, rows_active: int = 0) -> None:
+        """flush -> statistics kernel -> exchange rows, all on the backend's stream."""
+        if not ws.send_initialised:
+            self.backend.send_init(ws)
+        _native.check(
+            self.lib.nvrx_report_local(self.ctx, ws.d_stats, ws.send.data_ptr(), ws.K, ws.S, int(names_ok),
+                                       rows_active, self.backend.stream_handle)
+        )
+
+    def peek_stats(self) -> np.ndarray:
+        """Statistics of every used row right now ([rows_used, 8] on the host); exchanges nothing and
+        leaves the history minima alone."""
+        total = self.local_ranks * self.rows_per_rank
+        stats = torch.empty((total, _native.STATS_STRIDE), dtype=torch.float32, device=self.backend.device)
+        _native.check(self.lib.nvrx_report_local(self.ctx, stats.data_ptr(), None, 0, 0, 1, self.rows_used,
+                                                 self.backend.stream_handle))
+        with torch.cuda.stream(self.backend.stream):
+            host = stats.cpu()
+        self.backend.stream.synchronize()
+        return host.numpy()
+
+    def timing_enable(self, on: bool) -> None:
+        _native.check(self.lib.nvrx_timing_enable(self.ctx, int(on)))
+
+    def timing_read(self, reset: bool = True):
+        total = ctypes.c_double()
+        launches = ctypes.c_int()
+        _native.check(self.lib.nvrx_timing_read(self.ctx, ctypes.byref(total), ctypes.byref(launches), int(reset)))
+        return total.value, launches.value

@@ -1,0 +1,336 @@
+"""``Detector``: section timing + report orchestration, MI355X edition.
+
+API kept from the reference (straggler.py): ``CallableId`` (:35-62), ``CustomSection`` (:66-83) and
+the class-level, never-instantiated ``Detector`` with ``initialize / shutdown / detection_section /
+generate_report / generate_report_if_interval_elapsed / is_interval_elapsed / wrap_callables /
+restore_original_callables`` (:86-407), including its error behaviour (double initialize ->
+AssertionError, use before initialize -> RuntimeError("Detector is not initialized."), instantiation
+-> RuntimeError).
+
+What changed underneath:
+
+* a section's elapsed times are appended to a DEVICE ring (pinned staging + one scatter kernel per
+  flush) instead of a Python deque, so a report never converts thousands of Python floats into a
+  tensor (the reference's dominant cost, straggler.py:185);
+* ``profile_cuda=True`` brackets the section with a hipEvent pair on the current stream (GPU time of
+  the region, microseconds) instead of enabling CUPTI kernel tracing;
+* ``generate_report`` waits only for the recorded event pairs (not ``torch.cuda.synchronize()``),
+  then runs statistics -> all-gather -> scoring on the detector's own HIP stream.
+"""
+from __future__ import annotations
+
+import dataclasses
+import functools
+import inspect
+import socket
+import sys
+import time
+from collections.abc import Callable
+from contextlib import contextmanager
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Union
+
+from . import _native
+from . import backend as _backend_mod
+from .cupti import CuptiManager
+from .interval_tracker import ReportIntervalTracker
+from .reporting import ReportGenerator
+from .statistics import Statistic  # noqa: F401  (re-exported for callers that poke summaries)
+
+GPU_KEY_PREFIX = "hipevent::"  # kernel-summary key of a section's GPU-time row
+
+
+@dataclasses.dataclass(frozen=True)
+class CallableId:
+    """Names a callable as (owner object, attribute name); ``str()`` gives its section name.
+
+    The extra optional fields exist in the reference's dataclass and are accepted for compatibility.
+    """
+
+    obj: object
+    name: str
+    arg_filter_fn: Optional[Callable[[inspect.BoundArguments], bool]] = None
+    extra_args_fn: Optional[Callable[[inspect.BoundArguments], dict]] = None
+    ignored_args: Optional[tuple] = None
+
+    def __str__(self) -> str:
+        # naming rules of the reference (straggler.py:53-62): module name, qualified class name,
+        # or the class name of an instance
+        o = self.obj
+        if inspect.ismodule(o):
+            owner = o.__name__
+        elif inspect.isclass(o):
+            owner = f"{o.__module__}.{o.__name__}"
+        elif hasattr(o, "__class__"):
+            owner = getattr(o.__class__, "__name__", o)
+        else:
+            owner = getattr(o, "__name__", o)
+        return f"{owner}.{self.name}"
+
+
+class _ElapsedRing:
+    """deque-like facade (append / extend / clear / len) over one device ring row."""
+
+    __slots__ = ("_rings", "_row")
+
+    def __init__(self, rings, row: int):
+        self._rings = rings
+        self._row = row
+
+    def append(self, value: float) -> None:
+        self._rings.push(self._row, value)
+
+    def extend(self, values: Iterable[float]) -> None:
+        self._rings.push_many(self._row, list(values) if not hasattr(values, "__len__") else values)
+
+    def clear(self) -> None:
+        self._rings.set_count(self._row, 0)
+
+    def __len__(self) -> int:
+        return self._rings.count(self._row)
+
+
+class CustomSection:
+    """A user-defined code section (``Detector.detection_section``).
+
+    ``cpu_elapsed_times`` holds the wall-clock durations [ms] of profiled entries, newest
+    ``max_elapseds_len`` only; here it is a view of a device ring row rather than a deque.
+    ``CustomSection.max_elapseds_len`` (class attribute, default 8192 as in the reference,
+    straggler.py:80) is read by ``Detector.initialize`` as the ring capacity.
+    """
+
+    max_elapseds_len: int = 8 * 1024
+
+    __slots__ = ("name", "location", "total_entry_cnt", "row", "gpu_row", "cpu_elapsed_times")
+
+    def __init__(self, name: str, location: str, rings=None):
+        self.name = name
+        self.location = location
+        self.total_entry_cnt = 0
+        rings = rings if rings is not None else Detector.rings
+        self.row = rings.row_for(_native.KIND_SECTION, name)
+        self.gpu_row: Optional[int] = None
+        self.cpu_elapsed_times = _ElapsedRing(rings, self.row)
+
+
+class Detector:
+    """Straggler detector; class-level singleton, not meant to be instantiated.
+
+    Class attributes after ``initialize``: ``scores_to_compute``, ``gather_on_rank0``,
+    ``profiling_interval``, ``custom_sections`` (name -> CustomSection), ``cupti_manager``,
+    ``reporter`` (ReportGenerator), ``report_interval_tracker``, ``original_callables``, and ``rings``
+    (the device ring buffers).
+    """
+
+    initialized: bool = False
+    scores_to_compute: Sequence[str]
+    gather_on_rank0: bool
+    profiling_interval: int
+    report_time_interval: float
+    custom_sections: Dict[str, CustomSection]
+    cupti_manager: Optional[CuptiManager]
+    reporter: ReportGenerator
+    report_interval_tracker: ReportIntervalTracker
+    original_callables: Optional[Dict[CallableId, Any]]
+    rings: Any = None
+
+    def __new__(cls):
+        raise RuntimeError(f"class {cls.__name__} should not be instantiated")
+
+    # ---- lifecycle -----------------------------------------------------------------------------
+    @classmethod
+    def initialize(
+        cls,
+        scores_to_compute: Union[Sequence[str], str] = "all",
+        gather_on_rank0: bool = True,
+        profiling_interval: int = 1,
+        report_time_interval: float = 60,
+        node_name: Optional[str] = None,
+        max_rows: int = 256,
+    ):
+        """
+        Args:
+            scores_to_compute: list with 'relative_perf_scores' and/or 'individual_perf_scores', or "all".
+            gather_on_rank0: rank 0's report covers all ranks (others get None); else per-rank reports.
+            profiling_interval: profile every N-th entry of a section.
+            report_time_interval: seconds between reports for ``generate_report_if_interval_elapsed``.
+            node_name: name of this node in reports (default: ``socket.gethostname()``).
+            max_rows: timing rows (sections + GPU-timed regions) the device rings can hold.
+        """
+        assert not cls.initialized
+
+        cls.scores_to_compute = (
+            ["relative_perf_scores", "individual_perf_scores"] if str(scores_to_compute) == "all" else scores_to_compute
+        )
+        cls.gather_on_rank0 = gather_on_rank0
+        cls.profiling_interval = profiling_interval
+        cls.custom_sections = {}
+        ring_cap = int(CustomSection.max_elapseds_len)
+        cls.rings = _backend_mod.get_backend().make_rings(1, int(max_rows), ring_cap)
+        cls.cupti_manager = CuptiManager(statsMaxLenPerKernel=ring_cap, rings=cls.rings)
+        cls.cupti_manager.initialize()
+        cls.reporter = ReportGenerator(
+            scores_to_compute=cls.scores_to_compute,
+            gather_on_rank0=gather_on_rank0,
+            node_name=(node_name if node_name else socket.gethostname()),
+        )
+        cls.report_interval_tracker = ReportIntervalTracker(
+            time_interval=report_time_interval, profiling_interval=profiling_interval
+        )
+        cls.initialized = True
+        cls.original_callables = {}
+
+    @classmethod
+    def shutdown(cls):
+        cls.cupti_manager.shutdown()
+        cls.restore_original_callables()
+        cls.cupti_manager = None
+        if cls.rings is not None:
+            cls.rings.close()
+            cls.rings = None
+        cls.initialized = False
+
+    # ---- summaries (host-visible form; the report path itself keeps them on the device) -------------
+    @classmethod
+    def _get_section_summaries(cls):
+        """name -> {Statistic: value} for every section holding samples (computed on the device)."""
+        stats = cls.rings.peek_stats()
+        out = {}
+        for name, section in cls.custom_sections.items():
+            if len(section.cpu_elapsed_times) == 0:
+                continue
+            v = stats[section.row]
+            out[name] = {
+                Statistic.MIN: float(v[0]), Statistic.MAX: float(v[1]), Statistic.MED: float(v[2]),
+                Statistic.AVG: float(v[3]), Statistic.STD: float(v[4]), Statistic.NUM: int(v[5]),
+            }
+        return out
+
+    @classmethod
+    def _get_kernel_summaries(cls):
+        """key -> {Statistic: value} for every GPU-timed region (hipEvent rows)."""
+        out = {}
+        for key, ks in cls.cupti_manager.get_results().items():
+            out[key] = {
+                Statistic.MIN: ks.min, Statistic.MAX: ks.max, Statistic.MED: ks.median,
+                Statistic.AVG: ks.avg, Statistic.STD: ks.stddev, Statistic.NUM: ks.num_calls,
+            }
+        return out
+
+    @classmethod
+    def _reset_sections_elapseds(cls):
+        cls.rings.reset()
+
+    # ---- reports -----------------------------------------------------------------------------------
+    @classmethod
+    def generate_report(cls):
+        """Score everything recorded since the last report, then empty the rings.  Collective."""
+        assert cls.initialized
+        rings = cls.rings
+        # the recorded GPU regions must have finished; nothing else on the device is waited for
+        rings.harvest(wait=True)
+        section_rows = {
+            name: sec.row for name, sec in cls.custom_sections.items() if rings.count(sec.row) > 0
+        }
+        kernel_rows = {key: row for key, row in rings.kernel_row_names.items() if rings.count(row) > 0}
+        report = cls.reporter.generate_report_from_rings(rings, section_rows, kernel_rows)
+        rings.reset()  # both the section rows and the GPU-time rows, like :241-242 of the reference
+        return report
+
+    @classmethod
+    def generate_report_if_interval_elapsed(cls):
+        """Call once per training iteration on every rank; reports when the (rank-synchronised)
+        iteration interval has elapsed, otherwise returns None."""
+        assert cls.initialized
+        cls.report_interval_tracker.iter_increase()
+        if cls.report_interval_tracker.is_interval_elapsed():
+            return cls.generate_report()
+        return None
+
+    @classmethod
+    def is_interval_elapsed(cls) -> bool:
+        return cls.report_interval_tracker.is_interval_elapsed()
+
+    # ---- sections ----------------------------------------------------------------------------------
+    @staticmethod
+    def _get_this_context_block_location() -> str:
+        # frames: this function <- detection_section generator <- contextmanager.__enter__ <- user code
+        frame = sys._getframe(3)
+        return f"{frame.f_code.co_filename}:{frame.f_lineno}"
+
+    @classmethod
+    def _ensure_section_name_is_valid(cls, name, location):
+        known = cls.custom_sections.get(name)
+        if known is not None and known.location != location:
+            raise ValueError(f"Section name '{name}' is already used at: {known.location}")
+
+    @classmethod
+    @contextmanager
+    def detection_section(cls, name: Optional[str] = None, profile_cuda: bool = True):
+        """Time the enclosed block.
+
+        Args:
+            name: section name for reports (default: ``file:line`` of the ``with`` statement).
+            profile_cuda: also measure the block's GPU time with a hipEvent pair on the current
+                stream; it feeds the rank's GPU performance score.
+        """
+        if not cls.initialized:
+            raise RuntimeError("Detector is not initialized.")
+
+        section = cls.custom_sections.get(name) if name is not None else None
+        if section is None:
+            location = cls._get_this_context_block_location()
+            if name is None:
+                name = location
+            section = cls.custom_sections.get(name)
+            if section is None:
+                section = CustomSection(name=name, location=location, rings=cls.rings)
+                cls.custom_sections[name] = section
+
+        profiled = (section.total_entry_cnt % cls.profiling_interval) == 0
+        section.total_entry_cnt += 1
+        if not profiled:
+            yield
+            return
+
+        if profile_cuda:
+            cls.cupti_manager.start_profiling(GPU_KEY_PREFIX + name)
+        t0 = time.perf_counter_ns()
+        try:
+            yield
+        except BaseException:
+            # no sample for an entry that raised; just close the GPU region
+            if profile_cuda:
+                cls.cupti_manager.stop_profiling()
+            raise
+        elapsed_ms = (time.perf_counter_ns() - t0) * 1e-6
+        cls.rings.push(section.row, elapsed_ms)
+        if profile_cuda:
+            cls.cupti_manager.stop_profiling()
+
+    # ---- callable wrapping -------------------------------------------------------------------------
+    @classmethod
+    def _build_wrapper(cls, fn, callable_id, profile_cuda: bool = True):
+        section_name = str(callable_id)
+
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            with cls.detection_section(name=section_name, profile_cuda=profile_cuda):
+                return fn(*args, **kwargs)
+
+        return wrapper
+
+    @classmethod
+    def wrap_callables(cls, callable_ids: List[CallableId], profile_cuda: bool = True):
+        """Replace each ``getattr(cid.obj, cid.name)`` by a version that runs inside
+        ``detection_section(str(cid))``."""
+        cls.original_callables = {}
+        for cid in callable_ids:
+            original = getattr(cid.obj, cid.name)
+            cls.original_callables[cid] = original
+            setattr(cid.obj, cid.name, cls._build_wrapper(original, cid, profile_cuda=profile_cuda))
+
+    @classmethod
+    def restore_original_callables(cls):
+        if cls.original_callables:
+            for cid, original in cls.original_callables.items():
+                setattr(cid.obj, cid.name, original)

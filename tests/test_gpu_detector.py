@@ -1,0 +1,168 @@
+"""End-to-end GPU parity: Detector / FoldedJob on the MI355X vs outputs of the real reference."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import oracle
+from util import close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_report_vs_golden(rep, exp, S_names, rel=1e-4):
+    W = 8
+    for r in range(W):
+        assert np.isnan(rep.gpu_relative_perf_scores[r]) and np.isnan(rep.gpu_individual_perf_scores[r])
+    for n in S_names:
+        for r in range(W):
+            assert close(rep.section_relative_perf_scores[n][r], exp["section_relative_perf_scores"][n][str(r)], rel=rel)
+            assert close(rep.section_individual_perf_scores[n][r], exp["section_individual_perf_scores"][n][str(r)], rel=rel)
+    for thr in (0.75, 0.9):
+        got = rep.identify_stragglers(thr, thr, thr, thr)
+        e = exp["stragglers"][str(thr)]
+        assert sorted(x.rank for x in got["straggler_gpus_relative"]) == e["straggler_gpus_relative"]
+        assert sorted(x.rank for x in got["straggler_gpus_individual"]) == e["straggler_gpus_individual"]
+        assert {k: sorted(x.rank for x in v) for k, v in got["straggler_sections_relative"].items()} == e["straggler_sections_relative"]
+        assert {k: sorted(x.rank for x in v) for k, v in got["straggler_sections_individual"].items()} == e["straggler_sections_individual"]
+
+
+def test_stress_8ranks_64sections_10k_vs_reference_golden():
+    """BASELINE configs #3 and #5 folded onto one GPU (8 logical ranks): scores within 1e-4 of the
+    reference Detector's, flagged sets identical at thresholds 0.75 and 0.9, local summaries equal.
+    Ring capacity 8192 on both sides (the reference keeps the newest 8192 of 10 000)."""
+    from nvrx_straggler import Statistic
+    from nvrx_straggler.folded import FoldedJob
+
+    g = load_golden("stress.json")
+    names = [synth.section_name(s) for s in range(64)]
+    job = FoldedJob(total_ranks=8, section_names=names, ring_cap=8192, node_name="node0")
+    try:
+        for var in g["variants"]:
+            for r in range(8):
+                job.load(r, synth.stress_samples(r, var["S"], var["n"], var["slow_rank"], var["slow_factor"]))
+            rep = job.report()
+            exp = g["rank0"][var["name"]]
+            _check_report_vs_golden(rep, exp, names)
+            for n in names:  # rank 0's local summaries
+                e = exp["local_section_summaries"][n]
+                s = rep.local_section_summaries[n]
+                assert s[Statistic.MED] == np.float32(e["MED"]) and s[Statistic.NUM] == e["NUM"]
+                assert s[Statistic.MIN] == np.float32(e["MIN"]) and s[Statistic.MAX] == np.float32(e["MAX"])
+                assert close(s[Statistic.AVG], e["AVG"], rel=1e-6) and close(s[Statistic.STD], e["STD"], rel=1e-5)
+            assert rep.rank_to_node == {r: "node0" for r in range(8)}
+    finally:
+        job.close()
+
+
+def test_stress_capacity_10000_vs_oracle():
+    """Same workload with both sides' ring capacity raised to 10 000 (the bench configuration)."""
+    from nvrx_straggler.folded import FoldedJob
+
+    names = [synth.section_name(s) for s in range(64)]
+    job = FoldedJob(total_ranks=8, section_names=names, ring_cap=10_000)
+    try:
+        xs = [synth.stress_samples(r, 64, 10_000, 3, 1.5) for r in range(8)]
+        for r in range(8):
+            job.load(r, xs[r])
+        rep = job.report()
+        T = np.zeros((8, oracle.table_len(0, 64)), dtype=np.float32)
+        for r in range(8):
+            st = oracle.rows_stats(xs[r], np.full(64, 10_000, dtype=np.uint32))
+            T[r, :64] = st[:, 2]
+            T[r, 64:128] = st[:, 2]
+        exp = oracle.score_table(T, 0, 64)
+        for s, n in enumerate(names):
+            for r in range(8):
+                assert close(rep.section_relative_perf_scores[n][r], exp[r, 2 + 64 + s], rel=1e-6)
+        flagged = rep.identify_stragglers()["straggler_sections_relative"]
+        assert all({x.rank for x in v} == {3} for v in flagged.values()) and len(flagged) == 64
+    finally:
+        job.close()
+
+
+def test_detector_sleep_sections_single_rank():
+    """Detector API end to end on one rank: NUM honours profiling_interval, report resets the rings,
+    GPU-timed section produces a hipevent:: kernel summary, scores of a lone rank are 1."""
+    from nvrx_straggler import Detector, Statistic
+
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=False, profiling_interval=2, node_name="n0")
+    try:
+        x = torch.randn(256, 256, device="cuda")
+        for _ in range(4):
+            with Detector.detection_section("cpu_only", profile_cuda=False):
+                time.sleep(0.002)
+            with Detector.detection_section("with_gpu", profile_cuda=True):
+                (x @ x).sum()
+        rep = Detector.generate_report()
+        assert rep.local_section_summaries["cpu_only"][Statistic.NUM] == 2
+        assert rep.local_section_summaries["with_gpu"][Statistic.NUM] == 2
+        assert rep.local_section_summaries["cpu_only"][Statistic.MIN] >= 2.0
+        ks = rep.local_kernel_summaries
+        assert list(ks.keys()) == ["hipevent::with_gpu"] and ks["hipevent::with_gpu"][Statistic.NUM] == 2
+        assert ks["hipevent::with_gpu"][Statistic.MIN] > 0.0
+        assert rep.section_relative_perf_scores["cpu_only"][0] == pytest.approx(1.0)
+        assert rep.gpu_relative_perf_scores[0] == pytest.approx(1.0)
+        assert rep.gpu_individual_perf_scores[0] == pytest.approx(1.0)
+        # rings were emptied: the next report has nothing and must not crash (test_det_section_api.py:122-133)
+        rep2 = Detector.generate_report()
+        assert len(rep2.local_section_summaries) == 0 and len(rep2.local_kernel_summaries) == 0
+        assert np.isnan(rep2.gpu_relative_perf_scores[0])
+        # an exception inside a section records no sample (straggler.py:337-340)
+        with pytest.raises(ValueError):
+            with Detector.detection_section("raises", profile_cuda=True):
+                raise ValueError("boom")
+        assert len(Detector.custom_sections["raises"].cpu_elapsed_times) == 0
+        with pytest.raises(AssertionError):
+            Detector.initialize()
+    finally:
+        Detector.shutdown()
+    with pytest.raises(RuntimeError, match="Detector is not initialized."):
+        with Detector.detection_section("x"):
+            pass
+
+
+def test_profiler_module_twin_of_reference_cupti_tests():
+    """hipEvent twin of tests/straggler/unit/test_cupti_ext.py + test_cupti_manager.py: one key per
+    region, start/stop gating, reset, ring cap, singleton, refcounted manager."""
+    import nvrx_cupti_module
+    from nvrx_straggler.cupti import CuptiManager
+
+    prof = nvrx_cupti_module.CuptiProfiler(statsMaxLenPerKernel=7)
+    with pytest.raises(RuntimeError):
+        nvrx_cupti_module.CuptiProfiler()
+    prof.initialize()
+    x = torch.randn(512, 512, device="cuda")
+    (x @ x).sum().item()  # before start: not recorded
+    assert prof.get_stats() == {}
+    for _ in range(21):
+        prof.start("matmul")
+        x @ x
+        prof.stop()
+    st = prof.get_stats()
+    assert list(st.keys()) == ["matmul"] and st["matmul"].num_calls == 7  # ring cap (test_cupti_ext.py:98-116)
+    assert 0 < st["matmul"].min <= st["matmul"].median <= st["matmul"].max
+    assert "num calls: 7" in str(st["matmul"])
+    prof.reset()
+    assert prof.get_stats() == {}
+    prof.shutdown()
+    prof.close()
+
+    mgr = CuptiManager(statsMaxLenPerKernel=16)
+    with pytest.raises(RuntimeError, match="not initialized"):
+        mgr.start_profiling()
+    mgr.initialize()
+    with pytest.raises(RuntimeError, match="No active profiling run."):
+        mgr.stop_profiling()
+    mgr.start_profiling("outer")
+    mgr.start_profiling("inner")  # nested: only the outermost pair records
+    x @ x
+    mgr.stop_profiling()
+    mgr.stop_profiling()
+    res = mgr.get_results()
+    assert list(res.keys()) == ["outer"] and res["outer"].num_calls == 1
+    mgr.reset_results()
+    assert mgr.get_results() == {}
+    mgr.shutdown()

@@ -1,0 +1,190 @@
+"""GPU parity of the statistics kernel and the device rings against the CPU oracle and the golden
+vectors from the real reference.  All calls go through the C ABI (ctypes)."""
+import ctypes
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import oracle
+from util import close, load_golden
+
+pytestmark = pytest.mark.gpu
+
+STATS = ("MIN", "MAX", "MED", "AVG", "STD", "NUM")
+
+
+@pytest.fixture(scope="module")
+def be():
+    from nvrx_straggler.backend import get_backend
+
+    return get_backend()
+
+
+def _run(be, samples, counts, kinds=None):
+    s = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float32)).cuda()
+    c = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int32)).cuda()
+    k = torch.from_numpy(np.ascontiguousarray(kinds, dtype=np.uint8)).cuda() if kinds is not None else None
+    return be.row_stats(s, c, k).cpu().numpy()
+
+
+def _check_against_oracle(got, samples, counts, kinds, tag=""):
+    exp = oracle.rows_stats(samples, counts, kinds)
+    for r in range(samples.shape[0]):
+        n = int(counts[r])
+        kind = int(kinds[r]) if kinds is not None else 0
+        if n == 0:
+            assert np.isnan(got[r, :5]).all() and got[r, 5] == 0, (tag, r)
+            continue
+        # selections: bit-exact on the f32 samples
+        assert got[r, 0] == np.float32(exp[r, 0]), (tag, r, "MIN")
+        assert got[r, 1] == np.float32(exp[r, 1]), (tag, r, "MAX")
+        assert got[r, 2] == np.float32(exp[r, 2]), (tag, r, "MED", n, kind, got[r, 2], exp[r, 2])
+        assert got[r, 5] == n
+        # accumulations: f64 on the device, rounded to f32 on output.  The reference's kernel-row
+        # path accumulates sequentially in f32 (CuptiProfiler.cpp:63-69) and is itself only accurate
+        # to ~n*eps, hence the looser bound for kind 1.
+        tol = 1e-6 if kind == 0 else 2e-4
+        assert close(got[r, 3], exp[r, 3], rel=tol, abs_=1e-30), (tag, r, "AVG", got[r, 3], exp[r, 3])
+        if n > 1 or kind == 1:
+            assert close(got[r, 4], exp[r, 4], rel=max(tol, 2e-6), abs_=1e-6 * abs(exp[r, 3]) + 1e-30), (tag, r, "STD", got[r, 4], exp[r, 4])
+        else:
+            assert np.isnan(got[r, 4])
+
+
+def _golden_matrix():
+    cases = synth.section_stat_cases()
+    kept = [synth.retained(c["values"]) for c in cases]
+    stride = 8192
+    m = np.zeros((len(kept), stride), dtype=np.float32)
+    counts = np.zeros(len(kept), dtype=np.uint32)
+    for i, v in enumerate(kept):
+        m[i, : v.size] = v
+        counts[i] = v.size
+    return cases, m, counts
+
+
+def test_section_rows_match_reference_golden(be):
+    """kind 0 vs outputs of the reference's Detector._get_section_summaries (section_stats.json)."""
+    cases, m, counts = _golden_matrix()
+    got = _run(be, m, counts)
+    g = {c["name"]: c for c in load_golden("section_stats.json")["cases"]}
+    for i, c in enumerate(cases):
+        e = g[c["name"]]["expected"]
+        assert got[i, 0] == np.float32(e["MIN"]) and got[i, 1] == np.float32(e["MAX"])
+        assert got[i, 2] == np.float32(e["MED"]), (c["name"], got[i, 2], e["MED"])
+        assert got[i, 5] == e["NUM"]
+        assert close(got[i, 3], e["AVG"], rel=1e-6), c["name"]
+        assert close(got[i, 4], e["STD"], rel=2e-6, abs_=1e-6 * abs(e["AVG"])), (c["name"], got[i, 4], e["STD"])
+    _check_against_oracle(got, m, counts, None, "golden-k0")
+
+
+def test_kernel_rows_match_reference_golden(be):
+    """kind 1 vs outputs of the reference's computeStats (native.json)."""
+    cases, m, counts = _golden_matrix()
+    kinds = np.ones(len(cases), dtype=np.uint8)
+    # computeStats golden was taken on the full pushed vectors; rings hold the newest 8192
+    got = _run(be, m, counts, kinds)
+    g = {c["name"]: c for c in load_golden("native.json")["compute_stats"]}
+    for i, c in enumerate(cases):
+        if c["values"].size > 8192:
+            continue
+        e = g[c["name"]]["expected"]
+        assert got[i, 0] == np.float32(e[0]) and got[i, 1] == np.float32(e[1])
+        assert got[i, 2] == np.float32(e[2]), (c["name"], "median", got[i, 2], e[2])
+        assert got[i, 5] == e[5]
+        assert close(got[i, 3], e[3], rel=2e-4), (c["name"], "avg", got[i, 3], e[3])
+        assert close(got[i, 4], e[4], rel=2e-3, abs_=2e-4 * abs(e[3])), (c["name"], "std", got[i, 4], e[4])
+    _check_against_oracle(got, m, counts, kinds, "golden-k1")
+
+
+@pytest.mark.parametrize("stride", [4, 8, 64, 256, 1000, 1024, 2048, 3072, 4096, 5000, 8192, 10000, 16384, 20480, 32768, 65536])
+def test_random_rows_every_launch_shape(be, stride):
+    """Ragged counts (0, 1, 2, odd, even, full) x both kinds for every register-tile variant."""
+    rng = np.random.default_rng(stride)
+    rows = 24
+    m = rng.lognormal(1.0, 0.8, (rows, stride)).astype(np.float32)
+    m[3] = np.round(m[3], 1)  # heavy duplicates
+    m[4] = 42.0  # all equal
+    m[5, ::7] *= 1e4  # outliers stretch the key range
+    m[6] = -m[6]  # negative values order correctly
+    counts = rng.integers(0, stride + 1, rows).astype(np.uint32)
+    counts[:8] = [stride, max(stride - 1, 0), 1, stride, stride, stride, stride, 2]
+    counts[8] = 0
+    kinds = (np.arange(rows) % 2).astype(np.uint8)
+    got = _run(be, m, counts, kinds)
+    _check_against_oracle(got, m, counts, kinds, f"stride{stride}")
+
+
+def test_stress_shape_512_rows_x_10000(be):
+    """The folded N=1 workload (8 ranks x 64 sections x 10 000 samples): exact medians for all rows."""
+    m = np.concatenate([synth.stress_samples(r, 64, 10_000) for r in range(8)], axis=0)
+    counts = np.full(512, 10_000, dtype=np.uint32)
+    got = _run(be, m, counts)
+    _check_against_oracle(got, m, counts, None, "stress")
+    # size-independent property: statistics are permutation invariant
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(10_000)
+    got2 = _run(be, m[:, perm], counts)
+    assert np.array_equal(got[:, :3], got2[:, :3]) and np.array_equal(got[:, 5], got2[:, 5])
+    assert np.allclose(got[:, 3:5], got2[:, 3:5], rtol=1e-6)
+
+
+def test_linearity_and_shift_properties(be):
+    """median(a*x) == a*median(x) for power-of-two a (exact in f32); min<=med<=max; std>=0."""
+    rng = np.random.default_rng(9)
+    m = rng.normal(10, 0.3, (16, 8192)).astype(np.float32)
+    counts = np.full(16, 8192, dtype=np.uint32)
+    a = _run(be, m, counts)
+    b = _run(be, m * np.float32(4.0), counts)
+    assert np.array_equal(a[:, :3] * 4.0, b[:, :3])
+    assert (a[:, 0] <= a[:, 2]).all() and (a[:, 2] <= a[:, 1]).all() and (a[:, 4] >= 0).all()
+
+
+def test_bad_arguments_are_rejected(be):
+    from nvrx_straggler import _native
+
+    lib = _native.load()
+    x = torch.zeros(16, device="cuda")
+    c = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = torch.zeros(8, device="cuda")
+    assert lib.nvrx_row_stats(x.data_ptr(), c.data_ptr(), None, 1, 6, out.data_ptr(), None) == -22
+    assert b"multiple of 4" in lib.nvrx_last_error()
+    assert lib.nvrx_row_stats(None, c.data_ptr(), None, 1, 8, out.data_ptr(), None) == -22
+    big = 65536 + 4
+    assert lib.nvrx_row_stats(x.data_ptr(), c.data_ptr(), None, 1, big, out.data_ptr(), None) == -34
+    ctx = ctypes.c_void_p()
+    assert lib.nvrx_ctx_create(0, 1, 4, 70000, ctypes.byref(ctx)) == -34
+    assert lib.nvrx_ctx_create(99, 1, 4, 64, ctypes.byref(ctx)) == -22
+
+
+@pytest.mark.parametrize("cap,n", [(7, 21), (4, 3), (4, 4), (4, 5), (32, 100), (8192, 10000), (100, 1000)])
+def test_ring_overwrite_oldest_matches_reference(be, cap, n):
+    """Device ring == reference CircularBuffer / deque(maxlen): newest `cap` samples survive."""
+    rings = be.make_rings(1, 2, cap)
+    try:
+        vals = (np.arange(n, dtype=np.float32) * 0.5 + 1.0)
+        row = rings.row_for(0, "a")
+        for v in vals[: n // 2]:
+            rings.push(row, float(v))
+        rings.push_many(row, vals[n // 2 :])
+        assert rings.count(row) == min(n, cap)
+        stored = rings.read_row(row)[: min(n, cap)]
+        exp = oracle.ring_run(vals, cap)
+        assert sorted(stored.tolist()) == sorted(exp.tolist())
+        stats = rings.peek_stats()[row]
+        e = oracle.section_stats(exp.astype(np.float64))
+        assert stats[2] == np.float32(e[2]) and stats[5] == exp.size
+        # device-side append continues the same ring
+        extra = torch.arange(5, dtype=torch.float32, device="cuda") + 1000.0
+        rings.push_device(row, extra)
+        exp2 = oracle.ring_run(np.concatenate([vals, extra.cpu().numpy()]), cap)
+        stored2 = rings.read_row(row)[: exp2.size]
+        assert sorted(stored2.tolist()) == sorted(exp2.tolist())
+        rings.reset()
+        assert rings.count(row) == 0
+        assert np.isnan(rings.peek_stats()[row][2])
+    finally:
+        rings.close()
