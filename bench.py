@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Benchmark of the straggler-scoring hot path on MI355X: generate_report() latency.
+
+Workload (BASELINE.json, metric "generate_report() us ... 8 ranks x 64 sections x 10k samples"):
+8 logical ranks x 64 sections x 10 000 f32 timing samples per report, ring capacity 10 000 on both
+sides, relative + individual scores, gather_on_rank0.  With N GPUs each process holds 8/N logical
+ranks (strong scaling, total work fixed); N=1 folds the whole job onto one GPU (512 rows, 20.48 MB),
+N=8 is the production shape (one rank per GPU, 2.56 MB each).  A "step" is one collective
+generate_report(): re-arm resident samples -> flush (scatter kernel) -> statistics kernel -> one
+all-gather of the exchange rows (RCCL when N>1) -> score kernel -> one D2H of the results, host
+waits.  Inputs are resident in HBM before the timed region starts.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
+  roofline     -- the statistics kernel (k_row_stats) against the HBM roofline: algorithmic bytes =
+                  local_ranks * 64 * 10000 * 4 per launch, duration from hipEvent pairs recorded
+                  around every launch on the launch stream during a second, instrumented pass of the
+                  same K steps (the headline pass runs without the extra event records).
+  cpu_baseline -- the reference's CPU path restated in Python (oracle/, kind "port"), timed on this
+                  host: one rank's 64 x 10000 samples from Python deques -> torch.tensor + 5 torch
+                  reductions per section, + dict scoring; 1 core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "nvidia-resiliency-ext_amd"), os.path.join(REPO, "tests", "golden")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TOTAL_RANKS = 8
+SECTIONS = 64
+SAMPLES = 10_000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def _cpu_baseline(reps: int):
+    """Reference CPU path, restated (oracle.ref_port_*), on a bounded sample; rank 0, N=1 only."""
+    import collections
+
+    import synth
+    from oracle import oracle
+
+    torch.set_num_threads(1)
+    x = synth.stress_samples(0, SECTIONS, SAMPLES)
+    # the reference holds Python floats in deques (straggler.py:80-83, :343)
+    deques = {synth.section_name(s): collections.deque(x[s].astype(np.float64).tolist(), maxlen=SAMPLES) for s in range(SECTIONS)}
+    t_sum = []
+    summ = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        summ = oracle.ref_port_section_summaries(deques)
+        t_sum.append(time.perf_counter() - t0)
+    per_rank = [{n: dict(v) for n, v in summ.items()} for _ in range(TOTAL_RANKS)]
+    port = oracle.RefPortReportGenerator(TOTAL_RANKS)
+    t_sc = []
+    for _ in range(max(reps, 5)):
+        t0 = time.perf_counter()
+        port.generate_reports(per_rank, [{} for _ in range(TOTAL_RANKS)])
+        t_sc.append(time.perf_counter() - t0)
+    # C oracle (sorted-copy statistics) for information
+    counts = np.full(SECTIONS, SAMPLES, dtype=np.uint32)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        oracle.rows_stats(x, counts)
+    t_c = (time.perf_counter() - t0) / 5
+    summaries_us = float(np.median(t_sum)) * 1e6
+    scoring_us = float(np.median(t_sc)) * 1e6 / TOTAL_RANKS
+    return {
+        "value": round(summaries_us + scoring_us, 1),
+        "unit": "us",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"1 rank x {SECTIONS} sections x {SAMPLES} samples from Python deques: torch.tensor + 5 torch reductions "
+                  f"per section (median of {reps} reps) + dict scoring of {TOTAL_RANKS} simulated ranks / {TOTAL_RANKS}; "
+                  "no collectives",
+        "summaries_us": round(summaries_us, 1),
+        "scoring_us_per_rank": round(scoring_us, 1),
+        "c_oracle_stats_us": round(t_c * 1e6, 1),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def _pmc_traffic(local_ranks: int):
+    """HBM bytes per k_row_stats launch from the committed rocprofv3 PMC summary, if one exists for
+    this shape (collected in its own run; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM)."""
+    path = os.path.join(REPO, "profiles", "pmc_row_stats.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get(str(local_ranks), {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cpu-reps", type=int, default=60)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if TOTAL_RANKS % world:
+        raise SystemExit(f"--gpus must divide {TOTAL_RANKS}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import synth
+    from nvrx_straggler.folded import FoldedJob
+
+    job = FoldedJob(total_ranks=TOTAL_RANKS, section_names=[synth.section_name(s) for s in range(SECTIONS)],
+                    ring_cap=SAMPLES, node_name=f"node{rank}")
+    for lr, r in enumerate(job.logical_ranks()):
+        job.load(lr, synth.stress_samples(r, SECTIONS, SAMPLES, slow_rank=3, slow_factor=1.5))
+    torch.cuda.synchronize()
+
+    def step():
+        job.rearm(SAMPLES)
+        return job.report()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    rep = None
+    for _ in range(args.warmup):
+        rep = step()
+    # correctness guard inside the bench: flagged set of the x1.5 rank at the default threshold
+    if rank == 0:
+        flagged = rep.identify_stragglers()["straggler_sections_relative"]
+        assert len(flagged) == SECTIONS and all({s.rank for s in v} == {3} for v in flagged.values()), "wrong flagged set"
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    # instrumented pass: hipEvent pair around every statistics-kernel launch, on its launch stream
+    job.rings.timing_enable(True)
+    sync_all()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed_instr = time.perf_counter() - t1
+    kern_total_us, kern_launches = job.rings.timing_read(reset=True)
+    job.rings.timing_enable(False)
+
+    times = torch.tensor([elapsed, elapsed_instr], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    elapsed, elapsed_instr = times.tolist()
+
+    if rank == 0:
+        us_per_report = elapsed / args.steps * 1e6
+        kern_us = kern_total_us / max(kern_launches, 1)
+        alg_bytes = job.local_ranks * SECTIONS * SAMPLES * 4
+        achieved = alg_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+        out = {
+            "metric": "generate_report_latency_us",
+            "value": round(us_per_report, 2),
+            "unit": "us",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(us_per_report / 1e3, 5),
+            "higher_is_better": False,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{TOTAL_RANKS} ranks x {SECTIONS} sections x {SAMPLES} samples per report, ring capacity {SAMPLES}, "
+                            "relative+individual scores, gather_on_rank0",
+                "logical_ranks_per_gpu": job.local_ranks,
+                "rows_per_gpu": job.local_ranks * SECTIONS,
+                "exchange": "none (single process)" if world == 1 else f"1 all_gather_into_tensor of {job.local_ranks}x{2 * SECTIONS + 1} f32 per rank (RCCL)",
+                "target_us": 50,
+            },
+            "reports_per_s": round(1e6 / us_per_report, 1),
+            "instrumented_ms_per_step": round(elapsed_instr / args.steps * 1e3, 5),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_row_stats",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": _pmc_traffic(job.local_ranks),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_us_avg": round(kern_us, 3),
+                "launches_timed": kern_launches,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = _cpu_baseline(args.cpu_reps)
+        print(json.dumps(out), flush=True)
+
+    job.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

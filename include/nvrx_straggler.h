@@ -133,6 +133,8 @@ int nvrx_ring_push_many(nvrx_ctx *ctx, int row, const float *values, int n);
 int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, void *stream);
 /* Declare that `row` currently holds n valid samples in its device ring (no data movement). */
 int nvrx_ring_set_count(nvrx_ctx *ctx, int row, int n);
+/* Same for every row of the context at once (benchmark re-arm of resident data). */
+int nvrx_ring_set_count_all(nvrx_ctx *ctx, int n);
 /* Valid samples in `row` (including staged ones), min(total pushed, ring_cap). */
 int nvrx_ring_count(const nvrx_ctx *ctx, int row);
 /* Drop all samples of every row: deque.clear (straggler.py:223-225) / reset (CuptiProfiler.cpp:148-152).

@@ -998,7 +998,24 @@ int nvrx_ring_set_count(nvrx_ctx *ctx, int row, int n) {
     if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
     if (n < 0 || n > ctx->ring_cap) return fail(NVRX_ERR_INVALID, "count %d outside [0,%d]", n, ctx->ring_cap);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    // samples of this row still sitting in the staging buffer belong to the content being replaced:
+    // drop them, otherwise they would land on slots the new content is about to reuse
+    StagedSample *e = ctx->buf[ctx->cur].h_entries;
+    int kept = 0;
+    for (int i = 0; i < ctx->n_staged; i++)
+        if ((int)(e[i].row_slot >> 16) != row) e[kept++] = e[i];
+    ctx->n_staged = kept;
     ctx->total[row] = (uint64_t)n;
+    ctx->counts_dirty = true;
+    return NVRX_OK;
+}
+
+int nvrx_ring_set_count_all(nvrx_ctx *ctx, int n) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (n < 0 || n > ctx->ring_cap) return fail(NVRX_ERR_INVALID, "count %d outside [0,%d]", n, ctx->ring_cap);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->n_staged = 0;
+    std::fill(ctx->total.begin(), ctx->total.end(), (uint64_t)n);
     ctx->counts_dirty = true;
     return NVRX_OK;
 }

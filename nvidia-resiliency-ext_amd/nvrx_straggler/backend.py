@@ -249,6 +249,9 @@ class HipRings:
     def set_count(self, row: int, n: int, lr: int = 0) -> None:
         _native.check(self.lib.nvrx_ring_set_count(self.ctx, lr * self.rows_per_rank + row, n))
 
+    def set_count_all(self, n: int) -> None:
+        _native.check(self.lib.nvrx_ring_set_count_all(self.ctx, n))
+
     def count(self, row: int, lr: int = 0) -> int:
         return _native.check(self.lib.nvrx_ring_count(self.ctx, lr * self.rows_per_rank + row))
 

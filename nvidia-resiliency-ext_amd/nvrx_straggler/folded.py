@@ -53,9 +53,7 @@ class FoldedJob:
 
     def rearm(self, n: int) -> None:
         """Declare every row holds ``n`` resident samples again (after a report emptied the rings)."""
-        for lr in range(self.local_ranks):
-            for row in self.rows.values():
-                self.rings.set_count(row, n, lr=lr)
+        self.rings.set_count_all(n)
 
     def report(self, reset: bool = True):
         rep = self.reporter.generate_report_from_rings(self.rings, self.rows, {}, local_ranks=self.local_ranks)

@@ -1,0 +1,210 @@
+"""CPU checker backend for the host-logic tests -- TEST INFRASTRUCTURE, lives outside the product.
+
+Implements the small backend/rings interface of ``nvrx_straggler.backend`` on top of ``oracle/`` so
+that the Python host side (Detector plumbing, name mapping, exchange protocol, report assembly, PTL
+callback) can be exercised on a box without a GPU, including world_size-2 gloo runs.  It is injected
+with ``nvrx_straggler.backend.set_backend(OracleBackend())``; the product never selects it by itself
+and raises when the HIP engine is unavailable.
+"""
+import contextlib
+import time
+
+import numpy as np
+import torch
+
+from oracle import oracle
+
+STATS_STRIDE = 8
+
+
+def _table_len(K, S):
+    return 2 * (K + S) + K + 1
+
+
+class OracleWorkspace:
+    def __init__(self, R, K, S, local_ranks, stats_rows):
+        self.R, self.K, self.S = R, K, S
+        self.local_ranks = local_ranks
+        self.stats_rows = stats_rows
+        self.L = _table_len(K, S)
+        self.W = 2 + 2 * S
+        self.send = torch.zeros((local_ranks, self.L), dtype=torch.float32)
+        self.table = torch.zeros((R, self.L), dtype=torch.float32) if R != local_ranks else self.send
+        self.send_initialised = False
+        self.stats = np.zeros((stats_rows, STATS_STRIDE), dtype=np.float32)
+        self.meta = np.zeros(4, dtype=np.uint32)
+        self.scores = np.zeros((R, self.W), dtype=np.float32)
+        self.flags = np.zeros((R, self.W), dtype=np.uint8)
+
+    def set_send_row(self, lr, row):
+        self.send[lr].copy_(torch.from_numpy(row))
+        self.send_initialised = True
+
+
+class OracleBackend:
+    name = "oracle-test"
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self._ws = {}
+        self.score_calls = 0
+
+    def stream_context(self):
+        return contextlib.nullcontext()
+
+    @staticmethod
+    def current_stream_handle():
+        return 0
+
+    def synchronize(self):
+        pass
+
+    def workspace(self, R, K, S, local_ranks=1, stats_rows=0):
+        key = (R, K, S, local_ranks, stats_rows)
+        if key not in self._ws:
+            self._ws[key] = OracleWorkspace(R, K, S, local_ranks, stats_rows)
+        return self._ws[key]
+
+    def make_rings(self, local_ranks, rows_per_rank, ring_cap):
+        return OracleRings(self, local_ranks, rows_per_rank, ring_cap)
+
+    def send_init(self, ws):
+        KS = ws.K + ws.S
+        ws.send[:, :KS] = -1.0
+        ws.send[:, KS : 2 * KS] = float("nan")
+        ws.send[:, 2 * KS :] = 0.0
+        ws.send_initialised = True
+
+    def score(self, ws, table, do_indiv, do_rel, thresholds=(0.75,) * 4, wait=True, stats_rows=None):
+        self.score_calls += 1
+        T = table.numpy()
+        ws.scores[:] = oracle.score_table(T, ws.K, ws.S, do_indiv, do_rel)
+        thr = np.concatenate([[thresholds[2], thresholds[0]], np.full(ws.S, thresholds[3]), np.full(ws.S, thresholds[1])])
+        with np.errstate(invalid="ignore"):
+            ws.flags[:] = (ws.scores.astype(np.float64) < thr[None, :]).astype(np.uint8)
+        ws.meta[:] = [int((T[:, -1] > 0).all()), ws.R, ws.K, ws.S]
+
+
+class OracleRings:
+    """NumPy rings with the semantics of the device rings (overwrite-oldest, staged event timing)."""
+
+    def __init__(self, backend, local_ranks, rows_per_rank, ring_cap):
+        self.backend = backend
+        self.local_ranks = local_ranks
+        self.rows_per_rank = rows_per_rank
+        self.ring_cap = ring_cap
+        rows = local_ranks * rows_per_rank
+        self.samples = np.zeros((rows, ring_cap), dtype=np.float32)
+        self.total = np.zeros(rows, dtype=np.int64)
+        self.kinds = np.zeros(rows, dtype=np.uint8)
+        self.gid = np.full(rows, -1, dtype=np.int64)
+        self.hist_min = np.full(rows, np.inf, dtype=np.float32)
+        self.rows_used = 0
+        self.section_row_names = {}
+        self.kernel_row_names = {}
+        self._open = []
+        self._pending = []
+        self.closed = False
+
+    def close(self):
+        self.closed = True
+
+    def alloc_row(self):
+        if self.rows_used >= self.rows_per_rank:
+            raise RuntimeError("straggler rings are full")
+        self.rows_used += 1
+        return self.rows_used - 1
+
+    def row_for(self, kind, name):
+        table = self.kernel_row_names if kind == 1 else self.section_row_names
+        if name not in table:
+            table[name] = self.alloc_row()
+            self.configure(table[name], kind, -1)
+        return table[name]
+
+    def configure(self, row, kind, gid, lr=None):
+        for q in (range(self.local_ranks) if lr is None else (lr,)):
+            self.kinds[q * self.rows_per_rank + row] = kind
+            self.gid[q * self.rows_per_rank + row] = gid
+
+    def push(self, row, value, lr=0):
+        r = lr * self.rows_per_rank + row
+        self.samples[r, self.total[r] % self.ring_cap] = value
+        self.total[r] += 1
+
+    def push_many(self, row, values, lr=0):
+        for v in values:
+            self.push(row, float(v), lr)
+
+    def set_count(self, row, n, lr=0):
+        self.total[lr * self.rows_per_rank + row] = n
+
+    def set_count_all(self, n):
+        self.total[:] = n
+
+    def count(self, row, lr=0):
+        return int(min(self.total[lr * self.rows_per_rank + row], self.ring_cap))
+
+    def reset(self):
+        self.total[:] = 0
+
+    def reset_history(self):
+        self.hist_min[:] = np.inf
+
+    def flush(self):
+        pass
+
+    def event_begin(self, row, stream_handle, lr=0):
+        self._open.append((row, time.perf_counter_ns()))
+
+    def event_end(self, row, stream_handle, lr=0):
+        for i in range(len(self._open) - 1, -1, -1):
+            if self._open[i][0] == row:
+                _, t0 = self._open.pop(i)
+                self._pending.append((row, (time.perf_counter_ns() - t0) * 1e-3))
+                return
+        raise RuntimeError("event_end without event_begin")
+
+    def harvest(self, wait):
+        for row, us in self._pending:
+            self.push(row, us)
+        self._pending.clear()
+        return 0
+
+    def _stats(self):
+        counts = np.minimum(self.total, self.ring_cap).astype(np.uint32)
+        st = oracle.rows_stats(self.samples, counts, self.kinds)
+        out = np.zeros((self.samples.shape[0], STATS_STRIDE), dtype=np.float32)
+        out[:, :6] = st
+        out[:, 6] = np.where(counts > 0, out[:, 5] * out[:, 3], 0.0)
+        return out, counts
+
+    def peek_stats(self):
+        return self._stats()[0]
+
+    def report_local(self, ws, names_ok, rows_active=0):
+        if not ws.send_initialised:
+            self.backend.send_init(ws)
+        st, counts = self._stats()
+        ws.stats[: st.shape[0]] = st[: ws.stats.shape[0]]
+        K, KS, L = ws.K, ws.K + ws.S, ws.L
+        send = ws.send.numpy()
+        active = rows_active or self.rows_per_rank
+        for lr in range(self.local_ranks):
+            for row in range(active):
+                r = lr * self.rows_per_rank + row
+                if counts[r] and st[r, 2] < self.hist_min[r]:
+                    self.hist_min[r] = st[r, 2]
+                g = int(self.gid[r])
+                if 0 <= g < KS:
+                    send[lr, g] = st[r, 2] if counts[r] else -1.0
+                    send[lr, KS + g] = self.hist_min[r] if counts[r] else np.nan
+                    if g < K:
+                        send[lr, 2 * KS + g] = st[r, 6]
+            send[lr, L - 1] = 1.0 if names_ok else 0.0
+
+    def timing_enable(self, on):
+        pass
+
+    def timing_read(self, reset=True):
+        return 0.0, 0

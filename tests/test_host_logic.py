@@ -1,0 +1,359 @@
+"""CPU-only tests of the host side: C-ABI surface, loud failure without a GPU, name mapping, report
+views, and the multi-rank protocol on gloo (world_size 2/4/8) with the oracle-backed checker backend
+injected.  Expected values come from the REAL reference (tests/golden/scoring.json)."""
+import math
+import os
+import pickle
+import re
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import workers
+from mp_util import run_ranks
+from util import close, load_golden
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# --------------------------------------------------------------------------------------------------
+# C ABI
+# --------------------------------------------------------------------------------------------------
+def test_library_exports_every_symbol_in_the_header():
+    from nvrx_straggler import _native
+
+    header = open(os.path.join(REPO, "include", "nvrx_straggler.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*(nvrx_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 25
+    lib = _native.load()  # loads without a GPU; resolves every name in _native.SYMBOLS
+    bound = {name for name, _, _ in _native.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.nvrx_abi_version() == 1
+    assert lib.nvrx_last_error() is not None
+
+
+def test_abi_argument_validation_without_a_gpu():
+    """Pure argument checks return -EINVAL before any HIP call."""
+    from nvrx_straggler import _native
+
+    lib = _native.load()
+    assert lib.nvrx_row_stats(None, None, None, 1, 6, None, None) == -22
+    assert b"multiple of 4" in lib.nvrx_last_error()
+    assert lib.nvrx_score(None, 0, 0, 0, 1, 1, None, None, None, None, None) == -22
+    assert lib.nvrx_ctx_destroy(None) == 0
+    assert lib.nvrx_ring_push(None, 0, 1.0) == -22
+    with pytest.raises(_native.NativeError, match="ctx is null"):
+        _native.check(lib.nvrx_ring_flush(None, None))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box WITHOUT a GPU")
+def test_product_fails_loudly_without_gpu():
+    """No silent CPU path: without an MI355X the engine refuses to start."""
+    from nvrx_straggler import Detector, backend
+
+    backend.set_backend(None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        backend.get_backend()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Detector.initialize()
+    assert Detector.initialized is False
+    with pytest.raises(RuntimeError, match="Detector is not initialized."):
+        with Detector.detection_section("x"):
+            pass
+    with pytest.raises(RuntimeError, match="should not be instantiated"):
+        Detector()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "nvidia-resiliency-ext_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "oracle_backend" not in text, f
+
+
+# --------------------------------------------------------------------------------------------------
+# small host-side units
+# --------------------------------------------------------------------------------------------------
+def test_import_paths_and_exports():
+    import nvrx_straggler
+    from nvidia_resiliency_ext.attribution import straggler
+    import nvidia_resiliency_ext.straggler as old_path
+
+    assert straggler is nvrx_straggler and old_path is nvrx_straggler
+    for name in ("Report", "StragglerId", "Statistic", "CallableId", "Detector"):
+        assert hasattr(straggler, name)
+    assert straggler.reporting.ReportGenerator and straggler.interval_tracker.ReportIntervalTracker
+    assert straggler.cupti.CuptiManager
+    assert [str(s) for s in straggler.Statistic] == ["MIN", "MAX", "MED", "AVG", "STD", "NUM"]
+    assert repr(straggler.Statistic.MED) == "Statistic.MED"
+    import dataclasses
+
+    assert [f.name for f in dataclasses.fields(straggler.Report)] == [
+        "gpu_relative_perf_scores", "section_relative_perf_scores", "gpu_individual_perf_scores",
+        "section_individual_perf_scores", "rank_to_node", "local_section_summaries", "local_kernel_summaries",
+        "generate_report_elapsed_time", "gather_on_rank0", "rank"]
+
+
+def test_callable_id_naming_rules():
+    import nvrx_straggler as s
+
+    class Foo:
+        def bar(self):
+            pass
+
+    assert str(s.CallableId(Foo(), "bar")) == "Foo.bar"
+    assert str(s.CallableId(Foo, "bar")) == f"{Foo.__module__}.Foo.bar"
+    assert str(s.CallableId(math, "sqrt")) == "math.sqrt"
+
+
+def test_name_mapper_ids_are_stable_and_consecutive():
+    from nvrx_straggler.name_mapper import NameMapper
+
+    m = NameMapper()
+    m.gather_and_assign_ids(kernel_names=["k1", "k0"], section_names=["s0"])
+    assert m.kernel_name_to_id == {"k1": 0, "k0": 1} and m.section_name_to_id == {"s0": 0}
+    m.gather_and_assign_ids(kernel_names=["k0", "k2"], section_names=["s1", "s0"])
+    assert m.kernel_name_to_id == {"k1": 0, "k0": 1, "k2": 2} and m.section_name_to_id == {"s0": 0, "s1": 1}
+    assert m.get_kernel_name(2) == "k2" and m.get_section_id("s1") == 1 and m.kernel_counter == 3
+    v = m.version
+    m.gather_and_assign_ids(kernel_names=["k0"], section_names=[])
+    assert m.version == v
+    pickle.loads(pickle.dumps(m))
+
+
+def test_report_views_and_flag_paths_agree():
+    from nvrx_straggler.reporting import RankScores, Report, SectionScores, StragglerId, _DeviceFlags
+
+    scores = np.array([[np.nan, 1.0, 1.0, 0.5, 1.0, 0.7], [np.nan, 0.6, 0.8, np.nan, 0.74, 0.9]], dtype=np.float32)
+    S = 2
+    ranks = range(2)
+    names = ["a", "b"]
+    rep = Report(RankScores(ranks, scores[:, 1]), SectionScores(names, [0, 1], ranks, scores[:, 4:6]),
+                 RankScores(ranks, scores[:, 0]), SectionScores(names, [0, 1], ranks, scores[:, 2:4]),
+                 {0: "n0", 1: "n1"}, {}, {}, 0.1, True, 0)
+    assert rep.gpu_relative_perf_scores == {0: 1.0, 1: np.float32(0.6)}
+    assert len(rep.section_relative_perf_scores) == 2 and list(rep.section_relative_perf_scores["a"]) == [0, 1]
+    assert math.isnan(rep.section_individual_perf_scores["b"][1])
+    with pytest.raises(KeyError):
+        rep.gpu_relative_perf_scores[5]
+    s1 = rep.identify_stragglers()
+    assert s1["straggler_gpus_relative"] == {StragglerId(1, "n1")}
+    assert s1["straggler_gpus_individual"] == set()  # NaN never flagged
+    assert s1["straggler_sections_relative"] == {"a": {StragglerId(1, "n1")}, "b": {StragglerId(0, "n0")}}
+    assert s1["straggler_sections_individual"] == {"b": {StragglerId(0, "n0")}}
+    # device-flag path gives the same answer as the comparison path
+    thr = np.array([0.75, 0.75, 0.75, 0.75, 0.75, 0.75])
+    with np.errstate(invalid="ignore"):
+        flags = (scores.astype(np.float64) < thr).astype(np.uint8)
+    object.__setattr__(rep, "_device_flags", _DeviceFlags((0.75,) * 4, flags, ranks, names, [0, 1], S, True, True))
+    assert rep.identify_stragglers() == s1
+    assert rep.identify_stragglers(0.65, 0.65, 0.65, 0.65)["straggler_sections_relative"] == {}
+    back = pickle.loads(pickle.dumps(rep))  # travels through mp queues as plain dicts
+    assert back.gpu_relative_perf_scores == {0: 1.0, 1: np.float32(0.6)} and back.identify_stragglers() == s1
+    # plain-dict reports (user constructed) work too
+    plain = Report({0: 0.5}, {"s": {0: 0.9}}, {}, {}, {0: "n"}, {}, {}, 0.0, False, 0)
+    assert plain.identify_stragglers()["straggler_gpus_relative"] == {StragglerId(0, "n")}
+
+
+def test_cupti_manager_refcount_with_fake_native_module(monkeypatch):
+    """Manager logic is backend-independent (reference: tests/straggler/unit/test_cupti_manager.py)."""
+    from nvrx_straggler import backend
+    from nvrx_straggler.cupti import CuptiManager
+    from oracle_backend import OracleBackend
+
+    backend.set_backend(OracleBackend())
+    try:
+        mgr = CuptiManager(statsMaxLenPerKernel=8)
+        with pytest.raises(RuntimeError, match="CuptiManager was not initialized"):
+            mgr.start_profiling()
+        mgr.initialize()
+        with pytest.raises(RuntimeError, match="No active profiling run."):
+            mgr.stop_profiling()
+        mgr.start_profiling("outer")
+        mgr.start_profiling("inner")
+        assert mgr.started_cnt == 2
+        mgr.stop_profiling()
+        mgr.stop_profiling()
+        res = mgr.get_results()
+        assert list(res) == ["outer"] and res["outer"].num_calls == 1
+        import nvrx_cupti_module
+
+        with pytest.raises(RuntimeError, match="Only one CuptiProfiler instance is allowed."):
+            nvrx_cupti_module.CuptiProfiler()
+        mgr.reset_results()
+        assert mgr.get_results() == {}
+        mgr.shutdown()
+        nvrx_cupti_module.CuptiProfiler().close()  # slot released by shutdown
+    finally:
+        backend.set_backend(None)
+
+
+def test_interval_tracker_single_process():
+    from nvrx_straggler.interval_tracker import ReportIntervalTracker
+
+    tr = ReportIntervalTracker(time_interval=0.1, profiling_interval=1)
+    assert not tr.is_interval_elapsed()
+    for i in range(18):
+        tr.iter_increase()
+        time.sleep(0.002 if i else 0.05)  # a warm-up outlier must not matter (median)
+    assert tr.iter_interval is not None and 15 <= tr.iter_interval <= 60
+    tr2 = ReportIntervalTracker(time_interval=1e-9, profiling_interval=7)
+    for _ in range(18):
+        tr2.iter_increase()
+    assert tr2.iter_interval == 7  # floored at the profiling interval
+    tr2.current_iter = 14
+    assert tr2.is_interval_elapsed()
+
+
+class _FakeStrategy:
+    def training_step(self, batch):
+        time.sleep(0.001)
+        return batch
+
+
+class _FakeTrainer:
+    def __init__(self):
+        self.strategy = _FakeStrategy()
+        self.global_rank = 0
+        self.should_stop = False
+        self.checkpoint_callback = None
+
+
+class _FakeModule:
+    def __init__(self):
+        self.logged = []
+
+    def log_dict(self, d, **kw):
+        self.logged.append(d)
+
+
+def test_ptl_callback_with_duck_typed_trainer(caplog):
+    from nvidia_resiliency_ext.ptl_resiliency import StragglerDetectionCallback
+    from nvrx_straggler import Detector, backend
+    from oracle_backend import OracleBackend
+
+    with pytest.raises(ValueError, match="No straggler performance scores specified"):
+        StragglerDetectionCallback(1.0, False, False, 0, 0.7, 0.7, False, False)
+    backend.set_backend(OracleBackend())
+    cb = StragglerDetectionCallback(report_time_interval=0.02, calc_relative_gpu_perf=True, calc_individual_gpu_perf=True,
+                                    num_gpu_perf_scores_to_print=2, gpu_relative_perf_threshold=0.7,
+                                    gpu_individual_perf_threshold=0.7, stop_if_detected=True, enable_ptl_logging=True,
+                                    logger_name="test.straggler")
+    trainer, module = _FakeTrainer(), _FakeModule()
+    try:
+        import logging
+
+        caplog.set_level(logging.INFO, logger="test.straggler")
+        cb.setup(trainer, module, "fit")
+        assert Detector.initialized
+        for i in range(60):
+            trainer.strategy.training_step(i)
+            cb.on_train_batch_end(trainer, module, None, None, i)
+        assert Detector.report_interval_tracker.iter_interval is not None
+        assert "Trainer" not in Detector.custom_sections and "_FakeStrategy.training_step" in Detector.custom_sections
+        assert any("Straggler report processing time" in r.message for r in caplog.records)
+        assert any("GPU relative performance" in r.message for r in caplog.records)
+        assert module.logged and "gpu_relative_perf/median" in module.logged[0]
+        assert trainer.should_stop is False
+    finally:
+        cb.teardown(trainer, module, "fit")
+        backend.set_backend(None)
+    assert not Detector.initialized
+    txt = StragglerDetectionCallback._format_gpu_scores({r: 1.0 - 0.1 * r for r in range(8)}, {r: f"n{r}" for r in range(8)}, 2, 2)
+    assert "Worst performing 2/8 ranks" in txt and "Rank=7 Node=n7 Score=0.30" in txt and "Best performing 2/8" in txt
+
+
+# --------------------------------------------------------------------------------------------------
+# multi-rank protocol on gloo, against the reference's golden outputs
+# --------------------------------------------------------------------------------------------------
+def _compare_reports(got, exp, tag, rel=1e-6):
+    if exp is None:
+        assert got is None, tag
+        return
+    assert got is not None, tag
+    for key in ("gpu_relative_perf_scores", "gpu_individual_perf_scores"):
+        assert set(map(str, got[key].keys())) == set(exp[key].keys()), (tag, key)
+        for r, v in got[key].items():
+            assert close(v, exp[key][str(r)], rel=rel), (tag, key, r, v, exp[key][str(r)])
+    for key in ("section_relative_perf_scores", "section_individual_perf_scores"):
+        assert set(got[key].keys()) == set(exp[key].keys()), (tag, key, got[key].keys(), exp[key].keys())
+        for n, per_rank in got[key].items():
+            assert set(map(str, per_rank.keys())) == set(exp[key][n].keys()), (tag, key, n)
+            for r, v in per_rank.items():
+                assert close(v, exp[key][n][str(r)], rel=rel), (tag, key, n, r, v, exp[key][n][str(r)])
+    assert {str(k): v for k, v in got["rank_to_node"].items()} == exp["rank_to_node"], tag
+    assert got["gather_on_rank0"] == exp["gather_on_rank0"] and got["rank"] == exp["rank"]
+    for thr, e in exp.get("stragglers", {}).items():
+        assert got["stragglers"][thr] == e, (tag, thr)
+
+
+_SCENARIOS = load_golden("scoring.json")["scenarios"]
+
+
+@pytest.mark.parametrize("idx", range(len(_SCENARIOS)), ids=[s["scenario"]["name"] for s in _SCENARIOS])
+def test_report_generator_matches_reference_on_gloo_ranks(idx):
+    """Our ReportGenerator (host logic + one all-gather + table scoring) replays every scenario the
+    real reference was run on; scores within f32 rounding, NaN positions, key sets, rank_to_node,
+    name ids and flagged sets identical."""
+    g = _SCENARIOS[idx]
+    sc = g["scenario"]
+    res = run_ranks(workers.scoring_scenario, sc["world_size"], scenario=sc)
+    for r in range(sc["world_size"]):
+        for t in range(len(sc["steps"])):
+            _compare_reports(res[r]["reports"][t], g["per_rank"][r]["reports"][t], (sc["name"], r, t))
+        assert res[r]["ids"] == g["per_rank"][r]["ids"], (sc["name"], r)
+
+
+def test_all_gather_object_only_when_names_change():
+    counts = run_ranks(workers.gather_object_call_counts, 2, n_kernels=256)
+    assert counts[0] == [2, 0, 1, 0, 1] and counts[1] == [2, 0, 1, 0, 1]
+
+
+def test_detector_plumbing_two_gloo_ranks_sleep_sections():
+    """BASELINE config #1: 2 CPU ranks, Detector wrapping 2 time.sleep sections, relative scores on
+    rank 0; the slow rank's section is flagged at the default threshold."""
+    res = run_ranks(workers.detector_sleep_sections, 2, slow_rank=1, iters=20)
+    assert res[1]["report"] is None
+    rep = res[0]["report"]
+    assert set(rep["section_relative_perf_scores"].keys()) == {"section_a", "section_b"}
+    assert rep["section_relative_perf_scores"]["section_b"][1] == pytest.approx(0.5, abs=0.12)
+    assert rep["section_relative_perf_scores"]["section_a"][1] > 0.8
+    assert rep["section_relative_perf_scores"]["section_b"][0] == pytest.approx(1.0, abs=1e-6)
+    assert rep["stragglers"]["0.75"]["straggler_sections_relative"] == {"section_b": [1]}
+    assert rep["stragglers"]["0.75"]["straggler_gpus_relative"] == []
+    assert rep["rank_to_node"] == {0: "host0", 1: "host1"}
+    assert res[0]["n_after"] == 0 and res[0]["names"] == {0: "section_a", 1: "section_b"} == res[1]["names"]
+
+
+def test_wrap_callables_two_ranks():
+    res = run_ranks(workers.detector_wrap_callables, 2)
+    for r in range(2):
+        assert res[r]["names"] == ["Trainer.training_step"] and res[r]["num"] == 3 and res[r]["after_restore"] == 0
+        assert list(res[r]["rel"].keys()) == [r]
+    assert res[0]["rel"][0] == pytest.approx(1.0, abs=1e-6) and res[1]["rel"][1] == pytest.approx(0.5, abs=0.15)
+
+
+def test_folded_job_over_two_gloo_ranks():
+    """N>1 path of bench.py: 8 logical ranks over 2 processes, one all-gather of 4 rows per process."""
+    res = run_ranks(workers.folded_job_gloo, 2, total_ranks=8, sections=4, n=200)
+    assert res[1] is None
+    rep = res[0]
+    assert sorted(rep["section_relative_perf_scores"]["section_000"].keys()) == list(range(8))
+    for name, scores in rep["section_relative_perf_scores"].items():
+        assert scores[3] == pytest.approx(1 / 1.5, rel=0.02)
+        assert all(scores[r] > 0.97 for r in range(8) if r != 3)
+    assert all(v == [3] for v in rep["stragglers"]["0.75"]["straggler_sections_relative"].values())
+    assert len(rep["stragglers"]["0.75"]["straggler_sections_relative"]) == 4
+    assert rep["rank_to_node"] == {r: f"node{r // 4}" for r in range(8)}
+
+
+def test_interval_tracker_ranks_agree():
+    res = run_ranks(workers.interval_tracker_agreement, 2)
+    assert res[0] == res[1] and res[0] >= 1

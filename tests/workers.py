@@ -1,0 +1,152 @@
+"""Worker functions for the multi-process CPU tests (must be importable by spawned processes)."""
+import time
+from unittest import mock
+
+import numpy as np
+
+
+def _summ(d):
+    from nvrx_straggler import Statistic as S
+
+    key = {"MIN": S.MIN, "MAX": S.MAX, "MED": S.MED, "AVG": S.AVG, "STD": S.STD, "NUM": S.NUM}
+    return {n: {key[k]: v for k, v in s.items()} for n, s in d.items()}
+
+
+def report_to_plain(rep, thresholds=(0.75,)):
+    if rep is None:
+        return None
+    out = {
+        "gpu_relative_perf_scores": dict(rep.gpu_relative_perf_scores),
+        "section_relative_perf_scores": {k: dict(v) for k, v in rep.section_relative_perf_scores.items()},
+        "gpu_individual_perf_scores": dict(rep.gpu_individual_perf_scores),
+        "section_individual_perf_scores": {k: dict(v) for k, v in rep.section_individual_perf_scores.items()},
+        "rank_to_node": dict(rep.rank_to_node),
+        "gather_on_rank0": rep.gather_on_rank0,
+        "rank": rep.rank,
+        "stragglers": {},
+    }
+    for thr in thresholds:
+        s = rep.identify_stragglers(thr, thr, thr, thr)
+        out["stragglers"][str(thr)] = {
+            "straggler_gpus_relative": sorted(x.rank for x in s["straggler_gpus_relative"]),
+            "straggler_gpus_individual": sorted(x.rank for x in s["straggler_gpus_individual"]),
+            "straggler_sections_relative": {k: sorted(x.rank for x in v) for k, v in s["straggler_sections_relative"].items()},
+            "straggler_sections_individual": {k: sorted(x.rank for x in v) for k, v in s["straggler_sections_individual"].items()},
+        }
+    return out
+
+
+def scoring_scenario(rank, world, scenario):
+    """Replay one golden scenario through OUR ReportGenerator (dict-input path)."""
+    from nvrx_straggler.reporting import ReportGenerator
+
+    gen = ReportGenerator(scenario["scores_to_compute"], gather_on_rank0=scenario["gather_on_rank0"], node_name=f"node{rank}")
+    reports = []
+    for step in scenario["steps"]:
+        sec, ker = step[rank]
+        rep = gen.generate_report(_summ(sec), _summ(ker))
+        reports.append(report_to_plain(rep, scenario.get("thresholds", [0.75])))
+    ids = {"sections": dict(gen.name_mapper.section_name_to_id), "kernels": dict(gen.name_mapper.kernel_name_to_id)}
+    return {"reports": reports, "ids": ids}
+
+
+def gather_object_call_counts(rank, world, n_kernels):
+    """all_gather_object is used only when some rank meets a new name
+    (reference: tests/straggler/unit/test_data_shared.py:69-100 -> 2, 0, 1, 0, 1)."""
+    import torch
+
+    from nvrx_straggler import Statistic as S
+    from nvrx_straggler.reporting import ReportGenerator
+
+    def summ(v):
+        return {S.MIN: v, S.MAX: v, S.MED: v, S.AVG: v, S.STD: 0.0, S.NUM: 3}
+
+    gen = ReportGenerator(["relative_perf_scores", "individual_perf_scores"], gather_on_rank0=True, node_name=f"n{rank}")
+    counts = []
+    kernels = {f"kernel_{i}_" + "x" * 64: summ(1.0 + i + rank) for i in range(n_kernels)}
+    for round_ in range(5):
+        if round_ == 2:
+            kernels.update({f"late_{i}": summ(2.0 + rank) for i in range(n_kernels)})
+        if round_ == 4 and rank == world - 1:
+            kernels["only_last_rank_sees_this"] = summ(3.0)
+        with mock.patch("torch.distributed.all_gather_object", wraps=torch.distributed.all_gather_object) as m:
+            gen.generate_report({}, kernels)
+            counts.append(m.call_count)
+    return counts
+
+
+def detector_sleep_sections(rank, world, slow_rank, iters):
+    """BASELINE config #1: Detector wrapping time.sleep sections on gloo ranks (plumbing, no GPU)."""
+    from nvrx_straggler import Detector
+
+    Detector.initialize(scores_to_compute=["relative_perf_scores"], gather_on_rank0=True, node_name=f"host{rank}")
+    try:
+        for _ in range(iters):
+            with Detector.detection_section("section_a", profile_cuda=False):
+                time.sleep(0.004)
+            with Detector.detection_section("section_b", profile_cuda=False):
+                time.sleep(0.008 if rank == slow_rank else 0.004)
+        rep = Detector.generate_report()
+        out = report_to_plain(rep)
+        n_after = len(Detector.custom_sections["section_a"].cpu_elapsed_times)
+        names = dict(Detector.reporter.name_mapper.id_to_section_name)
+        return {"report": out, "n_after": n_after, "names": names}
+    finally:
+        Detector.shutdown()
+
+
+def detector_wrap_callables(rank, world):
+    from nvrx_straggler import CallableId, Detector
+
+    class Trainer:
+        def training_step(self, x):
+            time.sleep(0.002 * (rank + 1))
+            return x + 1
+
+    t = Trainer()
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=False, profiling_interval=2)
+    try:
+        Detector.wrap_callables([CallableId(t, "training_step")])
+        for i in range(6):
+            assert t.training_step(i) == i + 1
+        rep = Detector.generate_report()
+        Detector.restore_original_callables()
+        t.training_step(0)
+        rep2 = Detector.generate_report()
+        from nvrx_straggler import Statistic
+
+        return {
+            "names": list(rep.local_section_summaries.keys()),
+            "num": rep.local_section_summaries["Trainer.training_step"][Statistic.NUM],
+            "rel": dict(rep.section_relative_perf_scores["Trainer.training_step"]),
+            "after_restore": len(rep2.local_section_summaries),
+        }
+    finally:
+        Detector.shutdown()
+
+
+def folded_job_gloo(rank, world, total_ranks, sections, n):
+    """FoldedJob across gloo ranks: the all-gather carries local_ranks rows per process."""
+    import synth
+    from nvrx_straggler.folded import FoldedJob
+    from oracle_backend import OracleBackend  # noqa: F401
+
+    names = [synth.section_name(s) for s in range(sections)]
+    job = FoldedJob(total_ranks=total_ranks, section_names=names, ring_cap=n, node_name=f"node{rank}")
+    # CPU backend: feed through the host path
+    for lr, r in enumerate(job.logical_ranks()):
+        x = synth.stress_samples(r, sections, n, slow_rank=3, slow_factor=1.5)
+        for s, name in enumerate(names):
+            job.rings.push_many(job.rows[name], x[s], lr=lr)
+    rep = job.report()
+    return report_to_plain(rep, (0.75, 0.9))
+
+
+def interval_tracker_agreement(rank, world):
+    from nvrx_straggler.interval_tracker import ReportIntervalTracker
+
+    tr = ReportIntervalTracker(time_interval=0.2, profiling_interval=1)
+    for _ in range(20):
+        tr.iter_increase()
+        time.sleep(0.002 * (1 + rank))  # ranks run at different speeds; the MAX must win everywhere
+    return tr.iter_interval
