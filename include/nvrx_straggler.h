@@ -60,7 +60,7 @@ extern "C" {
 /* Score row length: {gpu_indiv, gpu_rel, indiv[S], rel[S]}  (reporting.py:353-360). */
 #define NVRX_SCORE_LEN(S) (2 + 2 * (S))
 /* Number of uint32 words of score-kernel metadata. */
-#define NVRX_META_WORDS 4
+#define NVRX_META_WORDS 8
 
 typedef struct nvrx_ctx nvrx_ctx;
 
@@ -97,13 +97,21 @@ int nvrx_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8
  *      argument order, reporting.py:84-90); NULL => 0.75 each;
  *   d_scores [R][NVRX_SCORE_LEN(S)] f32 out, NaN where the reference reports NaN / nothing;
  *   d_flags  [R][NVRX_SCORE_LEN(S)] u8 out, 1 where score < threshold (strict; NaN never flagged);
- *   d_meta   [NVRX_META_WORDS] u32 out: {all ranks' name flags set, R, K, S}.
+ *   d_meta   [NVRX_META_WORDS] u32 out: {all ranks' name flags set, R, K, S, seq, 0, 0, 0};
+ *   d_done_counter  device word (zero before the first launch) or NULL.  When given, d_scores /
+ *      d_flags / d_meta may point into pinned host memory (nvrx_host_alloc): after every block's
+ *      results are visible system-wide the kernel stores `seq` into d_meta[4] with release
+ *      semantics, so a host thread can wait with nvrx_poll_u32 instead of a stream sync + D2H.
+ *   d_stats_src / d_stats_dst / stats_rows  optional: the kernel also forwards `stats_rows`
+ *      statistics rows (16-byte aligned) from device memory to d_stats_dst (pinned host memory), so
+ *      they arrive with the scores under the same completion word.
  * Replaces _all_reduce_times (reporting.py:255-296), _compute_sections_perf_scores (:196-217),
  * _compute_gpu_perf_score (:219-253), _get_tensor_from_scores/_get_scores_from_tensor (:338-380) and
  * the thresholding of Report.identify_stragglers (:84-151). */
 int nvrx_score(const float *d_table, int R, int K, int S, int do_indiv, int do_rel,
                const double *thresholds, float *d_scores, uint8_t *d_flags, uint32_t *d_meta,
-               void *stream);
+               uint32_t *d_done_counter, uint32_t seq, const float *d_stats_src, float *d_stats_dst,
+               int stats_rows, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Context: device ring buffers + pinned staging + hipEvent timing for `local_ranks` logical ranks
@@ -137,6 +145,8 @@ int nvrx_ring_set_count(nvrx_ctx *ctx, int row, int n);
 int nvrx_ring_set_count_all(nvrx_ctx *ctx, int n);
 /* Valid samples in `row` (including staged ones), min(total pushed, ring_cap). */
 int nvrx_ring_count(const nvrx_ctx *ctx, int row);
+/* Valid-sample counts of rows [0, n) in one call. */
+int nvrx_ring_counts(const nvrx_ctx *ctx, int32_t *out, int n);
 /* Drop all samples of every row: deque.clear (straggler.py:223-225) / reset (CuptiProfiler.cpp:148-152).
  * History minima and row configuration are kept, as in the reference (reporting.py:186-191). */
 int nvrx_ring_reset(nvrx_ctx *ctx);
@@ -171,16 +181,22 @@ int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S
 /* Re-initialise an exchange buffer with the "no stats" sentinels (call when ids change). */
 int nvrx_send_init(float *d_send, int rows, int K, int S, void *stream);
 
-/* Kernel-time instrumentation for the benchmark: when enabled, nvrx_report_local brackets its
- * statistics kernel with a hipEvent pair on the launch stream; totals are read back here
- * (blocks until the recorded events complete). */
+/* Kernel-time instrumentation for the benchmark: when enabled, nvrx_report_local launches its
+ * statistics kernel through hipExtLaunchKernel with a start/stop hipEvent pair, which receive the
+ * kernel's own begin/end timestamps on the launch stream; totals are read back here (blocks until
+ * the recorded events complete). */
 int nvrx_timing_enable(nvrx_ctx *ctx, int on);
 int nvrx_timing_read(nvrx_ctx *ctx, double *total_us, int *launches, int reset);
 
 /* Small asynchronous D2H into pinned memory + completion tracking for the report results. */
-int nvrx_host_alloc(void **out, size_t bytes); /* pinned, device-visible */
+/* Pinned, device-mapped host memory; *out_device (optional) receives the address kernels use. */
+int nvrx_host_alloc(void **out, void **out_device, size_t bytes);
+/* Spin until *h_word == expected (acquire); NVRX_ERR_TIMEOUT after timeout_s seconds. */
+int nvrx_poll_u32(const uint32_t *h_word, uint32_t expected, double timeout_s);
 int nvrx_host_free(void *p);
 int nvrx_copy_to_host(nvrx_ctx *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream);
+/* Stateless: asynchronous D2H on `stream`, then wait for the stream (report results -> pinned host). */
+int nvrx_d2h_sync(void *h_dst, const void *d_src, size_t bytes, void *stream);
 /* Block (spin) until the last nvrx_copy_to_host on this context has landed. */
 int nvrx_wait(nvrx_ctx *ctx);
 

@@ -14,8 +14,11 @@
 //   rings        : straggler.py:80-83 deque(maxlen) / cupti_src/CircularBuffer.h:53-69
 //   scoring      : reporting.py:196-296,338-380   (see k_score)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -99,6 +102,12 @@ struct Epilogue {
     int L;
     float names_ok;
 };
+
+// Ablation switch for tools/kbench.cpp only (always 0 in the shipped library):
+// 1 = load + min/max/mean, 2 = + squared deviations, 3 = + one radix pass, 0 = everything.
+#ifndef NVRX_ABLATE
+#define NVRX_ABLATE 0
+#endif
 
 constexpr int HIST_BITS = 11;
 constexpr int HIST_BINS = 1 << HIST_BITS;
@@ -189,6 +198,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
 
         // ---- sum of squared deviations (two-pass, f64), pad invalid slots with the max key ----------
         double ss = 0.0;
+        if (NVRX_ABLATE != 1) {
 #pragma unroll
         for (int i = 0; i < VPT; i++) {
             const uint32_t e = (uint32_t)(i * THREADS + tid) * 4u;
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
 #pragma unroll
         for (int w = 1; w < WAVES; w++) ss += s_d[w];
         __syncthreads();
+        }
 
         // ---- exact selection of rank k = (n-1)/2 by radix select on d = key - kmin ---------------------
         // Only the bits below the top set bit of (kmax - kmin) can differ, so well-clustered timing
@@ -219,6 +230,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         int hi = 32 - __clz((int)range);  // __clz(0) == 32 -> hi = 0: all samples equal
         uint32_t prefix = 0u;
         uint32_t k = k_rank;
+        if (NVRX_ABLATE == 1 || NVRX_ABLATE == 2) hi = 0;
         while (hi > 0) {
             const int lo = hi > HIST_BITS ? hi - HIST_BITS : 0;
             const int nb = 1 << (hi - lo);
@@ -273,6 +285,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             k = s_bc[1];
             hi = lo;
             __syncthreads();
+            if (NVRX_ABLATE == 3) break;
         }
         const uint32_t dsel = prefix;
         float med = key2f(kmn + dsel);
@@ -420,6 +433,11 @@ struct ScoreArgs {
     float *scores;
     uint8_t *flags;
     uint32_t *meta;
+    uint32_t *done_counter;  // device word, zero between launches; null = no completion word
+    uint32_t seq;
+    const float4 *stats_src;  // optional: statistics rows to forward (device -> pinned host)
+    float4 *stats_dst;
+    int stats_n4;
 };
 
 constexpr int SCORE_THREADS = 256;
@@ -439,6 +457,9 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
     float *__restrict__ out = a.scores + (size_t)r * W;
     uint8_t *__restrict__ fl = a.flags ? a.flags + (size_t)r * W : nullptr;
     const float NaN = __builtin_nanf("");
+
+    // forward the local statistics rows next to the scores (keeps PCIe stores out of k_row_stats)
+    for (int i = r * SCORE_THREADS + tid; i < a.stats_n4; i += a.R * SCORE_THREADS) a.stats_dst[i] = a.stats_src[i];
 
     const float *minmed = a.minmed_pre;
     if (!minmed) {
@@ -537,6 +558,21 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
             a.meta[3] = (uint32_t)S;
         }
     }
+
+    if (a.done_counter) {
+        // Completion word for a polling host (results may live in pinned host memory): every block
+        // makes its stores visible system-wide, then takes a ticket; the last one publishes `seq`.
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();
+            const uint32_t ticket = atomicAdd(a.done_counter, 1u);
+            if (ticket == (uint32_t)a.R - 1u) {
+                *a.done_counter = 0u;  // ready for the next launch (launches on one stream are ordered)
+                __threadfence_system();
+                __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -590,15 +626,23 @@ const StatsVariant *pick_variant(int row_stride) {
     return nullptr;
 }
 
+// start/stop (optional): events that receive the kernel's own begin/end timestamps
+// (hipExtLaunchKernel: the dispatch's profiling timestamps, the same clock rocprofv3 reports).
 int launch_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8_t *d_kinds, int rows,
-                     int row_stride, float *d_stats, const Epilogue &ep, hipStream_t stream) {
+                     int row_stride, float *d_stats, const Epilogue &ep, hipStream_t stream,
+                     hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     if (rows == 0) return NVRX_OK;
     const StatsVariant *v = pick_variant(row_stride);
     if (!v)
         return fail(NVRX_ERR_RANGE, "row_stride %d exceeds the register-resident limit %d", row_stride,
                     NVRX_MAX_RING_CAP);
-    hipLaunchKernelGGL(v->fn, dim3(rows), dim3(v->threads), 0, stream, d_samples, d_counts, d_kinds, row_stride,
-                       d_stats, ep);
+    if (start || stop) {
+        hipExtLaunchKernelGGL(v->fn, dim3(rows), dim3(v->threads), 0, stream, start, stop, 0, d_samples, d_counts,
+                              d_kinds, row_stride, d_stats, ep);
+    } else {
+        hipLaunchKernelGGL(v->fn, dim3(rows), dim3(v->threads), 0, stream, d_samples, d_counts, d_kinds, row_stride,
+                           d_stats, ep);
+    }
     HIP_TRY(hipGetLastError());
     return NVRX_OK;
 }
@@ -765,7 +809,8 @@ int nvrx_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8
 }
 
 int nvrx_score(const float *d_table, int R, int K, int S, int do_indiv, int do_rel, const double *thresholds,
-               float *d_scores, uint8_t *d_flags, uint32_t *d_meta, void *stream) {
+               float *d_scores, uint8_t *d_flags, uint32_t *d_meta, uint32_t *d_done_counter, uint32_t seq,
+               const float *d_stats_src, float *d_stats_dst, int stats_rows, void *stream) {
     if (R <= 0 || K < 0 || S < 0) return fail(NVRX_ERR_INVALID, "bad table shape R=%d K=%d S=%d", R, K, S);
     if (!d_table || !d_scores) return fail(NVRX_ERR_INVALID, "null device pointer");
     hipStream_t st = as_stream(stream);
@@ -780,6 +825,13 @@ int nvrx_score(const float *d_table, int R, int K, int S, int do_indiv, int do_r
     a.scores = d_scores;
     a.flags = d_flags;
     a.meta = d_meta;
+    a.done_counter = d_meta ? d_done_counter : nullptr;
+    a.seq = seq;
+    if (d_stats_src && d_stats_dst && stats_rows > 0) {
+        a.stats_src = reinterpret_cast<const float4 *>(d_stats_src);
+        a.stats_dst = reinterpret_cast<float4 *>(d_stats_dst);
+        a.stats_n4 = stats_rows * (NVRX_STATS_STRIDE / 4);
+    }
     const int KS = K + S;
     size_t lds = (size_t)KS * sizeof(float);
     if (R > 64 || lds > 48 * 1024) {
@@ -1026,6 +1078,13 @@ int nvrx_ring_count(const nvrx_ctx *ctx, int row) {
     return (int)std::min<uint64_t>(ctx->total[(size_t)row], (uint64_t)ctx->ring_cap);
 }
 
+int nvrx_ring_counts(const nvrx_ctx *ctx, int32_t *out, int n) {
+    if (!ctx || !out) return fail(NVRX_ERR_INVALID, "null argument");
+    if (n < 0 || n > ctx->rows) return fail(NVRX_ERR_INVALID, "n %d outside [0,%d]", n, ctx->rows);
+    for (int r = 0; r < n; r++) out[r] = (int32_t)std::min<uint64_t>(ctx->total[(size_t)r], (uint64_t)ctx->ring_cap);
+    return NVRX_OK;
+}
+
 int nvrx_ring_reset(nvrx_ctx *ctx) {
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1151,18 +1210,17 @@ int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S
     ep.L = NVRX_TABLE_LEN(K, S);
     ep.names_ok = names_ok ? 1.0f : 0.0f;
     int pair = -1;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     if (ctx->timing) {
         rc = get_pair(ctx->timing_pairs, ctx->timing_free, &pair);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(ctx->timing_pairs[(size_t)pair].start, st));
+        ev_start = ctx->timing_pairs[(size_t)pair].start;
+        ev_stop = ctx->timing_pairs[(size_t)pair].end;
     }
     rc = launch_row_stats(ctx->d_samples, ctx->d_counts, ctx->d_kinds, ctx->local_ranks * rows_active, ctx->row_stride,
-                          d_stats, ep, st);
+                          d_stats, ep, st, ev_start, ev_stop);
     if (rc) return rc;
-    if (pair >= 0) {
-        HIP_TRY(hipEventRecord(ctx->timing_pairs[(size_t)pair].end, st));
-        ctx->timing_used.push_back(pair);
-    }
+    if (pair >= 0) ctx->timing_used.push_back(pair);
     return NVRX_OK;
 }
 
@@ -1198,15 +1256,42 @@ int nvrx_timing_read(nvrx_ctx *ctx, double *total_us, int *launches, int reset) 
 // ------------------------------------------------------------------------------------------------
 // host buffers and completion
 // ------------------------------------------------------------------------------------------------
-int nvrx_host_alloc(void **out, size_t bytes) {
+int nvrx_host_alloc(void **out, void **out_device, size_t bytes) {
     if (!out || bytes == 0) return fail(NVRX_ERR_INVALID, "bad arguments");
-    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocMapped));
     memset(*out, 0, bytes);
+    if (out_device) HIP_TRY(hipHostGetDevicePointer(out_device, *out, 0));
     return NVRX_OK;
+}
+
+int nvrx_poll_u32(const uint32_t *h_word, uint32_t expected, double timeout_s) {
+    if (!h_word) return fail(NVRX_ERR_INVALID, "null argument");
+    const volatile uint32_t *p = h_word;
+    if (*p == expected) return NVRX_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        if (*p == expected) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return NVRX_OK;
+        }
+        __builtin_ia32_pause();
+        if ((spins & 0x3FFu) == 0x3FFu) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt > timeout_s) return fail(NVRX_ERR_TIMEOUT, "completion word %u not seen after %.3f s (have %u)", expected, dt, *p);
+        }
+    }
 }
 
 int nvrx_host_free(void *p) {
     if (p) HIP_TRY(hipHostFree(p));
+    return NVRX_OK;
+}
+
+int nvrx_d2h_sync(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+    if (!h_dst || !d_src) return fail(NVRX_ERR_INVALID, "null argument");
+    hipStream_t st = as_stream(stream);
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return NVRX_OK;
 }
 

@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_uint32, c_void_p
 
 _LIB_NAME = "libnvrx_straggler_hip.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
@@ -20,14 +20,15 @@ STATS_STRIDE = 8
 STAT_MIN, STAT_MAX, STAT_MED, STAT_AVG, STAT_STD, STAT_NUM, STAT_WEIGHT = range(7)
 KIND_SECTION, KIND_KERNEL = 0, 1
 MAX_RING_CAP = 65536
-META_WORDS = 4
+META_WORDS = 8
 
 # every symbol include/nvrx_straggler.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("nvrx_abi_version", c_int, []),
     ("nvrx_last_error", c_char_p, []),
     ("nvrx_row_stats", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    ("nvrx_score", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("nvrx_score", c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_uint32, c_void_p, c_void_p, c_int, c_void_p]),
     ("nvrx_ctx_create", c_int, [c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     ("nvrx_ctx_destroy", c_int, [c_void_p]),
     ("nvrx_ctx_set_stream", c_int, [c_void_p, c_void_p]),
@@ -39,6 +40,7 @@ SYMBOLS = [
     ("nvrx_ring_set_count", c_int, [c_void_p, c_int, c_int]),
     ("nvrx_ring_set_count_all", c_int, [c_void_p, c_int]),
     ("nvrx_ring_count", c_int, [c_void_p, c_int]),
+    ("nvrx_ring_counts", c_int, [c_void_p, c_void_p, c_int]),
     ("nvrx_ring_reset", c_int, [c_void_p]),
     ("nvrx_history_reset", c_int, [c_void_p, c_void_p]),
     ("nvrx_ring_flush", c_int, [c_void_p, c_void_p]),
@@ -50,8 +52,10 @@ SYMBOLS = [
     ("nvrx_send_init", c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     ("nvrx_timing_enable", c_int, [c_void_p, c_int]),
     ("nvrx_timing_read", c_int, [c_void_p, POINTER(c_double), POINTER(c_int), c_int]),
-    ("nvrx_host_alloc", c_int, [POINTER(c_void_p), c_size_t]),
+    ("nvrx_host_alloc", c_int, [POINTER(c_void_p), POINTER(c_void_p), c_size_t]),
+    ("nvrx_poll_u32", c_int, [c_void_p, c_uint32, c_double]),
     ("nvrx_host_free", c_int, [c_void_p]),
+    ("nvrx_d2h_sync", c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     ("nvrx_copy_to_host", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("nvrx_wait", c_int, [c_void_p]),
 ]

@@ -68,24 +68,44 @@ class Workspace:
         self.send = torch.empty((local_ranks, self.L), dtype=torch.float32, device=dev)
         self.table = torch.empty((R, self.L), dtype=torch.float32, device=dev) if R != local_ranks else self.send
         self.send_initialised = False
-        # one result block: meta | scores | flags | stats (stats last: only the used rows are copied)
+        # one result block in PINNED, device-mapped host memory: meta | scores | flags | stats.
+        # The kernels store their results straight into it and the score kernel publishes a
+        # sequence word last, so a report needs no D2H copy and no stream synchronisation.
         self._off_meta = 0
         self._off_scores = self._off_meta + _align(_native.META_WORDS * 4)
         self._off_flags = self._off_scores + _align(R * self.W * 4)
         self._off_stats = self._off_flags + _align(R * self.W)
         self.nbytes = self._off_stats + _align(max(stats_rows, 1) * _native.STATS_STRIDE * 4)
-        self.out_dev = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
-        self.out_host = torch.zeros(self.nbytes, dtype=torch.uint8, pin_memory=True)
-        host = self.out_host.numpy()
+        h_ptr, d_ptr = ctypes.c_void_p(), ctypes.c_void_p()
+        _native.check(backend.lib.nvrx_host_alloc(ctypes.byref(h_ptr), ctypes.byref(d_ptr), self.nbytes))
+        self._lib = backend.lib
+        self.h_ptr, self.d_ptr = h_ptr.value, d_ptr.value
+        host = np.frombuffer((ctypes.c_uint8 * self.nbytes).from_address(self.h_ptr), dtype=np.uint8)
         self.stats = host[self._off_stats : self._off_stats + stats_rows * 32].view(np.float32).reshape(stats_rows, _native.STATS_STRIDE)
-        self.meta = host[self._off_meta : self._off_meta + 16].view(np.uint32)
+        self.meta = host[self._off_meta : self._off_meta + _native.META_WORDS * 4].view(np.uint32)
         self.scores = host[self._off_scores : self._off_scores + R * self.W * 4].view(np.float32).reshape(R, self.W)
         self.flags = host[self._off_flags : self._off_flags + R * self.W].reshape(R, self.W)
-        base = self.out_dev.data_ptr()
-        self.d_stats = base + self._off_stats
-        self.d_meta = base + self._off_meta
-        self.d_scores = base + self._off_scores
-        self.d_flags = base + self._off_flags
+        # statistics are produced in device memory and forwarded to the host block by the score kernel
+        self.stats_dev = torch.zeros((max(stats_rows, 1), _native.STATS_STRIDE), dtype=torch.float32, device=dev)
+        self.d_stats = self.stats_dev.data_ptr()
+        self.h_stats_dst = self.d_ptr + self._off_stats
+        self.d_meta = self.d_ptr + self._off_meta
+        self.d_scores = self.d_ptr + self._off_scores
+        self.d_flags = self.d_ptr + self._off_flags
+        self.h_seq = self.h_ptr + self._off_meta + 16  # meta[4]
+        self.done_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_counter = self.done_counter.data_ptr()
+        self.seq = 0
+        self.send_ptr = self.send.data_ptr()
+        self.table_ptr = self.table.data_ptr()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self.h_ptr:
+                self._lib.nvrx_host_free(self.h_ptr)
+                self.h_ptr = None
+        except Exception:
+            pass
 
     def set_send_row(self, lr: int, row: np.ndarray) -> None:
         """Host-packed exchange row (dict-input path)."""
@@ -111,10 +131,12 @@ class HipBackend:
         self.stream = torch.cuda.Stream(device=self.device)
         self._workspaces = {}
         self._thr = (ctypes.c_double * 4)(*DEFAULT_THRESHOLDS)
+        self._thr_src = DEFAULT_THRESHOLDS
+        self._stream_handle = self.stream.cuda_stream
 
     @property
     def stream_handle(self) -> int:
-        return self.stream.cuda_stream
+        return self._stream_handle
 
     def stream_context(self):
         return torch.cuda.stream(self.stream)
@@ -132,6 +154,8 @@ class HipBackend:
                 self._workspaces.clear()
             with torch.cuda.device(self.device):
                 ws = Workspace(self, R, K, S, local_ranks, stats_rows)
+                # the buffers were zero-filled on torch's current stream; the report runs on ours
+                torch.cuda.current_stream().synchronize()
             self._workspaces[key] = ws
         return ws
 
@@ -145,21 +169,26 @@ class HipBackend:
     def score(self, ws: Workspace, table: torch.Tensor, do_indiv: bool, do_rel: bool,
               thresholds: Sequence[float] = DEFAULT_THRESHOLDS, wait: bool = True,
               stats_rows: Optional[int] = None) -> None:
-        """Score kernel + the one D2H of the result block; on return ``ws.scores/flags/meta/stats``
-        hold this report's values (when ``wait``).  Only the first ``stats_rows`` statistics rows are
-        copied (default: all)."""
+        """Score kernel, then spin on the completion word it publishes into the pinned result block
+        (two C calls, no torch dispatch, no D2H copy, no stream sync); on return
+        ``ws.scores/flags/meta/stats`` hold this report's values."""
+        if thresholds is not self._thr_src:
+            for i in range(4):
+                self._thr[i] = float(thresholds[i])
+            self._thr_src = thresholds
+        lib = self.lib
         nrows = ws.stats_rows if stats_rows is None else min(stats_rows, ws.stats_rows)
-        nbytes = ws._off_stats + nrows * _native.STATS_STRIDE * 4
-        for i in range(4):
-            self._thr[i] = float(thresholds[i])
-        with torch.cuda.stream(self.stream):
-            _native.check(
-                self.lib.nvrx_score(table.data_ptr(), ws.R, ws.K, ws.S, int(do_indiv), int(do_rel), self._thr,
-                                    ws.d_scores, ws.d_flags, ws.d_meta, self.stream_handle)
-            )
-            ws.out_host[:nbytes].copy_(ws.out_dev[:nbytes], non_blocking=True)
+        table_ptr = ws.table_ptr if table is ws.table else (ws.send_ptr if table is ws.send else table.data_ptr())
+        ws.seq = (ws.seq % 0x7FFFFFFF) + 1
+        rc = lib.nvrx_score(table_ptr, ws.R, ws.K, ws.S, int(do_indiv), int(do_rel), self._thr,
+                            ws.d_scores, ws.d_flags, ws.d_meta, ws.d_counter, ws.seq,
+                            ws.d_stats, ws.h_stats_dst, nrows, self._stream_handle)
+        if rc < 0:
+            _native.check(rc)
         if wait:
-            self.stream.synchronize()
+            rc = lib.nvrx_poll_u32(ws.h_seq, ws.seq, 30.0)
+            if rc < 0:
+                _native.check(rc)
 
     def synchronize(self) -> None:
         self.stream.synchronize()
@@ -191,6 +220,7 @@ class HipRings:
         self.ctx = ctx
         _native.check(self.lib.nvrx_ctx_set_stream(ctx, backend.stream_handle))
         self.rows_used = 0
+        self._counts_buf = np.zeros(64, dtype=np.int32)
         #: every name that ever got a ring row (rows are never recycled; a reset only empties them)
         self.section_row_names = {}
         self.kernel_row_names = {}
@@ -255,6 +285,14 @@ class HipRings:
     def count(self, row: int, lr: int = 0) -> int:
         return _native.check(self.lib.nvrx_ring_count(self.ctx, lr * self.rows_per_rank + row))
 
+    def counts(self) -> np.ndarray:
+        """Valid-sample counts of the used rows of logical rank 0 (one C call)."""
+        n = self.rows_used
+        if self._counts_buf.size < n:
+            self._counts_buf = np.zeros(max(n, 64), dtype=np.int32)
+        _native.check(self.lib.nvrx_ring_counts(self.ctx, self._counts_buf.ctypes.data, n))
+        return self._counts_buf[:n]
+
     def reset(self) -> None:
         _native.check(self.lib.nvrx_ring_reset(self.ctx))
 
@@ -286,10 +324,10 @@ class HipRings:
         """flush -> statistics kernel -> exchange rows, all on the backend's stream."""
         if not ws.send_initialised:
             self.backend.send_init(ws)
-        _native.check(
-            self.lib.nvrx_report_local(self.ctx, ws.d_stats, ws.send.data_ptr(), ws.K, ws.S, int(names_ok),
-                                       rows_active, self.backend.stream_handle)
-        )
+        rc = self.lib.nvrx_report_local(self.ctx, ws.d_stats, ws.send_ptr, ws.K, ws.S, int(names_ok),
+                                        rows_active, self.backend.stream_handle)
+        if rc < 0:
+            _native.check(rc)
 
     def peek_stats(self) -> np.ndarray:
         """Statistics of every used row right now ([rows_used, 8] on the host); exchanges nothing and

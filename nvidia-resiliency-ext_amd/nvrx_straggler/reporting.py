@@ -332,12 +332,16 @@ class ReportGenerator:
             K, S = mapper.kernel_counter, mapper.section_counter
             world = self.world_size if exchanged else 1
             ws = be.workspace(world * local_ranks, K, S, local_ranks, stats_rows)
-            with be.stream_context():
+            if world > 1:
+                with be.stream_context():  # the collective must queue behind the statistics kernel
+                    fill_send(ws, mapper, names_ok)
+                    table = dist_utils.all_gather_rows(ws.send, ws.table, self.group)
+            else:
                 fill_send(ws, mapper, names_ok)
-                table = dist_utils.all_gather_rows(ws.send, ws.table, self.group) if world > 1 else ws.send
+                table = ws.send
             be.score(ws, table, self.is_computing_indiv_scores, self.is_computing_rel_scores, self.thresholds,
                      wait=True, stats_rows=stats_rows_used)
-            if int(ws.meta[0]) == 1:
+            if ws.meta[0] == 1:
                 return ws, mapper
             # some rank (maybe this one) has names without ids: cold path, then go again
             mapper.sync_names(kernel_names, section_names)

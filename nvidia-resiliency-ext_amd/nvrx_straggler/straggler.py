@@ -132,6 +132,9 @@ class Detector:
     report_interval_tracker: ReportIntervalTracker
     original_callables: Optional[Dict[CallableId, Any]]
     rings: Any = None
+    _occupied_key: Optional[bytes] = None
+    _active_sections: Dict[str, int] = {}
+    _active_kernels: Dict[str, int] = {}
 
     def __new__(cls):
         raise RuntimeError(f"class {cls.__name__} should not be instantiated")
@@ -164,6 +167,7 @@ class Detector:
         cls.gather_on_rank0 = gather_on_rank0
         cls.profiling_interval = profiling_interval
         cls.custom_sections = {}
+        cls._occupied_key = None
         ring_cap = int(CustomSection.max_elapseds_len)
         cls.rings = _backend_mod.get_backend().make_rings(1, int(max_rows), ring_cap)
         cls.cupti_manager = CuptiManager(statsMaxLenPerKernel=ring_cap, rings=cls.rings)
@@ -228,11 +232,15 @@ class Detector:
         rings = cls.rings
         # the recorded GPU regions must have finished; nothing else on the device is waited for
         rings.harvest(wait=True)
-        section_rows = {
-            name: sec.row for name, sec in cls.custom_sections.items() if rings.count(sec.row) > 0
-        }
-        kernel_rows = {key: row for key, row in rings.kernel_row_names.items() if rings.count(row) > 0}
-        report = cls.reporter.generate_report_from_rings(rings, section_rows, kernel_rows)
+        # which rows hold samples this window (one C call); the name tables are rebuilt only when
+        # that set changes, so a steady-state report does no per-section Python work
+        occupied = (rings.counts() > 0).tobytes()
+        if occupied != cls._occupied_key:
+            counts = rings.counts()
+            cls._active_sections = {n: sec.row for n, sec in cls.custom_sections.items() if counts[sec.row] > 0}
+            cls._active_kernels = {k: row for k, row in rings.kernel_row_names.items() if counts[row] > 0}
+            cls._occupied_key = occupied
+        report = cls.reporter.generate_report_from_rings(rings, cls._active_sections, cls._active_kernels)
         rings.reset()  # both the section rows and the GPU-time rows, like :241-242 of the reference
         return report
 

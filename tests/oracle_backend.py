@@ -142,6 +142,9 @@ class OracleRings:
     def set_count_all(self, n):
         self.total[:] = n
 
+    def counts(self):
+        return np.minimum(self.total[: self.rows_used], self.ring_cap).astype(np.int32)
+
     def count(self, row, lr=0):
         return int(min(self.total[lr * self.rows_per_rank + row], self.ring_cap))
 

@@ -43,7 +43,7 @@ def test_abi_argument_validation_without_a_gpu():
     lib = _native.load()
     assert lib.nvrx_row_stats(None, None, None, 1, 6, None, None) == -22
     assert b"multiple of 4" in lib.nvrx_last_error()
-    assert lib.nvrx_score(None, 0, 0, 0, 1, 1, None, None, None, None, None) == -22
+    assert lib.nvrx_score(None, 0, 0, 0, 1, 1, None, None, None, None, None, 0, None, None, 0, None) == -22
     assert lib.nvrx_ctx_destroy(None) == 0
     assert lib.nvrx_ring_push(None, 0, 1.0) == -22
     with pytest.raises(_native.NativeError, match="ctx is null"):
