@@ -70,24 +70,69 @@ __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float(u);
 }
 
+// ---- wave64 reductions on the DPP cross-lane path (no LDS traffic) ------------------------------
+// quad_perm -> row_shr:4/8 -> row_bcast:15/31 leaves the wave total in lane 63; readlane broadcasts it
+// through an SGPR.  `old` supplies the value for lanes a DPP step has no source for.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
+}
+constexpr int DPP_QUAD_1032 = 0xb1, DPP_QUAD_2301 = 0x4e, DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112,
+              DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, m, 64));
-    return v;
+    v = min(v, dpp<DPP_QUAD_1032>(v, v));
+    v = min(v, dpp<DPP_QUAD_2301>(v, v));
+    v = min(v, dpp<DPP_ROW_SHR4>(v, v));
+    v = min(v, dpp<DPP_ROW_SHR8>(v, v));
+    v = min(v, dpp<DPP_BCAST15>(v, v));
+    v = min(v, dpp<DPP_BCAST31>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m, 64));
-    return v;
+    v = max(v, dpp<DPP_QUAD_1032>(v, v));
+    v = max(v, dpp<DPP_QUAD_2301>(v, v));
+    v = max(v, dpp<DPP_ROW_SHR4>(v, v));
+    v = max(v, dpp<DPP_ROW_SHR8>(v, v));
+    v = max(v, dpp<DPP_BCAST15>(v, v));
+    v = max(v, dpp<DPP_BCAST31>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
-    return v;
+    v += dpp<DPP_QUAD_1032>(0u, v);
+    v += dpp<DPP_QUAD_2301>(0u, v);
+    v += dpp<DPP_ROW_SHR4>(0u, v);
+    v += dpp<DPP_ROW_SHR8>(0u, v);
+    v += dpp<DPP_BCAST15>(0u, v);
+    v += dpp<DPP_BCAST31>(0u, v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double src) {
+    const uint64_t u = (uint64_t)__double_as_longlong(src);
+    const uint32_t lo = dpp<CTRL>(0u, (uint32_t)u), hi = dpp<CTRL>(0u, (uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));  // +0.0 where no source lane
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    v += dpp_f64<DPP_QUAD_1032>(v);
+    v += dpp_f64<DPP_QUAD_2301>(v);
+    v += dpp_f64<DPP_ROW_SHR4>(v);
+    v += dpp_f64<DPP_ROW_SHR8>(v);
+    v += dpp_f64<DPP_BCAST15>(v);
+    v += dpp_f64<DPP_BCAST31>(v);
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), 63);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// inclusive prefix sum across the wave (row_shr:1,2,4,8 inside a row, then the two row broadcasts)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+    v += dpp<DPP_ROW_SHR1>(0u, v);
+    v += dpp<DPP_ROW_SHR2>(0u, v);
+    v += dpp<DPP_ROW_SHR4>(0u, v);
+    v += dpp<DPP_ROW_SHR8>(0u, v);
+    v += dpp<DPP_BCAST15, 0xa>(0u, v);
+    v += dpp<DPP_BCAST31, 0xc>(0u, v);
     return v;
 }
 
@@ -125,12 +170,16 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                                                        float *__restrict__ stats, Epilogue ep) {
     constexpr int WAVES = THREADS / 64;
     constexpr int PER = HIST_BINS / THREADS;  // histogram bins scanned per thread
+    constexpr int NKEY = VPT * 4;
+    constexpr int CAND_MAX = 256;  // a selected bin this small is finished by direct ranking
     static_assert(HIST_BINS % THREADS == 0, "THREADS must divide the histogram size");
 
     __shared__ uint32_t s_hist[HIST_BINS];
-    __shared__ double s_d[WAVES];
-    __shared__ uint32_t s_u[2 * WAVES];
-    __shared__ uint32_t s_bc[2];
+    __shared__ uint32_t s_cand[CAND_MAX];
+    __shared__ double s_d[2 * WAVES];    // [0,W) partial sums, [W,2W) partial squared deviations
+    __shared__ uint32_t s_u[3 * WAVES];  // [0,W) min keys, [W,2W) max keys, [2W,3W) scan totals
+    __shared__ uint32_t s_bc[4];         // {selected bin, rank inside it, its population, candidate cursor}
+    __shared__ uint32_t s_res[1];        // key offset found by direct ranking
 
     const int row = ep.rows_active ? (int)(blockIdx.x / ep.rows_active) * ep.rows_per_rank + (int)(blockIdx.x % ep.rows_active)
                                    : (int)blockIdx.x;
@@ -141,6 +190,9 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
     uint32_t n = counts[row];
     if (n > (uint32_t)row_stride) n = (uint32_t)row_stride;
     const int kind = kinds ? kinds[row] : NVRX_KIND_SECTION;
+    // epilogue inputs are fetched now so their latency hides under the row load
+    const int row_gid = (ep.send && ep.gid) ? ep.gid[row] : -1;
+    const float row_hmin = ep.hist_min ? ep.hist_min[row] : __builtin_nanf("");
 
     float r_min, r_max, r_med, r_avg, r_std;
 
@@ -148,9 +200,9 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         r_min = r_max = r_med = r_avg = r_std = __builtin_nanf("");
     } else {
         const float4 *__restrict__ src = reinterpret_cast<const float4 *>(samples + (size_t)row * (size_t)row_stride);
-        uint32_t key[VPT * 4];
+        uint32_t key[NKEY];
 
-        // ---- load (HBM -> VGPR), local min/max/sum ------------------------------------------------
+        // ---- load (HBM -> VGPR): VPT independent 16-byte loads per lane ---------------------------
         float4 x[VPT];
 #pragma unroll
         for (int i = 0; i < VPT; i++) {
@@ -158,32 +210,43 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((uint32_t)(v * 4) < n) x[i] = src[v];
         }
-        uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
-        double sum = 0.0;
+        // the histogram is cleared while the loads are in flight
+#pragma unroll
+        for (int j = 0; j < PER; j++) s_hist[tid * PER + j] = 0u;
+
+        // ---- min / max / sum / sum of squares in ONE pass over the registers, branch-free ---------------
+        // f32 partials per lane around the lane's own pivot p (its first sample): s = sum(x-p),
+        // q = sum((x-p)^2).  Once the row mean m is known each lane turns them into its exact share of
+        // sum((x-m)^2) = q - 2(m-p)s + cnt(m-p)^2 in f64; cross-lane sums are f64 throughout.
+        const float pivot = x[0].x;
+        uint32_t kmn = 0xFFFFFFFFu, kmx = 0u, cnt = 0u;
+        float psum = 0.f, psq = 0.f;
 #pragma unroll
         for (int i = 0; i < VPT; i++) {
             const uint32_t e = (uint32_t)(i * THREADS + tid) * 4u;
             const float xs[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const uint32_t k = f2key(xs[c]);
-                key[i * 4 + c] = k;
-                if (e + c < n) {
-                    kmn = min(kmn, k);
-                    kmx = max(kmx, k);
-                    sum += (double)xs[c];
-                }
+                const bool valid = e + c < n;
+                const uint32_t kk = f2key(xs[c]);
+                key[i * 4 + c] = kk;
+                kmn = min(kmn, valid ? kk : 0xFFFFFFFFu);
+                kmx = max(kmx, valid ? kk : 0u);
+                const float d = valid ? xs[c] - pivot : 0.f;
+                psum += d;
+                psq = fmaf(d, d, psq);
+                cnt += valid ? 1u : 0u;
             }
         }
         kmn = wave_min_u32(kmn);
         kmx = wave_max_u32(kmx);
-        sum = wave_sum_f64(sum);
+        double sum = wave_sum_f64((double)psum + (double)cnt * (double)pivot);
         if (lane == 0) {
             s_u[wave] = kmn;
             s_u[WAVES + wave] = kmx;
             s_d[wave] = sum;
         }
-        __syncthreads();
+        __syncthreads();  // (1) partials published, histogram cleared
         kmn = s_u[0];
         kmx = s_u[WAVES];
         sum = s_d[0];
@@ -193,57 +256,51 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             kmx = max(kmx, s_u[WAVES + w]);
             sum += s_d[w];
         }
-        __syncthreads();
         const double mean = sum / (double)n;
-
-        // ---- sum of squared deviations (two-pass, f64), pad invalid slots with the max key ----------
-        double ss = 0.0;
         if (NVRX_ABLATE != 1) {
+            const double dm = mean - (double)pivot;
+            const double lane_ss = (double)psq - 2.0 * dm * (double)psum + (double)cnt * dm * dm;
+            const double wss = wave_sum_f64(lane_ss);
+            if (lane == 0) s_d[WAVES + wave] = wss;  // consumed after the final barrier
+        }
+        // tail slots are padded with the max key: padding sorts last and never moves rank k < n
 #pragma unroll
         for (int i = 0; i < VPT; i++) {
             const uint32_t e = (uint32_t)(i * THREADS + tid) * 4u;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (e + c < n) {
-                    const double d = (double)key2f(key[i * 4 + c]) - mean;
-                    ss += d * d;
-                } else {
-                    key[i * 4 + c] = kmx;  // padding sorts last, never changes rank k < n
-                }
-            }
-        }
-        ss = wave_sum_f64(ss);
-        if (lane == 0) s_d[wave] = ss;
-        __syncthreads();
-        ss = s_d[0];
-#pragma unroll
-        for (int w = 1; w < WAVES; w++) ss += s_d[w];
-        __syncthreads();
+            for (int c = 0; c < 4; c++) key[i * 4 + c] = (e + c < n) ? key[i * 4 + c] : kmx;
         }
 
         // ---- exact selection of rank k = (n-1)/2 by radix select on d = key - kmin ---------------------
-        // Only the bits below the top set bit of (kmax - kmin) can differ, so well-clustered timing
-        // data needs two 11-bit passes, and the first histogram is spread over the data's own range
-        // (no hot bin for the shared exponent bits).
+        // Only the bits below the top set bit of (kmax - kmin) can differ, so clustered timing data
+        // needs ONE 11-bit histogram pass spread over the data's own range; the selected bin is then
+        // small enough to be ranked directly.  Heavier bins fall back to further radix passes.
         const uint32_t k_rank = (n - 1u) >> 1;
         const uint32_t range = kmx - kmn;
         int hi = 32 - __clz((int)range);  // __clz(0) == 32 -> hi = 0: all samples equal
         uint32_t prefix = 0u;
         uint32_t k = k_rank;
+        bool first = true;
         if (NVRX_ABLATE == 1 || NVRX_ABLATE == 2) hi = 0;
         while (hi > 0) {
             const int lo = hi > HIST_BITS ? hi - HIST_BITS : 0;
             const int nb = 1 << (hi - lo);
             const uint32_t bmask = (uint32_t)nb - 1u;
-            const uint32_t mask_hi = hi >= 32 ? 0u : (0xFFFFFFFFu << hi);
-            for (int b = tid; b < nb; b += THREADS) s_hist[b] = 0u;
-            __syncthreads();
+            if (first) {
+                // every key participates: no predicate, histogram already cleared
 #pragma unroll
-            for (int j = 0; j < VPT * 4; j++) {
-                const uint32_t d = key[j] - kmn;
-                if ((d & mask_hi) == prefix) atomicAdd(&s_hist[(d >> lo) & bmask], 1u);
+                for (int j = 0; j < NKEY; j++) atomicAdd(&s_hist[((key[j] - kmn) >> lo) & bmask], 1u);
+            } else {
+                const uint32_t mask_hi = hi >= 32 ? 0u : (0xFFFFFFFFu << hi);
+                for (int b = tid; b < nb; b += THREADS) s_hist[b] = 0u;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < NKEY; j++) {
+                    const uint32_t d = key[j] - kmn;
+                    if ((d & mask_hi) == prefix) atomicAdd(&s_hist[(d >> lo) & bmask], 1u);
+                }
             }
-            __syncthreads();
+            __syncthreads();  // (2) histogram complete
             // block-wide exclusive scan of the histogram, PER consecutive bins per thread
             uint32_t c[PER];
             uint32_t local = 0u;
@@ -253,39 +310,92 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                 c[j] = b < nb ? s_hist[b] : 0u;
                 local += c[j];
             }
-            uint32_t incl = local;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-                if (lane >= o) incl += t;
-            }
-            if (lane == 63) s_u[wave] = incl;
-            __syncthreads();
+            const uint32_t incl = wave_scan_u32(local);
+            if (lane == 63) s_u[2 * WAVES + wave] = incl;
+            __syncthreads();  // (3) wave totals
             uint32_t base = 0u;
 #pragma unroll
-            for (int w = 0; w < WAVES; w++)
-                if (w < wave) base += s_u[w];
-            uint32_t excl = base + incl - local;
+            for (int w = 0; w < WAVES; w++) base += (w < wave) ? s_u[2 * WAVES + w] : 0u;
+            const uint32_t excl = base + incl - local;
             if (k >= excl && k < excl + local) {
-                uint32_t b = (uint32_t)tid * PER;
+                uint32_t b = (uint32_t)tid * PER, below = excl, pop = c[0];
 #pragma unroll
-                for (int j = 0; j < PER; j++) {
-                    if (k >= excl + c[j]) {
-                        excl += c[j];
-                        b++;
-                    } else {
-                        break;
-                    }
+                for (int j = 0; j < PER - 1; j++) {
+                    const bool adv = (b == (uint32_t)tid * PER + j) && (k >= below + c[j]);
+                    below += adv ? c[j] : 0u;
+                    pop = adv ? c[j + 1] : pop;
+                    b += adv ? 1u : 0u;
                 }
                 s_bc[0] = b;
-                s_bc[1] = k - excl;
+                s_bc[1] = k - below;
+                s_bc[2] = pop;
+                s_bc[3] = 0u;
             }
-            __syncthreads();
+            __syncthreads();  // (4) selected bin published
             prefix |= s_bc[0] << lo;
             k = s_bc[1];
+            const uint32_t pop = s_bc[2];
             hi = lo;
-            __syncthreads();
+            first = false;
             if (NVRX_ABLATE == 3) break;
+            if (hi > 0 && pop <= (uint32_t)CAND_MAX) {
+                // ---- finish by ranking the bin's few members directly -------------------------------
+                // Wave-aggregated compaction: ballots count the wave's members (scalar adds), lane 0
+                // reserves the wave's span of s_cand with ONE atomic, members then store themselves.
+                const uint32_t mask_sel = 0xFFFFFFFFu << hi;
+                uint32_t wave_members = 0u;
+#pragma unroll
+                for (int j = 0; j < NKEY; j++)
+                    wave_members += (uint32_t)__popcll(__ballot(((key[j] - kmn) & mask_sel) == prefix));
+                if (wave_members) {  // wave-uniform
+                    uint32_t base = 0u;
+                    if (lane == 0) base = atomicAdd(&s_bc[3], wave_members);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+                    for (int j = 0; j < NKEY; j++) {
+                        const uint32_t d = key[j] - kmn;
+                        const bool member = (d & mask_sel) == prefix;
+                        const unsigned long long b = __ballot(member);
+                        if (b) {  // wave-uniform
+                            if (member) s_cand[base + (uint32_t)__popcll(b & lt)] = d;
+                            base += (uint32_t)__popcll(b);
+                        }
+                    }
+                }
+                __syncthreads();  // (5) candidates listed
+                // Wave-parallel ranking: each wave takes every WAVES-th candidate, its 64 lanes compare
+                // it with the whole list (<= 4 chunks of 64) and a ballot popcount gives its rank.
+                const int chunks = (int)((pop + 63u) >> 6);
+                uint32_t cv[CAND_MAX / 64];
+#pragma unroll
+                for (int q = 0; q < CAND_MAX / 64; q++) {
+                    const uint32_t idx = (uint32_t)(q * 64 + lane);
+                    cv[q] = (q < chunks && idx < pop) ? s_cand[idx] : 0xFFFFFFFFu;
+                }
+                for (uint32_t i = (uint32_t)wave; i < pop; i += WAVES) {
+                    // candidate i lives in lane (i & 63) of chunk (i >> 6): broadcast it without LDS
+                    uint32_t src = cv[0];
+#pragma unroll
+                    for (int q = 1; q < CAND_MAX / 64; q++) src = ((int)(i >> 6) == q) ? cv[q] : src;
+                    const uint32_t mine = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(i & 63u));
+                    uint32_t below = 0u;
+#pragma unroll
+                    for (int q = 0; q < CAND_MAX / 64; q++) {
+                        if (q < chunks) {  // wave-uniform
+                            const uint32_t idx = (uint32_t)(q * 64 + lane);
+                            const bool less = idx < pop && (cv[q] < mine || (cv[q] == mine && idx < i));
+                            below += (uint32_t)__popcll(__ballot(less));
+                        }
+                    }
+                    if (below == k && lane == 0) s_res[0] = mine;
+                }
+                __syncthreads();  // (6) result
+                prefix = s_res[0];
+                hi = 0;
+                break;
+            }
+            __syncthreads();  // s_hist / s_u / s_bc are reused by the next pass
         }
         const uint32_t dsel = prefix;
         float med = key2f(kmn + dsel);
@@ -294,13 +404,14 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             // mean of the two middle order statistics (CuptiProfiler.cpp:57-59): also need rank k+1
             uint32_t cnt_le = 0u, mn_gt = 0xFFFFFFFFu;
 #pragma unroll
-            for (int j = 0; j < VPT * 4; j++) {
+            for (int j = 0; j < NKEY; j++) {
                 const uint32_t d = key[j] - kmn;
                 cnt_le += (d <= dsel) ? 1u : 0u;
-                if (d > dsel) mn_gt = min(mn_gt, d);
+                mn_gt = min(mn_gt, d > dsel ? d : 0xFFFFFFFFu);
             }
             cnt_le = wave_sum_u32(cnt_le);
             mn_gt = wave_min_u32(mn_gt);
+            __syncthreads();  // everyone is done reading s_u from the min/max phase
             if (lane == 0) {
                 s_u[wave] = cnt_le;
                 s_u[WAVES + wave] = mn_gt;
@@ -317,14 +428,20 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             med = (med + key2f(kmn + dnext)) / 2.0f;
         }
 
+        __syncthreads();  // squared-deviation partials of every wave are visible
+        double ss = 0.0;
+        if (NVRX_ABLATE != 1) {
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) ss += s_d[WAVES + w];
+        }
         r_min = key2f(kmn);
         r_max = key2f(kmx);
         r_med = med;
         r_avg = (float)mean;
         if (kind == NVRX_KIND_KERNEL) {
-            r_std = (float)sqrt(ss / (double)n);
+            r_std = sqrtf((float)(ss / (double)n));
         } else {
-            r_std = n > 1u ? (float)sqrt(ss / (double)(n - 1u)) : __builtin_nanf("");
+            r_std = n > 1u ? sqrtf((float)(ss / (double)(n - 1u))) : __builtin_nanf("");
         }
     }
 
@@ -339,10 +456,9 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         o[NVRX_STAT_NUM] = (float)n;
         o[NVRX_STAT_WEIGHT] = weight;
         o[7] = 0.0f;
-        float h = __builtin_nanf("");
+        float h = row_hmin;
         if (ep.hist_min) {
             // _update_local_min_times (reporting.py:298-314): history is never reset by a report
-            h = ep.hist_min[row];
             if (n && r_med < h) {
                 h = r_med;
                 ep.hist_min[row] = h;
@@ -351,7 +467,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         if (ep.send) {
             const int lr = row / ep.rows_per_rank;
             float *s = ep.send + (size_t)lr * ep.L;
-            const int g = ep.gid ? ep.gid[row] : -1;
+            const int g = row_gid;
             if (g >= 0 && g < ep.KS) {
                 s[g] = n ? r_med : -1.0f;  // -1 = "no stats on this rank" (reporting.py:273)
                 s[ep.KS + g] = n ? h : __builtin_nanf("");
