@@ -81,6 +81,7 @@ class Workspace:
         self._lib = backend.lib
         self.h_ptr, self.d_ptr = h_ptr.value, d_ptr.value
         host = np.frombuffer((ctypes.c_uint8 * self.nbytes).from_address(self.h_ptr), dtype=np.uint8)
+        self._host = host
         self.stats = host[self._off_stats : self._off_stats + stats_rows * 32].view(np.float32).reshape(stats_rows, _native.STATS_STRIDE)
         self.meta = host[self._off_meta : self._off_meta + _native.META_WORDS * 4].view(np.uint32)
         self.scores = host[self._off_scores : self._off_scores + R * self.W * 4].view(np.float32).reshape(R, self.W)
@@ -106,6 +107,10 @@ class Workspace:
                 self.h_ptr = None
         except Exception:
             pass
+
+    def host_block(self) -> np.ndarray:
+        """A private copy of the pinned result block (the block itself is overwritten by the next report)."""
+        return self._host.copy()
 
     def set_send_row(self, lr: int, row: np.ndarray) -> None:
         """Host-packed exchange row (dict-input path)."""

@@ -36,6 +36,7 @@ class FoldedJob:
         self.ring_cap = ring_cap
         self.reporter = ReportGenerator(list(scores_to_compute), gather_on_rank0=gather_on_rank0, pg=pg, node_name=node_name)
         self.rows = {name: self.rings.row_for(_native.KIND_SECTION, name) for name in self.section_names}
+        self._no_kernel_rows = {}  # same object every report so the reporter's cached plan stays valid
 
     def logical_ranks(self):
         """Global logical ranks held by this process."""
@@ -56,7 +57,8 @@ class FoldedJob:
         self.rings.set_count_all(n)
 
     def report(self, reset: bool = True):
-        rep = self.reporter.generate_report_from_rings(self.rings, self.rows, {}, local_ranks=self.local_ranks)
+        rep = self.reporter.generate_report_from_rings(self.rings, self.rows, self._no_kernel_rows,
+                                                       local_ranks=self.local_ranks)
         if reset:
             self.rings.reset()
         return rep

@@ -49,14 +49,26 @@ class StragglerId:
 # --------------------------------------------------------------------------------------------------
 # lazy views over the score arrays
 # --------------------------------------------------------------------------------------------------
+def _resolve(x):
+    """Arrays may be handed to the views as zero-argument callables and are materialised on first use."""
+    return x() if callable(x) else x
+
+
 class RankScores(_MappingABC):
     """``rank -> score`` view over one column of the score array."""
 
-    __slots__ = ("_ranks", "_values")
+    __slots__ = ("_ranks", "_src")
 
-    def __init__(self, ranks: Sequence[int], values: np.ndarray):
+    def __init__(self, ranks: Sequence[int], values):
         self._ranks = ranks
-        self._values = values
+        self._src = values  # ndarray, or callable returning it
+
+    @property
+    def _values(self) -> np.ndarray:
+        v = self._src
+        if callable(v):
+            v = self._src = v()
+        return v
 
     def __getitem__(self, rank: int) -> float:
         try:
@@ -86,13 +98,20 @@ class RankScores(_MappingABC):
 class SectionScores(_MappingABC):
     """``section name -> (rank -> score)`` view over a [ranks, sections] block of the score array."""
 
-    __slots__ = ("_names", "_cols", "_ranks", "_block")
+    __slots__ = ("_names", "_cols", "_ranks", "_src")
 
-    def __init__(self, names: Sequence[str], cols: Sequence[int], ranks: Sequence[int], block: np.ndarray):
-        self._names = list(names)
-        self._cols = {n: c for n, c in zip(names, cols)}
+    def __init__(self, names: Sequence[str], cols, ranks: Sequence[int], block):
+        self._names = names
+        self._cols = cols if isinstance(cols, dict) else {n: c for n, c in zip(names, cols)}
         self._ranks = ranks
-        self._block = block
+        self._src = block  # ndarray [ranks, S], or callable returning it
+
+    @property
+    def _block(self) -> np.ndarray:
+        b = self._src
+        if callable(b):
+            b = self._src = b()
+        return b
 
     def __getitem__(self, name: str) -> RankScores:
         return RankScores(self._ranks, self._block[:, self._cols[name]])
@@ -113,18 +132,19 @@ class SectionScores(_MappingABC):
 class StatSummaries(_MappingABC):
     """``name -> {Statistic: value}`` built from device statistics rows on first access."""
 
-    __slots__ = ("_rows", "_stats", "_cache")
+    __slots__ = ("_rows", "_src", "_cache")
 
-    def __init__(self, rows: Mapping[str, int], stats: np.ndarray):
-        self._rows = rows  # name -> row index, only rows that hold samples
-        self._stats = stats
+    def __init__(self, rows: Mapping[str, int], stats):
+        self._rows = rows  # name -> row index, only rows that hold samples (treated as immutable)
+        self._src = stats  # ndarray [rows, 8], or callable returning it
         self._cache: Optional[Dict[str, Dict[Statistic, Any]]] = None
 
     def _materialise(self) -> Dict[str, Dict[Statistic, Any]]:
         if self._cache is None:
+            stats = _resolve(self._src)
             out = {}
             for name, row in self._rows.items():
-                vals = self._stats[row]
+                vals = stats[row]
                 d = {stat: float(vals[col]) for stat, col in STAT_COLUMNS}
                 d[Statistic.NUM] = int(vals[5])
                 out[name] = d
@@ -223,11 +243,11 @@ class _DeviceFlags:
     """Below-threshold bytes written by the score kernel, with the thresholds they were computed for."""
 
     def __init__(self, thresholds, flags: np.ndarray, ranks, names, cols, S, has_rel, has_indiv):
-        self.thresholds = tuple(float(t) for t in thresholds)  # gpu_rel, sec_rel, gpu_indiv, sec_indiv
-        self.flags = flags
+        self.thresholds = thresholds  # (gpu_rel, sec_rel, gpu_indiv, sec_indiv) as floats
+        self._flags = flags  # ndarray [ranks, 2+2S] u8, or callable returning it
         self.ranks = ranks
         self.names = names
-        self.cols = cols
+        self.cols = cols if isinstance(cols, dict) else dict(zip(names, cols))
         self.S = S
         self.has_rel = has_rel
         self.has_indiv = has_indiv
@@ -239,11 +259,12 @@ class _DeviceFlags:
         return [self.ranks[int(i)] for i in np.nonzero(column)[0]]
 
     def decode(self):
-        f, S = self.flags, self.S
+        f, S = _resolve(self._flags), self.S
         gi = self._ranks_of(f[:, 0]) if self.has_indiv else []
         gr = self._ranks_of(f[:, 1]) if self.has_rel else []
-        si = {n: self._ranks_of(f[:, 2 + c]) for n, c in zip(self.names, self.cols)} if self.has_indiv else {}
-        sr = {n: self._ranks_of(f[:, 2 + S + c]) for n, c in zip(self.names, self.cols)} if self.has_rel else {}
+        cols = self.cols
+        si = {n: self._ranks_of(f[:, 2 + cols[n]]) for n in self.names} if self.has_indiv else {}
+        sr = {n: self._ranks_of(f[:, 2 + S + cols[n]]) for n in self.names} if self.has_rel else {}
         return gr, gi, sr, si
 
 
@@ -282,6 +303,7 @@ class ReportGenerator:
         self._private_mapper = NameMapper(pg=pg)
         self.rank_to_node: Dict[int, str] = collections.defaultdict(lambda: "<unk>")
         self._ring_gid_state = None
+        self._ring_plan = None
 
     # ---- pieces kept from the reference's host logic ----------------------------------------------
     @staticmethod
@@ -311,7 +333,7 @@ class ReportGenerator:
         return self.is_computing_rel_scores or self.gather_on_rank0
 
     def _score_round(self, kernel_names: List[str], section_names: List[str], fill_send, local_ranks: int = 1,
-                     stats_rows: int = 0, stats_rows_used: Optional[int] = None):
+                     stats_rows: int = 0, stats_rows_used: Optional[int] = None, resync_first: bool = False):
         """pack -> all-gather -> score, repeated once after a name sync if any rank met a new name.
 
         ``fill_send(ws, mapper, names_ok)`` must leave this rank's exchange rows in ``ws.send``.
@@ -320,6 +342,10 @@ class ReportGenerator:
         be = _backend_mod.get_backend()
         exchanged = self._exchanged()
         mapper = self.name_mapper if exchanged else self._private_mapper
+        if resync_first:
+            # the planned path already ran this report's first exchange and saw an incomplete flag:
+            # every rank is now heading for the name sync, so join it before exchanging rows again
+            mapper.sync_names(kernel_names, section_names)
         while True:
             names_ok = mapper.has_all_names(kernel_names, section_names)
             if not names_ok and (not exchanged or self.world_size == 1):
@@ -359,14 +385,14 @@ class ReportGenerator:
                 return None
             ranks = range(ws.R)
             names = [mapper.get_section_name(i) for i in range(S)]
-            cols = list(range(S))
+            cols = {n: i for i, n in enumerate(names)}
         else:
             me = self.rank * local_ranks if self._exchanged() else 0
             scores = scores[me : me + local_ranks]
             flags = flags[me : me + local_ranks]
             ranks = range(self.rank * local_ranks, (self.rank + 1) * local_ranks)
             names = list(local_section_names)
-            cols = [mapper.get_section_id(n) for n in names]
+            cols = {n: mapper.get_section_id(n) for n in names}
         gpu_i = RankScores(ranks, scores[:, 0]) if has_indiv else empty
         gpu_r = RankScores(ranks, scores[:, 1]) if has_rel else empty
         sec_i = SectionScores(names, cols, ranks, scores[:, 2 : 2 + S]) if (has_indiv and names) else empty
@@ -381,6 +407,114 @@ class ReportGenerator:
             local_section_summaries=section_summaries,
             local_kernel_summaries=kernel_summaries,
             generate_report_elapsed_time=elapsed_ms,
+            gather_on_rank0=self.gather_on_rank0,
+            rank=self.rank,
+        )
+        object.__setattr__(
+            report, "_device_flags", _DeviceFlags(self.thresholds, flags, ranks, names, cols, S, has_rel, has_indiv)
+        )
+        return report
+
+    # ---- steady-state plan of the ring path ---------------------------------------------------------
+    class _RingPlan:
+        """Everything about a ring report that only changes when names, ids or topology change."""
+
+        __slots__ = ("key", "ws", "mapper", "snames", "knames", "names", "cols", "ranks", "row_lo", "row_hi",
+                     "rows_used", "stats_needed", "section_rows", "kernel_rows")
+
+    def _build_ring_plan(self, key, rings, section_rows, kernel_rows, local_ranks):
+        be = _backend_mod.get_backend()
+        exchanged = self._exchanged()
+        mapper = self.name_mapper if exchanged else self._private_mapper
+        knames, snames = list(kernel_rows.keys()), list(section_rows.keys())
+        if not mapper.has_all_names(knames, snames):
+            if exchanged and self.world_size > 1:
+                return None  # ids must be agreed with the other ranks first: general path
+            for s in snames:
+                mapper._assign_section_id(s)
+            for k in knames:
+                mapper._assign_kernel_id(k)
+        K, S = mapper.kernel_counter, mapper.section_counter
+        world = self.world_size if exchanged else 1
+        total_rows = rings.local_ranks * rings.rows_per_rank
+        plan = self._RingPlan()
+        plan.key = key
+        plan.mapper = mapper
+        plan.ws = be.workspace(world * local_ranks, K, S, local_ranks, total_rows)
+        plan.snames, plan.knames = snames, knames
+        plan.rows_used = rings.rows_used
+        plan.stats_needed = rings.rows_used if rings.local_ranks == 1 else total_rows
+        plan.section_rows, plan.kernel_rows = section_rows, kernel_rows
+        if self.gather_on_rank0:
+            plan.ranks = range(plan.ws.R)
+            plan.names = [mapper.get_section_name(i) for i in range(S)]
+            plan.row_lo, plan.row_hi = 0, plan.ws.R
+        else:
+            me = self.rank * local_ranks if exchanged else 0
+            plan.ranks = range(self.rank * local_ranks, (self.rank + 1) * local_ranks)
+            plan.names = snames
+            plan.row_lo, plan.row_hi = me, me + local_ranks
+        plan.cols = {n: mapper.get_section_id(n) for n in plan.names}
+        # point every ring row at its slot of the exchange row (cold)
+        for name, row in rings.kernel_row_names.items():
+            g = mapper.kernel_name_to_id.get(name, -1) if _NCCL_MARKER not in name else -1
+            rings.configure(row, 1, g)
+        for name, row in rings.section_row_names.items():
+            g = mapper.section_name_to_id.get(name)
+            rings.configure(row, 0, K + g if g is not None else -1)
+        plan.ws.send_initialised = False
+        self._ring_gid_state = None  # the general path must re-derive its own view if it runs next
+        return plan
+
+    def _report_from_plan(self, plan, rings, t0):
+        """The steady-state report: three C calls (+ one collective), one host copy, lazy views."""
+        be = _backend_mod.get_backend()
+        ws = plan.ws
+        if self.world_size > 1 and self._exchanged():
+            with be.stream_context():  # the collective must queue behind the statistics kernel
+                rings.report_local(ws, True, rows_active=plan.rows_used)
+                table = dist_utils.all_gather_rows(ws.send, ws.table, self.group)
+        else:
+            rings.report_local(ws, True, rows_active=plan.rows_used)
+            table = ws.send
+        be.score(ws, table, self.is_computing_indiv_scores, self.is_computing_rel_scores, self.thresholds,
+                 wait=True, stats_rows=plan.stats_needed)
+        if ws.meta[0] != 1:
+            return False  # another rank met a new name: fall back to the general (name-syncing) path
+        if self.gather_on_rank0 and self.rank != 0:
+            return None
+        S, W, R = ws.S, ws.W, ws.R
+        blob = ws.host_block()  # one memcpy out of the pinned block; everything below views into it
+        lo, hi = plan.row_lo, plan.row_hi
+        off_s, off_f, off_t = ws._off_scores, ws._off_flags, ws._off_stats
+        cache = {}
+
+        def scores():
+            a = cache.get("s")
+            if a is None:
+                a = cache["s"] = blob[off_s : off_s + R * W * 4].view(np.float32).reshape(R, W)[lo:hi]
+            return a
+
+        def flags():
+            return blob[off_f : off_f + R * W].reshape(R, W)[lo:hi]
+
+        def stats():
+            return blob[off_t : off_t + plan.stats_needed * 32].view(np.float32).reshape(plan.stats_needed, 8)
+
+        has_rel, has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
+        ranks, names, cols = plan.ranks, plan.names, plan.cols
+        empty: Dict = {}
+        report = Report(
+            gpu_relative_perf_scores=RankScores(ranks, lambda: scores()[:, 1]) if has_rel else empty,
+            section_relative_perf_scores=(SectionScores(names, cols, ranks, lambda: scores()[:, 2 + S : 2 + 2 * S])
+                                          if (has_rel and names) else empty),
+            gpu_individual_perf_scores=RankScores(ranks, lambda: scores()[:, 0]) if has_indiv else empty,
+            section_individual_perf_scores=(SectionScores(names, cols, ranks, lambda: scores()[:, 2 : 2 + S])
+                                            if (has_indiv and names) else empty),
+            rank_to_node=self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
+            local_section_summaries=StatSummaries(plan.section_rows, stats),
+            local_kernel_summaries=StatSummaries(plan.kernel_rows, stats),
+            generate_report_elapsed_time=(time.perf_counter_ns() - t0) * 1e-6,
             gather_on_rank0=self.gather_on_rank0,
             rank=self.rank,
         )
@@ -443,7 +577,19 @@ class ReportGenerator:
         t0 = time.perf_counter_ns()
         self.world_size = dist_utils.get_world_size(self.group)
         self.rank = dist_utils.get_rank(self.group)
-        kernel_rows = {k: r for k, r in kernel_rows.items() if _NCCL_MARKER not in k}
+        # steady state: same name tables as last time -> run the cached plan
+        key = (id(section_rows), len(section_rows), id(kernel_rows), len(kernel_rows), self.name_mapper.version,
+               self._private_mapper.version, self.world_size, self.rank, rings.rows_used, local_ranks, id(rings))
+        plan = self._ring_plan
+        resync_first = False
+        if plan is not None and plan.key == key:
+            out = self._report_from_plan(plan, rings, t0)
+            if out is not False:
+                return out
+            self._ring_plan = None
+            resync_first = True  # some OTHER rank met a new name during this report's exchange
+        kernel_rows = {k: r for k, r in kernel_rows.items() if _NCCL_MARKER not in k} if any(
+            _NCCL_MARKER in k for k in kernel_rows) else kernel_rows
         self._maybe_gather_rank_to_node()
         if local_ranks > 1 and not getattr(self, "_rank_to_node_folded", False):
             # folded runs: every logical rank inherits the node of the process that holds it
@@ -471,8 +617,13 @@ class ReportGenerator:
             rings.report_local(ws, names_ok, rows_active=rows_used)
 
         ws, mapper = self._score_round(knames, snames, fill_send, local_ranks=local_ranks, stats_rows=total_rows,
-                                       stats_rows_used=stats_needed)
+                                       stats_rows_used=stats_needed, resync_first=resync_first)
         stats = ws.stats[:stats_needed].copy()
         sec_summ = StatSummaries(dict(section_rows), stats)
         ker_summ = StatSummaries(dict(kernel_rows), stats)
-        return self._assemble(ws, mapper, snames, sec_summ, ker_summ, t0, local_ranks=local_ranks)
+        report = self._assemble(ws, mapper, snames, sec_summ, ker_summ, t0, local_ranks=local_ranks)
+        # names are settled now: the next report with the same tables takes the planned path
+        key = (id(section_rows), len(section_rows), id(kernel_rows), len(kernel_rows), self.name_mapper.version,
+               self._private_mapper.version, self.world_size, self.rank, rings.rows_used, local_ranks, id(rings))
+        self._ring_plan = self._build_ring_plan(key, rings, section_rows, kernel_rows, local_ranks)
+        return report

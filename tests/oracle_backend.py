@@ -31,10 +31,22 @@ class OracleWorkspace:
         self.send = torch.zeros((local_ranks, self.L), dtype=torch.float32)
         self.table = torch.zeros((R, self.L), dtype=torch.float32) if R != local_ranks else self.send
         self.send_initialised = False
-        self.stats = np.zeros((stats_rows, STATS_STRIDE), dtype=np.float32)
-        self.meta = np.zeros(4, dtype=np.uint32)
-        self.scores = np.zeros((R, self.W), dtype=np.float32)
-        self.flags = np.zeros((R, self.W), dtype=np.uint8)
+        # same single-block layout as the product workspace: meta | scores | flags | stats
+        al = lambda n: (n + 63) // 64 * 64  # noqa: E731
+        self._off_meta = 0
+        self._off_scores = al(32)
+        self._off_flags = self._off_scores + al(R * self.W * 4)
+        self._off_stats = self._off_flags + al(R * self.W)
+        self.nbytes = self._off_stats + al(max(stats_rows, 1) * STATS_STRIDE * 4)
+        self._host = np.zeros(self.nbytes, dtype=np.uint8)
+        h = self._host
+        self.stats = h[self._off_stats : self._off_stats + stats_rows * 32].view(np.float32).reshape(stats_rows, STATS_STRIDE)
+        self.meta = h[0:32].view(np.uint32)
+        self.scores = h[self._off_scores : self._off_scores + R * self.W * 4].view(np.float32).reshape(R, self.W)
+        self.flags = h[self._off_flags : self._off_flags + R * self.W].reshape(R, self.W)
+
+    def host_block(self):
+        return self._host.copy()
 
     def set_send_row(self, lr, row):
         self.send[lr].copy_(torch.from_numpy(row))
@@ -82,7 +94,7 @@ class OracleBackend:
         thr = np.concatenate([[thresholds[2], thresholds[0]], np.full(ws.S, thresholds[3]), np.full(ws.S, thresholds[1])])
         with np.errstate(invalid="ignore"):
             ws.flags[:] = (ws.scores.astype(np.float64) < thr[None, :]).astype(np.uint8)
-        ws.meta[:] = [int((T[:, -1] > 0).all()), ws.R, ws.K, ws.S]
+        ws.meta[:4] = [int((T[:, -1] > 0).all()), ws.R, ws.K, ws.S]
 
 
 class OracleRings:

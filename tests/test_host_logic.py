@@ -357,3 +357,29 @@ def test_folded_job_over_two_gloo_ranks():
 def test_interval_tracker_ranks_agree():
     res = run_ranks(workers.interval_tracker_agreement, 2)
     assert res[0] == res[1] and res[0] >= 1
+
+
+def test_steady_state_plan_and_name_change_on_one_rank():
+    """Reports 0-2 run the cached plan; at report 3 only rank 1 has a new section, which must force both
+    ranks through the name sync (rank 0 learns it from the flag word in the gathered table); later
+    reports are planned again.  Scores follow the reference's rules (rank-only section -> NaN)."""
+    res = run_ranks(workers.detector_name_change_midway, 2)
+    assert res[0]["ids"] == res[1]["ids"] == {"a": 0, "b": 1, "late_rank1_only": 2, "late_everywhere": 3}
+    assert res[0]["planned"] and res[1]["planned"]
+    assert all(r is None for r in res[1]["reports"])
+    reps = res[0]["reports"]
+    for t in range(6):
+        rel = reps[t]["section_relative_perf_scores"]
+        assert rel["a"] == {0: 1.0, 1: 0.5}
+        assert rel["b"] == ({0: 1.0, 1: 1.0} if t < 4 else {0: 1.0, 1: 0.5})
+        if t >= 3:
+            assert math.isnan(rel["late_rank1_only"][0]) and math.isnan(rel["late_rank1_only"][1])
+            ind = reps[t]["section_individual_perf_scores"]["late_rank1_only"]
+            assert math.isnan(ind[0]) and ind[1] == 1.0
+        else:
+            assert "late_rank1_only" not in rel
+        if t == 5:
+            assert rel["late_everywhere"] == {0: 1.0, 1: 1.0}
+    # individual scores remember the best median: b doubled on rank 0 (4 -> 8) and x4 on rank 1
+    assert reps[5]["section_individual_perf_scores"]["b"] == {0: 0.5, 1: 0.25}
+    assert reps[5]["stragglers"]["0.75"]["straggler_sections_individual"] == {"b": [0, 1]}

@@ -150,3 +150,36 @@ def interval_tracker_agreement(rank, world):
         tr.iter_increase()
         time.sleep(0.002 * (1 + rank))  # ranks run at different speeds; the MAX must win everywhere
     return tr.iter_interval
+
+
+def detector_name_change_midway(rank, world):
+    """Several reports through the cached steady-state plan; then one rank alone meets a new section,
+    which must push EVERY rank through the name-syncing path (the flag rides in the exchange row)."""
+    import numpy as np
+
+    from nvrx_straggler import Detector
+
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name=f"h{rank}")
+    out = []
+    try:
+        def feed(name, value, n=5):
+            with Detector.detection_section(name, profile_cuda=False):
+                pass
+            sec = Detector.custom_sections[name]
+            sec.cpu_elapsed_times.clear()
+            sec.cpu_elapsed_times.extend(np.full(n, value, dtype=np.float32))
+
+        for t in range(6):
+            feed("a", 2.0 * (rank + 1))
+            feed("b", 4.0 if t < 4 else 8.0 * (rank + 1))
+            if t >= 3 and rank == 1:
+                feed("late_rank1_only", 1.0)
+            if t == 5:
+                feed("late_everywhere", 3.0)
+            rep = Detector.generate_report()
+            out.append(report_to_plain(rep))
+        planned = Detector.reporter._ring_plan is not None
+        return {"reports": out, "planned": planned,
+                "ids": dict(Detector.reporter.name_mapper.section_name_to_id)}
+    finally:
+        Detector.shutdown()
