@@ -149,9 +149,23 @@ struct Epilogue {
 };
 
 // Ablation switch for tools/kbench.cpp only (always 0 in the shipped library):
-// 1 = load + min/max/mean, 2 = + squared deviations, 3 = + one radix pass, 0 = everything.
+// 1 = load + min/max/mean/std only (no selection), 0 = everything.
 #ifndef NVRX_ABLATE
 #define NVRX_ABLATE 0
+#endif
+
+// Phase clocks for tools/kbench.cpp only (never defined in the shipped library): thread 0 of every
+// workgroup stores the shader clock at phase boundaries.
+#ifdef NVRX_PHASE_CLOCKS
+__device__ unsigned long long g_phase[4096][12];
+#define NVRX_PHASE(i)                                                                     \
+    do {                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_phase[blockIdx.x][i] = clock64(); \
+    } while (0)
+#else
+#define NVRX_PHASE(i) \
+    do {              \
+    } while (0)
 #endif
 
 constexpr int HIST_BITS = 11;
@@ -161,25 +175,71 @@ constexpr int HIST_BINS = 1 << HIST_BITS;
 // k_row_stats: one workgroup per timing row.
 //   HBM: the row is read once, 16 B per lane per load, VPT independent loads in flight per lane.
 //   Registers: the row lives in VPT*4 order-preserving keys per lane for the rest of the kernel.
-//   LDS: 8 KB histogram + a few words of reduction scratch.
+//   LDS: 8 KB histogram + thread sums + a 1 KB candidate list + a few words of reduction scratch.
+//
+// What bounds it (tools/micro/*.cpp, phase clocks of tools/kbench.cpp): a row of n keys on one CU costs
+// n/64 clk per VALU instruction applied to every key (156 clk at n = 10 000), ~10 clk of the CU's LDS
+// pipe per DS instruction however few lanes are active (one histogram pass = n/64 DS instructions =
+// ~1600 clk), and every exchange between waves is a dependent chain (LDS round trip ~75 clk, returning
+// LDS atomic ~250, 6-step DPP reduction ~150, exchange through a barrier ~175).  So the kernel
+// (1) keeps the per-key instruction count low, (2) starts the histogram before the row's exact range
+// is known, so that its DS traffic runs under the HBM load instead of after it, and (3) keeps the
+// number of exchanges after the last tile small:
+//
+//   tile 0 (the first THREADS*4 samples) gives a range estimate [mn0 - R, mx0 + R], R = mx0 - mn0
+//   -> every key of every tile goes into a 2048-bin LDS histogram over that range as its tile arrives
+//      (keys outside are clamped into the two edge bins), while min / max / moments accumulate
+//   -> ONE exchange (thread sums; every wave then scans them on its own, results wave-uniform in SGPRs)
+//      locates the bin holding rank k = (n-1)/2
+//   -> the bin's few members append themselves to a candidate list (a wave only leaves its compare
+//      loop where one of its lanes holds a member) and every wave ranks the candidates on its own.
+//
+// The result is always exact: if the median lands in an edge bin (the estimate missed: drifting or
+// heavy-tailed rows) the histogram is rebuilt over the exact [kmin, kmax]; a bin too heavy to rank
+// directly (> CAND_MAX members, e.g. many equal samples) is refined by further 11-bit passes until it
+// is a single key value.  Rows that fit in one tile skip the estimate: tile 0 is the whole row.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// min and max reductions interleaved so that the two dependent DPP chains hide each other's latency
+__device__ __forceinline__ void wave_minmax_u32(uint32_t &mn, uint32_t &mx) {
+    mn = min(mn, dpp<DPP_QUAD_1032>(mn, mn));
+    mx = max(mx, dpp<DPP_QUAD_1032>(mx, mx));
+    mn = min(mn, dpp<DPP_QUAD_2301>(mn, mn));
+    mx = max(mx, dpp<DPP_QUAD_2301>(mx, mx));
+    mn = min(mn, dpp<DPP_ROW_SHR4>(mn, mn));
+    mx = max(mx, dpp<DPP_ROW_SHR4>(mx, mx));
+    mn = min(mn, dpp<DPP_ROW_SHR8>(mn, mn));
+    mx = max(mx, dpp<DPP_ROW_SHR8>(mx, mx));
+    mn = min(mn, dpp<DPP_BCAST15>(mn, mn));
+    mx = max(mx, dpp<DPP_BCAST15>(mx, mx));
+    mn = min(mn, dpp<DPP_BCAST31>(mn, mn));
+    mx = max(mx, dpp<DPP_BCAST31>(mx, mx));
+    mn = (uint32_t)__builtin_amdgcn_readlane((int)mn, 63);
+    mx = (uint32_t)__builtin_amdgcn_readlane((int)mx, 63);
+}
+
 template <int THREADS, int VPT>
 __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__ samples,
                                                        const uint32_t *__restrict__ counts,
                                                        const uint8_t *__restrict__ kinds, int row_stride,
                                                        float *__restrict__ stats, Epilogue ep) {
     constexpr int WAVES = THREADS / 64;
-    constexpr int PER = HIST_BINS / THREADS;  // histogram bins scanned per thread
+    constexpr int PER = HIST_BINS / THREADS;  // histogram bins summed per thread
+    constexpr int G = THREADS / 64;           // thread sums per lane in the wave-redundant scan
     constexpr int NKEY = VPT * 4;
     constexpr int CAND_MAX = 256;  // a selected bin this small is finished by direct ranking
+    constexpr int SEG = CAND_MAX / WAVES;  // candidate slots per wave
     static_assert(HIST_BINS % THREADS == 0, "THREADS must divide the histogram size");
+    static_assert(THREADS >= CAND_MAX, "candidate list is initialised one word per thread");
 
-    __shared__ uint32_t s_hist[HIST_BINS];
-    __shared__ uint32_t s_cand[CAND_MAX];
-    __shared__ double s_d[2 * WAVES];    // [0,W) partial sums, [W,2W) partial squared deviations
-    __shared__ uint32_t s_u[3 * WAVES];  // [0,W) min keys, [W,2W) max keys, [2W,3W) scan totals
-    __shared__ uint32_t s_bc[4];         // {selected bin, rank inside it, its population, candidate cursor}
-    __shared__ uint32_t s_res[1];        // key offset found by direct ranking
+    __shared__ __attribute__((aligned(16))) uint32_t s_hist[HIST_BINS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_sum[THREADS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cand[CAND_MAX];  // WAVES private segments of SEG slots
+    __shared__ __attribute__((aligned(16))) uint32_t s_lt[CAND_MAX];    // per slot: how many candidates are smaller
+    __shared__ __attribute__((aligned(16))) double s_d[2 * WAVES];  // [0,W) partial sums, [W,2W) squared deviations
+    __shared__ __attribute__((aligned(16))) uint32_t s_mm[4];       // {tile-0 min, tile-0 max, row min, row max}
+    __shared__ uint32_t s_cur[1];                                   // set when a wave's candidate segment overflowed
 
     const int row = ep.rows_active ? (int)(blockIdx.x / ep.rows_active) * ep.rows_per_rank + (int)(blockIdx.x % ep.rows_active)
                                    : (int)blockIdx.x;
@@ -187,6 +247,10 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
+    NVRX_PHASE(0);
+#ifdef NVRX_PHASE_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_phase[blockIdx.x][10] = wall_clock64();
+#endif
     uint32_t n = counts[row];
     if (n > (uint32_t)row_stride) n = (uint32_t)row_stride;
     const int kind = kinds ? kinds[row] : NVRX_KIND_SECTION;
@@ -195,6 +259,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
     const float row_hmin = ep.hist_min ? ep.hist_min[row] : __builtin_nanf("");
 
     float r_min, r_max, r_med, r_avg, r_std;
+    int path = 0;  // diagnostic: 1 = estimate held, 2 = histogram rebuilt over the exact range, +4 = refined
 
     if (n == 0) {
         r_min = r_max = r_med = r_avg = r_std = __builtin_nanf("");
@@ -210,198 +275,314 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((uint32_t)(v * 4) < n) x[i] = src[v];
         }
-        // the histogram is cleared while the loads are in flight
+        // LDS scratch is initialised while the loads are in flight
 #pragma unroll
         for (int j = 0; j < PER; j++) s_hist[tid * PER + j] = 0u;
+        if (tid < CAND_MAX) {
+            s_cand[tid] = 0xFFFFFFFFu;
+            s_lt[tid] = 0u;
+        }
+        if (tid < 4) s_mm[tid] = (tid & 1) ? 0u : 0xFFFFFFFFu;
+        if (tid == 0) s_cur[0] = 0u;
+        __syncthreads();  // (0)
 
-        // ---- min / max / sum / sum of squares in ONE pass over the registers, branch-free ---------------
+        // Tiles that are valid for every lane (i < full_tiles, block-uniform) skip the tail masking;
+        // slots past the row's end get the key 0xFFFFFFFF and never take part in anything.
+        const int full_tiles = (int)(n / (uint32_t)(THREADS * 4));
+        const uint32_t k_rank = (n - 1u) >> 1;
+        const double inv_n = 1.0 / (double)n;  // off the critical path: computed while the loads are in flight
+
+        // ---- tile 0: keys, and the range estimate the histogram is laid over ---------------------------
+        uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
+        {
+            const float xs[4] = {x[0].x, x[0].y, x[0].z, x[0].w};
+            const uint32_t e = (uint32_t)tid * 4u;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const bool valid = full_tiles > 0 || e + c < n;
+                const uint32_t kk = f2key(xs[c]);
+                key[c] = valid ? kk : 0xFFFFFFFFu;
+                kmn = min(kmn, key[c]);
+                kmx = max(kmx, valid ? kk : 0u);
+            }
+            uint32_t a = kmn, b = kmx;
+            wave_minmax_u32(a, b);
+            if (lane == 0) {
+                atomicMin(&s_mm[0], a);
+                atomicMax(&s_mm[1], b);
+            }
+        }
+        __syncthreads();  // (1) tile-0 range
+        const bool speculative = VPT > 1 && n > (uint32_t)(THREADS * 4);
+        uint32_t lo0, sh;  // histogram origin (a key) and log2 of the bin width
+        {
+            const uint32_t mn0 = uni(s_mm[0]), mx0 = uni(s_mm[1]);
+            const uint32_t R = speculative ? mx0 - mn0 : 0u;
+            lo0 = mn0 > R ? mn0 - R : 0u;
+            const uint32_t hi0 = mx0 < 0xFFFFFFFFu - R ? mx0 + R : 0xFFFFFFFFu;
+            const int top = 32 - __clz((int)(hi0 - lo0));  // (hi0 - lo0) >> sh < 2048
+            sh = (uint32_t)(top > HIST_BITS ? top - HIST_BITS : 0);
+        }
+        NVRX_PHASE(1);
+
+        // ---- every tile: histogram + min / max + moments in ONE pass over the registers ------------------
         // f32 partials per lane around the lane's own pivot p (its first sample): s = sum(x-p),
         // q = sum((x-p)^2).  Once the row mean m is known each lane turns them into its exact share of
         // sum((x-m)^2) = q - 2(m-p)s + cnt(m-p)^2 in f64; cross-lane sums are f64 throughout.
         const float pivot = x[0].x;
-        uint32_t kmn = 0xFFFFFFFFu, kmx = 0u, cnt = 0u;
+        uint32_t cnt = 0u;
         float psum = 0.f, psq = 0.f;
 #pragma unroll
         for (int i = 0; i < VPT; i++) {
-            const uint32_t e = (uint32_t)(i * THREADS + tid) * 4u;
             const float xs[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+            if (i < full_tiles) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const bool valid = e + c < n;
-                const uint32_t kk = f2key(xs[c]);
-                key[i * 4 + c] = kk;
-                kmn = min(kmn, valid ? kk : 0xFFFFFFFFu);
-                kmx = max(kmx, valid ? kk : 0u);
-                const float d = valid ? xs[c] - pivot : 0.f;
-                psum += d;
-                psq = fmaf(d, d, psq);
-                cnt += valid ? 1u : 0u;
+                for (int c = 0; c < 4; c++) {
+                    uint32_t kk;
+                    if (i == 0) {
+                        kk = key[c];
+                    } else {
+                        kk = f2key(xs[c]);
+                        key[i * 4 + c] = kk;
+                        kmn = min(kmn, kk);
+                        kmx = max(kmx, kk);
+                    }
+                    const float d = xs[c] - pivot;
+                    psum += d;
+                    psq = fmaf(d, d, psq);
+                    if (NVRX_ABLATE == 0) atomicAdd(&s_hist[min(__builtin_elementwise_sub_sat(kk, lo0) >> sh, (uint32_t)(HIST_BINS - 1))], 1u);
+                }
+                cnt += 4u;
+            } else {
+                const uint32_t e = (uint32_t)(i * THREADS + tid) * 4u;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const bool valid = e + c < n;
+                    uint32_t kk;
+                    if (i == 0) {
+                        kk = key[c];
+                    } else {
+                        kk = valid ? f2key(xs[c]) : 0xFFFFFFFFu;
+                        key[i * 4 + c] = kk;
+                        kmn = min(kmn, kk);
+                        kmx = max(kmx, valid ? kk : 0u);
+                    }
+                    const float d = valid ? xs[c] - pivot : 0.f;
+                    psum += d;
+                    psq = fmaf(d, d, psq);
+                    cnt += valid ? 1u : 0u;
+                    if (NVRX_ABLATE == 0 && valid)
+                        atomicAdd(&s_hist[min(__builtin_elementwise_sub_sat(kk, lo0) >> sh, (uint32_t)(HIST_BINS - 1))], 1u);
+                }
             }
         }
-        kmn = wave_min_u32(kmn);
-        kmx = wave_max_u32(kmx);
+        wave_minmax_u32(kmn, kmx);
         double sum = wave_sum_f64((double)psum + (double)cnt * (double)pivot);
         if (lane == 0) {
-            s_u[wave] = kmn;
-            s_u[WAVES + wave] = kmx;
+            atomicMin(&s_mm[2], kmn);
+            atomicMax(&s_mm[3], kmx);
             s_d[wave] = sum;
         }
-        __syncthreads();  // (1) partials published, histogram cleared
-        kmn = s_u[0];
-        kmx = s_u[WAVES];
-        sum = s_d[0];
+        NVRX_PHASE(2);
+        __syncthreads();  // (2) histogram complete, row min / max / partial sums published
+        kmn = uni(s_mm[2]);
+        kmx = uni(s_mm[3]);
+        NVRX_PHASE(3);
+
+        // Locate rank k in the finished histogram: every thread sums its PER consecutive bins, ONE
+        // exchange, then every wave scans all THREADS sums on its own (lane L holds sums [L*G, L*G+G)).
+        // Returns the bin; k becomes the rank inside it, pop its population (all wave-uniform).
+        auto locate = [&](uint32_t &k, uint32_t &pop) -> uint32_t {
+            {
+                uint32_t local = 0u;
 #pragma unroll
-        for (int w = 1; w < WAVES; w++) {
-            kmn = min(kmn, s_u[w]);
-            kmx = max(kmx, s_u[WAVES + w]);
-            sum += s_d[w];
-        }
-        const double mean = sum / (double)n;
-        if (NVRX_ABLATE != 1) {
+                for (int j = 0; j < PER; j++) local += s_hist[tid * PER + j];
+                s_sum[tid] = local;
+            }
+            __syncthreads();  // thread sums published
+            uint32_t ts[G];
+            uint32_t local = 0u;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                ts[g] = s_sum[lane * G + g];
+                local += ts[g];
+            }
+            const uint32_t incl = wave_scan_u32(local);
+            const uint32_t excl = incl - local;
+            // inside every lane: how many of its G sums lie wholly below rank k, and their total
+            // (plain VALU in all lanes at once; only the owner lane's answer is read back)
+            uint32_t gcnt = 0u, gblw = 0u;
+            {
+                uint32_t run = excl;
+#pragma unroll
+                for (int g = 0; g < G - 1; g++) {
+                    run += ts[g];
+                    const bool adv = k >= run;
+                    gcnt += adv ? 1u : 0u;
+                    gblw = adv ? run : gblw;
+                }
+            }
+            gblw = max(gblw, excl);
+            const int L = __builtin_ctzll(__ballot(k >= excl && k < incl));  // exactly one lane owns rank k
+            const uint32_t gsel = (uint32_t)__builtin_amdgcn_readlane((int)gcnt, L);
+            uint32_t krem = k - (uint32_t)__builtin_amdgcn_readlane((int)gblw, L);
+            const uint32_t tsel = (uint32_t)L * G + gsel;  // thread whose PER bins hold rank k
+            uint32_t bsel = 0u;
+            {
+                // same address in every lane (LDS broadcast): the values are wave-uniform VGPRs
+                uint32_t run = 0u, blw = 0u;
+                pop = s_hist[tsel * PER];
+#pragma unroll
+                for (int j = 0; j < PER - 1; j++) {
+                    run += s_hist[tsel * PER + j];
+                    const bool adv = krem >= run;
+                    bsel += adv ? 1u : 0u;
+                    blw = adv ? run : blw;
+                    pop = adv ? s_hist[tsel * PER + j + 1] : pop;
+                }
+                krem -= blw;
+                bsel = uni(bsel);
+                krem = uni(krem);
+                pop = uni(pop);
+            }
+            k = krem;
+            return tsel * PER + bsel;
+        };
+
+        // mean and this wave's share of the squared deviations (needs the partial sums of barrier (2))
+        double mean = 0.0;
+        auto finish_moments = [&]() {
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) mean += s_d[w];  // = row sum, same order in every thread
+            mean = mean * inv_n;
             const double dm = mean - (double)pivot;
             const double lane_ss = (double)psq - 2.0 * dm * (double)psum + (double)cnt * dm * dm;
             const double wss = wave_sum_f64(lane_ss);
-            if (lane == 0) s_d[WAVES + wave] = wss;  // consumed after the final barrier
-        }
-        // tail slots are padded with the max key: padding sorts last and never moves rank k < n
-#pragma unroll
-        for (int i = 0; i < VPT; i++) {
-            const uint32_t e = (uint32_t)(i * THREADS + tid) * 4u;
-#pragma unroll
-            for (int c = 0; c < 4; c++) key[i * 4 + c] = (e + c < n) ? key[i * 4 + c] : kmx;
-        }
+            if (lane == 0) s_d[WAVES + wave] = wss;
+        };
 
-        // ---- exact selection of rank k = (n-1)/2 by radix select on d = key - kmin ---------------------
-        // Only the bits below the top set bit of (kmax - kmin) can differ, so clustered timing data
-        // needs ONE 11-bit histogram pass spread over the data's own range; the selected bin is then
-        // small enough to be ranked directly.  Heavier bins fall back to further radix passes.
-        const uint32_t k_rank = (n - 1u) >> 1;
-        const uint32_t range = kmx - kmn;
-        int hi = 32 - __clz((int)range);  // __clz(0) == 32 -> hi = 0: all samples equal
-        uint32_t prefix = 0u;
-        uint32_t k = k_rank;
-        bool first = true;
-        if (NVRX_ABLATE == 1 || NVRX_ABLATE == 2) hi = 0;
-        while (hi > 0) {
-            const int lo = hi > HIST_BITS ? hi - HIST_BITS : 0;
-            const int nb = 1 << (hi - lo);
-            const uint32_t bmask = (uint32_t)nb - 1u;
-            if (first) {
-                // every key participates: no predicate, histogram already cleared
+        uint32_t med_key;
+        if (NVRX_ABLATE != 0 || kmn == kmx) {
+            med_key = kmn;  // all samples equal (or selection ablated)
+            finish_moments();
+            __syncthreads();
+        } else {
+            uint32_t k = k_rank, pop;
+            uint32_t bin = locate(k, pop);
+            path = 1;
+            if (speculative && (bin == 0u || bin == (uint32_t)(HIST_BINS - 1))) {
+                // The estimate missed: the edge bins also hold everything that was clamped.  Rebuild the
+                // histogram over the exact range (nothing is clamped any more) and locate again.
+                path = 2;
+                lo0 = kmn;
+                const int top = 32 - __clz((int)(kmx - kmn));
+                sh = (uint32_t)(top > HIST_BITS ? top - HIST_BITS : 0);
 #pragma unroll
-                for (int j = 0; j < NKEY; j++) atomicAdd(&s_hist[((key[j] - kmn) >> lo) & bmask], 1u);
-            } else {
-                const uint32_t mask_hi = hi >= 32 ? 0u : (0xFFFFFFFFu << hi);
-                for (int b = tid; b < nb; b += THREADS) s_hist[b] = 0u;
+                for (int j = 0; j < PER; j++) s_hist[tid * PER + j] = 0u;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < NKEY; j++)
+                    if (key[j] != 0xFFFFFFFFu || (j < full_tiles * 4)) atomicAdd(&s_hist[(key[j] - lo0) >> sh], 1u);
+                __syncthreads();
+                k = k_rank;
+                bin = locate(k, pop);
+            }
+            uint32_t base = lo0 + (bin << sh);  // first key of the bin that holds the median
+            NVRX_PHASE(4);
+            bool moments_done = false;
+            while (sh > 0u) {
+                if (pop <= (uint32_t)CAND_MAX) {
+                    // ---- finish by ranking the bin's few members directly ----------------------------------
+                    // Members go to this wave's private segment of s_cand: the wave-uniform cursor lives in an
+                    // SGPR, so appending costs no LDS atomic, and a wave only leaves the compare loop where
+                    // one of its lanes holds a member.
+                    uint32_t wcnt = 0u;
+#pragma unroll
+                    for (int j = 0; j < NKEY; j++) {
+                        const uint32_t r = key[j] - base;  // wraps to a huge value below the bin
+                        const bool member = (r >> sh) == 0u;
+                        const unsigned long long bal = __ballot(member);
+                        if (bal) {  // wave-uniform
+                            const uint32_t pos = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                            if (member && pos < (uint32_t)SEG) s_cand[wave * SEG + pos] = r;
+                            wcnt += (uint32_t)__popcll(bal);
+                        }
+                    }
+                    if (wcnt > (uint32_t)SEG && lane == 0) s_cur[0] = 1u;
+                    if (!moments_done) {
+                        finish_moments();
+                        moments_done = true;
+                    }
+                    __syncthreads();  // candidates listed (unused slots hold 0xFFFFFFFF), deviation partials published
+                    NVRX_PHASE(5);
+                    if (uni(s_cur[0]) == 0u) {
+                        // All-pairs ranking split over the waves: every lane owns 4 of the CAND_MAX slots, each
+                        // wave compares all owners with ITS OWN members only and adds its partial "smaller than"
+                        // counts into s_lt; after one more exchange every wave picks the value at rank k on its
+                        // own -- the largest candidate with lt <= k (empty slots compare as +inf: lt = pop > k).
+                        const uint4 own = reinterpret_cast<const uint4 *>(s_cand)[lane];
+                        const uint32_t cv[4] = {own.x, own.y, own.z, own.w};
+                        uint32_t lt[4] = {0u, 0u, 0u, 0u};
+                        const uint4 *seg4 = reinterpret_cast<const uint4 *>(s_cand + wave * SEG);
+                        for (uint32_t j = 0; j < min(wcnt, (uint32_t)SEG); j += 4u) {
+                            const uint4 v = seg4[j >> 2];  // same address in every lane: LDS broadcast
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                lt[q] += (v.x < cv[q]) ? 1u : 0u;
+                                lt[q] += (v.y < cv[q]) ? 1u : 0u;
+                                lt[q] += (v.z < cv[q]) ? 1u : 0u;
+                                lt[q] += (v.w < cv[q]) ? 1u : 0u;
+                            }
+                        }
+                        if (wcnt) {  // wave-uniform
+#pragma unroll
+                            for (int q = 0; q < 4; q++) atomicAdd(&s_lt[lane * 4 + q], lt[q]);
+                        }
+                        __syncthreads();  // partial counts added up
+                        const uint4 tot = reinterpret_cast<const uint4 *>(s_lt)[lane];
+                        uint32_t best = tot.x <= k ? cv[0] : 0u;
+                        best = max(best, tot.y <= k ? cv[1] : 0u);
+                        best = max(best, tot.z <= k ? cv[2] : 0u);
+                        best = max(best, tot.w <= k ? cv[3] : 0u);
+                        base += wave_max_u32(best);
+                        sh = 0u;
+                        break;
+                    }
+                    // a wave held more members than its segment takes: start over with a finer histogram
+                    __syncthreads();
+                    if (tid < CAND_MAX) s_cand[tid] = 0xFFFFFFFFu;
+                    if (tid == 0) s_cur[0] = 0u;
+                }
+                // ---- too heavy to rank directly: spread the bin's members over up to 2048 finer bins -------
+                path |= 4;
+                const uint32_t sh2 = sh > (uint32_t)HIST_BITS ? sh - (uint32_t)HIST_BITS : 0u;
+                __syncthreads();  // every wave is done reading s_hist / s_sum
+#pragma unroll
+                for (int j = 0; j < PER; j++) s_hist[tid * PER + j] = 0u;
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < NKEY; j++) {
-                    const uint32_t d = key[j] - kmn;
-                    if ((d & mask_hi) == prefix) atomicAdd(&s_hist[(d >> lo) & bmask], 1u);
+                    const uint32_t r = key[j] - base;
+                    if ((r >> sh) == 0u) atomicAdd(&s_hist[r >> sh2], 1u);
                 }
+                __syncthreads();
+                bin = locate(k, pop);
+                base += bin << sh2;
+                sh = sh2;
             }
-            __syncthreads();  // (2) histogram complete
-            // block-wide exclusive scan of the histogram, PER consecutive bins per thread
-            uint32_t c[PER];
-            uint32_t local = 0u;
-#pragma unroll
-            for (int j = 0; j < PER; j++) {
-                const int b = tid * PER + j;
-                c[j] = b < nb ? s_hist[b] : 0u;
-                local += c[j];
+            if (!moments_done) {
+                finish_moments();
+                __syncthreads();
             }
-            const uint32_t incl = wave_scan_u32(local);
-            if (lane == 63) s_u[2 * WAVES + wave] = incl;
-            __syncthreads();  // (3) wave totals
-            uint32_t base = 0u;
-#pragma unroll
-            for (int w = 0; w < WAVES; w++) base += (w < wave) ? s_u[2 * WAVES + w] : 0u;
-            const uint32_t excl = base + incl - local;
-            if (k >= excl && k < excl + local) {
-                uint32_t b = (uint32_t)tid * PER, below = excl, pop = c[0];
-#pragma unroll
-                for (int j = 0; j < PER - 1; j++) {
-                    const bool adv = (b == (uint32_t)tid * PER + j) && (k >= below + c[j]);
-                    below += adv ? c[j] : 0u;
-                    pop = adv ? c[j + 1] : pop;
-                    b += adv ? 1u : 0u;
-                }
-                s_bc[0] = b;
-                s_bc[1] = k - below;
-                s_bc[2] = pop;
-                s_bc[3] = 0u;
-            }
-            __syncthreads();  // (4) selected bin published
-            prefix |= s_bc[0] << lo;
-            k = s_bc[1];
-            const uint32_t pop = s_bc[2];
-            hi = lo;
-            first = false;
-            if (NVRX_ABLATE == 3) break;
-            if (hi > 0 && pop <= (uint32_t)CAND_MAX) {
-                // ---- finish by ranking the bin's few members directly -------------------------------
-                // Wave-aggregated compaction: ballots count the wave's members (scalar adds), lane 0
-                // reserves the wave's span of s_cand with ONE atomic, members then store themselves.
-                const uint32_t mask_sel = 0xFFFFFFFFu << hi;
-                uint32_t wave_members = 0u;
-#pragma unroll
-                for (int j = 0; j < NKEY; j++)
-                    wave_members += (uint32_t)__popcll(__ballot(((key[j] - kmn) & mask_sel) == prefix));
-                if (wave_members) {  // wave-uniform
-                    uint32_t base = 0u;
-                    if (lane == 0) base = atomicAdd(&s_bc[3], wave_members);
-                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-                    for (int j = 0; j < NKEY; j++) {
-                        const uint32_t d = key[j] - kmn;
-                        const bool member = (d & mask_sel) == prefix;
-                        const unsigned long long b = __ballot(member);
-                        if (b) {  // wave-uniform
-                            if (member) s_cand[base + (uint32_t)__popcll(b & lt)] = d;
-                            base += (uint32_t)__popcll(b);
-                        }
-                    }
-                }
-                __syncthreads();  // (5) candidates listed
-                // Wave-parallel ranking: each wave takes every WAVES-th candidate, its 64 lanes compare
-                // it with the whole list (<= 4 chunks of 64) and a ballot popcount gives its rank.
-                const int chunks = (int)((pop + 63u) >> 6);
-                uint32_t cv[CAND_MAX / 64];
-#pragma unroll
-                for (int q = 0; q < CAND_MAX / 64; q++) {
-                    const uint32_t idx = (uint32_t)(q * 64 + lane);
-                    cv[q] = (q < chunks && idx < pop) ? s_cand[idx] : 0xFFFFFFFFu;
-                }
-                for (uint32_t i = (uint32_t)wave; i < pop; i += WAVES) {
-                    // candidate i lives in lane (i & 63) of chunk (i >> 6): broadcast it without LDS
-                    uint32_t src = cv[0];
-#pragma unroll
-                    for (int q = 1; q < CAND_MAX / 64; q++) src = ((int)(i >> 6) == q) ? cv[q] : src;
-                    const uint32_t mine = (uint32_t)__builtin_amdgcn_readlane((int)src, (int)(i & 63u));
-                    uint32_t below = 0u;
-#pragma unroll
-                    for (int q = 0; q < CAND_MAX / 64; q++) {
-                        if (q < chunks) {  // wave-uniform
-                            const uint32_t idx = (uint32_t)(q * 64 + lane);
-                            const bool less = idx < pop && (cv[q] < mine || (cv[q] == mine && idx < i));
-                            below += (uint32_t)__popcll(__ballot(less));
-                        }
-                    }
-                    if (below == k && lane == 0) s_res[0] = mine;
-                }
-                __syncthreads();  // (6) result
-                prefix = s_res[0];
-                hi = 0;
-                break;
-            }
-            __syncthreads();  // s_hist / s_u / s_bc are reused by the next pass
+            med_key = base;
+            NVRX_PHASE(6);
         }
-        const uint32_t dsel = prefix;
-        float med = key2f(kmn + dsel);
+        const uint32_t dsel = med_key - kmn;
+        float med = key2f(med_key);
 
         if (kind == NVRX_KIND_KERNEL && (n & 1u) == 0u) {
-            // mean of the two middle order statistics (CuptiProfiler.cpp:57-59): also need rank k+1
+            // mean of the two middle order statistics (CuptiProfiler.cpp:57-59): also need rank k+1.
+            // Slots past the row's end hold 0xFFFFFFFF and sort after every real sample.
             uint32_t cnt_le = 0u, mn_gt = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 0; j < NKEY; j++) {
@@ -411,29 +592,28 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             }
             cnt_le = wave_sum_u32(cnt_le);
             mn_gt = wave_min_u32(mn_gt);
-            __syncthreads();  // everyone is done reading s_u from the min/max phase
+            __syncthreads();  // s_sum is free again
             if (lane == 0) {
-                s_u[wave] = cnt_le;
-                s_u[WAVES + wave] = mn_gt;
+                s_sum[wave] = cnt_le;
+                s_sum[WAVES + wave] = mn_gt;
             }
             __syncthreads();
-            cnt_le = s_u[0];
-            mn_gt = s_u[WAVES];
+            cnt_le = s_sum[0];
+            mn_gt = s_sum[WAVES];
 #pragma unroll
             for (int w = 1; w < WAVES; w++) {
-                cnt_le += s_u[w];
-                mn_gt = min(mn_gt, s_u[WAVES + w]);
+                cnt_le += s_sum[w];
+                mn_gt = min(mn_gt, s_sum[WAVES + w]);
             }
             const uint32_t dnext = (cnt_le >= k_rank + 2u) ? dsel : mn_gt;
             med = (med + key2f(kmn + dnext)) / 2.0f;
         }
 
-        __syncthreads();  // squared-deviation partials of every wave are visible
+        NVRX_PHASE(7);
+        // squared-deviation partials were published before the last barrier each path went through
         double ss = 0.0;
-        if (NVRX_ABLATE != 1) {
 #pragma unroll
-            for (int w = 0; w < WAVES; w++) ss += s_d[WAVES + w];
-        }
+        for (int w = 0; w < WAVES; w++) ss += s_d[WAVES + w];
         r_min = key2f(kmn);
         r_max = key2f(kmx);
         r_med = med;
@@ -455,7 +635,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         o[NVRX_STAT_STD] = r_std;
         o[NVRX_STAT_NUM] = (float)n;
         o[NVRX_STAT_WEIGHT] = weight;
-        o[7] = 0.0f;
+        o[7] = (float)path;  // diagnostic only (selection path taken)
         float h = row_hmin;
         if (ep.hist_min) {
             // _update_local_min_times (reporting.py:298-314): history is never reset by a report
@@ -476,6 +656,10 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             if (row - lr * ep.rows_per_rank == 0) s[ep.L - 1] = ep.names_ok;
         }
     }
+    NVRX_PHASE(8);
+#ifdef NVRX_PHASE_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_phase[blockIdx.x][9] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1028,6 +1212,7 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_hist_min), (size_t)ctx->rows * sizeof(float)));
     hipLaunchKernelGGL(k_fill_f32, dim3((ctx->rows + 255) / 256), dim3(256), 0, nullptr, ctx->d_hist_min, (size_t)ctx->rows, INFINITY);
     CTX_TRY(hipGetLastError());
+
     CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_kinds), (size_t)ctx->rows, hipHostMallocDefault));
     CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_gid), (size_t)ctx->rows * sizeof(int32_t), hipHostMallocDefault));
     memset(ctx->h_kinds, 0, (size_t)ctx->rows);

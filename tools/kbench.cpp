@@ -1,56 +1,189 @@
 // tools/kbench.cpp -- standalone timing of k_row_stats variants on the folded N=1 shape
-// (512 rows x 10000 f32).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude [-DNVRX_ABLATE=k]
-//   tools/kbench.cpp -o /tmp/kbench ; run: /tmp/kbench [rows] [n] [threads]
+// (512 rows x 10000 f32), with a CPU check of every row's median/min/max/mean/std.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude [-DNVRX_ABLATE=k] [-DNVRX_PHASE_CLOCKS]
+//   tools/kbench.cpp -o tools/bin/kbench ; run: kbench [rows] [n] [threads] [dist]
+// dist: 0 = N(10,0.3) (bench shape), 1 = lognormal heavy tail, 2 = few distinct values, 3 = drifting ramp + noise
 // Includes the library source directly so ablation builds need no second copy of the kernel.
 #include "../nvidia-resiliency-ext_amd/csrc/nvrx_straggler.hip"
 
 #include <random>
 
+#define CK(x)                                                                        \
+    do {                                                                             \
+        hipError_t e_ = (x);                                                         \
+        if (e_ != hipSuccess) {                                                      \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                  \
+            exit(1);                                                                 \
+        }                                                                            \
+    } while (0)
+
+static std::mt19937 g_rng(1);
+
+static void gen(std::vector<float> &h, int rows, int n, int stride, int dist, float scale) {
+    std::normal_distribution<float> nd(10.f, 0.3f);
+    std::lognormal_distribution<float> ln(1.0f, 1.5f);
+    for (int r = 0; r < rows; r++)
+        for (int i = 0; i < n; i++) {
+            float v;
+            switch (dist) {
+                case 1: v = ln(g_rng); break;
+                case 2: v = 5.0f + (float)(g_rng() % 7); break;
+                case 3: v = 10.f + 5.f * (float)i / (float)n + 0.1f * nd(g_rng); break;
+                case 4: v = (g_rng() % 100 == 0) ? 1000.f * nd(g_rng) : nd(g_rng); break;  // outliers
+                case 5: v = -nd(g_rng); break;                                               // negative values
+                default: v = nd(g_rng);
+            }
+            h[(size_t)r * stride + i] = v * scale;
+        }
+}
+
+struct Expect {
+    std::vector<float> med, mn, mx;
+    std::vector<double> avg, sd;
+};
+
+static Expect expect(const std::vector<float> &h, int rows, int n, int stride) {
+    Expect e;
+    e.med.resize(rows); e.mn.resize(rows); e.mx.resize(rows); e.avg.resize(rows); e.sd.resize(rows);
+    for (int r = 0; r < rows; r++) {
+        std::vector<float> v(h.begin() + (size_t)r * stride, h.begin() + (size_t)r * stride + n);
+        double s = 0;
+        for (float x : v) s += x;
+        const double m = s / n;
+        double ss = 0;
+        for (float x : v) ss += (x - m) * (x - m);
+        e.avg[r] = m;
+        e.sd[r] = n > 1 ? sqrt(ss / (n - 1)) : NAN;
+        std::nth_element(v.begin(), v.begin() + (n - 1) / 2, v.end());
+        e.med[r] = v[(n - 1) / 2];
+        e.mn[r] = *std::min_element(v.begin(), v.end());
+        e.mx[r] = *std::max_element(v.begin(), v.end());
+    }
+    return e;
+}
+
 int main(int argc, char **argv) {
     const int rows = argc > 1 ? atoi(argv[1]) : 512;
     const int n = argc > 2 ? atoi(argv[2]) : 10000;
+    const int only_threads = argc > 3 ? atoi(argv[3]) : 0;
+    const int dist = argc > 4 ? atoi(argv[4]) : 0;
+    const int use_win = argc > 5 ? atoi(argv[5]) : 1;
     const int stride = (n + 3) & ~3;
-    std::vector<float> h((size_t)rows * stride);
-    std::mt19937 rng(1);
-    std::normal_distribution<float> nd(10.f, 0.3f);
-    for (auto &v : h) v = nd(rng);
+    std::vector<float> h((size_t)rows * stride, 0.f);
     float *d_s, *d_stats;
-    uint32_t *d_c;
-    hipMalloc(&d_s, h.size() * 4);
-    hipMalloc(&d_stats, (size_t)rows * 8 * 4);
-    hipMalloc(&d_c, rows * 4);
-    hipMemcpy(d_s, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    uint32_t *d_c, *d_wlo, *d_wsh;
+    CK(hipMalloc(&d_s, h.size() * 4));
+    CK(hipMalloc(&d_stats, (size_t)rows * 8 * 4));
+    CK(hipMalloc(&d_c, rows * 4));
+    CK(hipMalloc(&d_wlo, rows * 4));
+    CK(hipMalloc(&d_wsh, rows * 4));
     std::vector<uint32_t> c(rows, (uint32_t)n);
-    hipMemcpy(d_c, c.data(), rows * 4, hipMemcpyHostToDevice);
+    CK(hipMemcpy(d_c, c.data(), rows * 4, hipMemcpyHostToDevice));
     hipEvent_t a, b;
-    hipEventCreate(&a);
-    hipEventCreate(&b);
-    Epilogue ep{};
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
     for (int threads : {256, 512, 1024}) {
-        if (argc > 3 && atoi(argv[3]) != threads) continue;
+        if (only_threads && only_threads != threads) continue;
         const StatsVariant *best = nullptr;
         for (const StatsVariant &v : kVariants)
             if (v.threads == threads && v.threads * v.vpt * 4 >= stride && (!best || v.vpt < best->vpt)) best = &v;
         if (!best) continue;
+        Epilogue ep{};
+        (void)use_win;
+        CK(hipMemset(d_wlo, 0, rows * 4));
+        CK(hipMemset(d_wsh, 0xFF, rows * 4));
+        auto launch = [&]() -> float {
+            hipExtLaunchKernelGGL(best->fn, dim3(rows), dim3(best->threads), 0, nullptr, a, b, 0, (const float *)d_s,
+                                  (const uint32_t *)d_c, (const uint8_t *)nullptr, stride, d_stats, ep);
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            return ms;
+        };
+        std::vector<float> st((size_t)rows * 8);
+        int total_bad = 0;
+        auto check = [&](const Expect &e, const char *what) {
+            CK(hipMemcpy(st.data(), d_stats, st.size() * 4, hipMemcpyDeviceToHost));
+            int bad = 0, hits = 0;
+            double worst_avg = 0, worst_std = 0;
+            for (int r = 0; r < rows; r++) {
+                const float *o = &st[(size_t)r * 8];
+                if (NVRX_ABLATE == 0 && o[2] != e.med[r]) bad++;
+                if (o[0] != e.mn[r] || o[1] != e.mx[r]) bad++;
+                hits += o[7] == 1.0f;  // estimate held, no refinement
+                worst_avg = std::max(worst_avg, fabs(o[3] - e.avg[r]) / fabs(e.avg[r]));
+                worst_std = std::max(worst_std, fabs(o[4] - e.sd[r]) / fabs(e.sd[r]));
+            }
+            total_bad += bad;
+            printf("  %-28s mismatches %d  fast path %d/%d  avg_err %.1e std_err %.1e\n", what, bad, hits, rows, worst_avg, worst_std);
+        };
+        // fresh draws of the same distribution: report 0 is cold, later ones should hit the window
+        float ms_seq[6];
+        for (int step = 0; step < 6; step++) {
+            gen(h, rows, n, stride, dist, 1.0f);
+            CK(hipMemcpy(d_s, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+            ms_seq[step] = launch();
+            char what[64];
+            snprintf(what, sizeof(what), "fresh draw %d (%.2f us)", step, ms_seq[step] * 1e3);
+            check(expect(h, rows, n, stride), what);
+        }
+        Expect e = expect(h, rows, n, stride);
         double tot = 0;
         float mn = 1e9f;
         const int reps = 50;
         for (int i = 0; i < reps + 5; i++) {
-            hipExtLaunchKernelGGL(best->fn, dim3(rows), dim3(best->threads), 0, nullptr, a, b, 0, (const float *)d_s,
-                                  (const uint32_t *)d_c, (const uint8_t *)nullptr, stride, d_stats, ep);
-            hipEventSynchronize(b);
-            float ms;
-            hipEventElapsedTime(&ms, a, b);
+            const float ms = launch();
             if (i >= 5) {
                 tot += ms;
                 mn = std::min(mn, ms);
             }
         }
-        float st[8];
-        hipMemcpy(st, d_stats, sizeof(st), hipMemcpyDeviceToHost);
-        printf("ablate=%d threads=%4d vpt=%2d rows=%d n=%d : avg %.2f us  min %.2f us  -> %.0f GB/s   (row0 med %.5f)\n",
-               NVRX_ABLATE, best->threads, best->vpt, rows, n, tot / reps * 1e3, mn * 1e3,
-               (double)rows * n * 4 / (tot / reps * 1e-3) / 1e9, st[2]);
+        check(e, "steady state (same data)");
+        printf("ablate=%d dist=%d win=%d threads=%4d vpt=%2d rows=%d n=%d : avg %.2f us  min %.2f us  -> %.0f GB/s\n", NVRX_ABLATE, dist,
+               use_win, best->threads, best->vpt, rows, n, tot / reps * 1e3, mn * 1e3, (double)rows * n * 4 / (tot / reps * 1e-3) / 1e9);
+#ifdef NVRX_PHASE_CLOCKS
+        {
+            static unsigned long long ph[4096][12];
+            CK(hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph)));
+            const int nb = std::min(rows, 4096);
+            unsigned long long w0 = ~0ull, w1 = 0;
+            for (int r = 0; r < nb; r++) {
+                w0 = std::min(w0, ph[r][10]);
+                w1 = std::max(w1, ph[r][9]);
+            }
+            // clock64 bases differ per XCD: report per-block deltas between consecutive phase marks
+            for (int i = 1; i <= 8; i++) {
+                double s = 0;
+                unsigned long long lo = ~0ull, hi = 0;
+                for (int r = 0; r < nb; r++) {
+                    const unsigned long long v = ph[r][i] - ph[r][i - 1];
+                    s += (double)v;
+                    lo = std::min(lo, v);
+                    hi = std::max(hi, v);
+                }
+                printf("  phase %d-%d: mean %7.0f  min %6llu  max %6llu clk\n", i - 1, i, s / nb, lo, hi);
+            }
+            double s = 0, stg = 0;
+            unsigned long long hi = 0;
+            for (int r = 0; r < nb; r++) {
+                s += (double)(ph[r][8] - ph[r][0]);
+                stg += (double)(ph[r][10] - w0);
+                hi = std::max(hi, ph[r][10] - w0);
+            }
+            printf("  block total: mean %.0f clk; start stagger (wall, 10 ns ticks): mean %.1f max %llu; kernel wall span %llu ticks\n",
+                   s / nb, stg / nb, hi, w1 - w0);
+        }
+#endif
+        // the distribution moves: x1.5 (every window misses once), then a mild x1.01 drift
+        for (float scale : {1.5f, 1.5f, 1.515f, 0.2f, 0.2f}) {
+            gen(h, rows, n, stride, dist, scale);
+            CK(hipMemcpy(d_s, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+            const float ms = launch();
+            char what[64];
+            snprintf(what, sizeof(what), "scale x%.3f (%.2f us)", scale, ms * 1e3);
+            check(expect(h, rows, n, stride), what);
+        }
+        printf("  TOTAL mismatches %d\n", total_bad);
     }
     return 0;
 }
