@@ -172,6 +172,141 @@ constexpr int HIST_BITS = 11;
 constexpr int HIST_BINS = 1 << HIST_BITS;
 
 // ------------------------------------------------------------------------------------------------
+// Cross-rank scoring on the exchanged table (layout in nvrx_straggler.h).  (Fusing this into the tail
+// of k_row_stats behind a last-workgroup ticket was measured and dropped: 512 device-scope atomics on
+// one word serialise at the memory side of the 8 XCDs, ~40 ns each = 20 us.)
+// ------------------------------------------------------------------------------------------------
+struct ScoreArgs {
+    const float *table;
+    const float *minmed_pre;  // null: compute column minima in LDS
+    int R, K, S;
+    int do_indiv, do_rel;
+    double thr[4];  // gpu_rel, section_rel, gpu_indiv, section_indiv
+    float *scores;
+    uint8_t *flags;
+    uint32_t *meta;
+    uint32_t *done_counter;  // device word, zero between launches; null = no completion word
+    uint32_t seq;
+    const float4 *stats_src;  // optional: statistics rows to forward (device -> pinned host)
+    float4 *stats_dst;
+    int stats_n4;
+};
+
+// all_reduce(MIN) of the f32 MED tensor with -1 sentinels (reporting.py:273-295) into s_min[KS]
+__device__ __forceinline__ void score_colmin(const ScoreArgs &a, int tid, int nthr, float *s_min) {
+    const int KS = a.K + a.S;
+    const int L = NVRX_TABLE_LEN(a.K, a.S);
+    for (int j = tid; j < KS; j += nthr) {
+        float m = INFINITY;
+        for (int q = 0; q < a.R; q++) {
+            const float v = a.table[(size_t)q * L + j];
+            if (v < m) m = v;
+        }
+        s_min[j] = m >= 0.0f ? m : __builtin_nanf("");  // reporting.py:289,295
+    }
+}
+
+// Scores and flags of rank r, by all NTHR threads of the workgroup (contains one barrier).
+template <int NTHR>
+__device__ __forceinline__ void score_rank(const ScoreArgs &a, int r, int tid, const float *minmed,
+                                           double (*s_red)[NTHR / 64], uint32_t (*s_cnt)[NTHR / 64]) {
+    const int K = a.K, S = a.S, KS = K + S;
+    const int L = NVRX_TABLE_LEN(K, S);
+    const int W = NVRX_SCORE_LEN(S);
+    const int lane = tid & 63, wave = tid >> 6;
+    const float *__restrict__ row = a.table + (size_t)r * L;
+    float *__restrict__ out = a.scores + (size_t)r * W;
+    uint8_t *__restrict__ fl = a.flags ? a.flags + (size_t)r * W : nullptr;
+    const float NaN = __builtin_nanf("");
+
+    // section scores: reference / MED (reporting.py:196-217), rounded to f32 (reporting.py:352)
+    for (int s = tid; s < S; s += NTHR) {
+        const float med = row[K + s];
+        float si = NaN, sr = NaN;
+        if (med >= 0.0f) {
+            if (a.do_indiv) si = (float)((double)row[KS + K + s] / (double)med);
+            if (a.do_rel) sr = (float)((double)minmed[K + s] / (double)med);
+        }
+        out[2 + s] = si;
+        out[2 + S + s] = sr;
+        if (fl) {
+            fl[2 + s] = ((double)si < a.thr[3]) ? 1 : 0;
+            fl[2 + S + s] = ((double)sr < a.thr[1]) ? 1 : 0;
+        }
+    }
+
+    // GPU score: weighted mean of per-kernel ratios (reporting.py:219-253)
+    double wi = 0.0, si = 0.0, wr = 0.0, sr = 0.0;
+    uint32_t nk = 0, ncommon = 0;
+    for (int k = tid; k < K; k += NTHR) {
+        const float medf = row[k];
+        if (!(medf >= 0.0f)) continue;
+        const double med = (double)medf;
+        const double w = (double)row[2 * KS + k];
+        nk++;
+        si += ((double)row[KS + k] / med) * w;
+        wi += w;
+        const float mm = minmed[k];
+        if (mm == mm) {
+            ncommon++;
+            sr += ((double)mm / med) * w;
+            wr += w;
+        }
+    }
+    if (K > 0) {  // block-uniform
+        wi = wave_sum_f64(wi);
+        si = wave_sum_f64(si);
+        wr = wave_sum_f64(wr);
+        sr = wave_sum_f64(sr);
+        nk = wave_sum_u32(nk);
+        ncommon = wave_sum_u32(ncommon);
+    }
+    if (lane == 0) {
+        s_red[0][wave] = wi;
+        s_red[1][wave] = si;
+        s_red[2][wave] = wr;
+        s_red[3][wave] = sr;
+        s_cnt[0][wave] = nk;
+        s_cnt[1][wave] = ncommon;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        wi = si = wr = sr = 0.0;
+        nk = ncommon = 0;
+        for (int w = 0; w < NTHR / 64; w++) {
+            wi += s_red[0][w];
+            si += s_red[1][w];
+            wr += s_red[2][w];
+            sr += s_red[3][w];
+            nk += s_cnt[0][w];
+            ncommon += s_cnt[1][w];
+        }
+        const float gi = (a.do_indiv && nk > 0) ? (float)(si / wi) : NaN;
+        const float gr = (a.do_rel && ncommon > 0) ? (float)(sr / wr) : NaN;
+        out[0] = gi;
+        out[1] = gr;
+        if (fl) {
+            fl[0] = ((double)gi < a.thr[2]) ? 1 : 0;
+            fl[1] = ((double)gr < a.thr[0]) ? 1 : 0;
+        }
+    }
+}
+
+// is_all_true(has_all_names) (name_mapper.py:68-69, dist_utils.py:107-115) folded into the table; one wave
+__device__ __forceinline__ void score_meta(const ScoreArgs &a, int lane) {
+    const int L = NVRX_TABLE_LEN(a.K, a.S);
+    uint32_t bad = 0;
+    for (int q = lane; q < a.R; q += 64) bad += (a.table[(size_t)q * L + (L - 1)] > 0.0f) ? 0u : 1u;
+    bad = wave_sum_u32(bad);
+    if (lane == 0) {
+        a.meta[0] = bad ? 0u : 1u;
+        a.meta[1] = (uint32_t)a.R;
+        a.meta[2] = (uint32_t)a.K;
+        a.meta[3] = (uint32_t)a.S;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_row_stats: one workgroup per timing row.
 //   HBM: the row is read once, 16 B per lane per load, VPT independent loads in flight per lane.
 //   Registers: the row lives in VPT*4 order-preserving keys per lane for the rest of the kernel.
@@ -223,7 +358,7 @@ template <int THREADS, int VPT>
 __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__ samples,
                                                        const uint32_t *__restrict__ counts,
                                                        const uint8_t *__restrict__ kinds, int row_stride,
-                                                       float *__restrict__ stats, Epilogue ep) {
+                                                       float *__restrict__ stats, Epilogue ep, int uniform_n) {
     constexpr int WAVES = THREADS / 64;
     constexpr int PER = HIST_BINS / THREADS;  // histogram bins summed per thread
     constexpr int G = THREADS / 64;           // thread sums per lane in the wave-redundant scan
@@ -251,7 +386,8 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
 #ifdef NVRX_PHASE_CLOCKS
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_phase[blockIdx.x][10] = wall_clock64();
 #endif
-    uint32_t n = counts[row];
+    // uniform_n >= 0: every launched row holds that many samples (kernel argument: no counts upload)
+    uint32_t n = uniform_n >= 0 ? (uint32_t)uniform_n : counts[row];
     if (n > (uint32_t)row_stride) n = (uint32_t)row_stride;
     const int kind = kinds ? kinds[row] : NVRX_KIND_SECTION;
     // epilogue inputs are fetched now so their latency hides under the row load
@@ -724,22 +860,6 @@ __global__ void k_colmin(const float *__restrict__ table, int R, int KS, int L, 
     minmed[j] = m >= 0.0f ? m : __builtin_nanf("");  // reporting.py:289,295
 }
 
-struct ScoreArgs {
-    const float *table;
-    const float *minmed_pre;  // null: compute column minima in LDS
-    int R, K, S;
-    int do_indiv, do_rel;
-    double thr[4];  // gpu_rel, section_rel, gpu_indiv, section_indiv
-    float *scores;
-    uint8_t *flags;
-    uint32_t *meta;
-    uint32_t *done_counter;  // device word, zero between launches; null = no completion word
-    uint32_t seq;
-    const float4 *stats_src;  // optional: statistics rows to forward (device -> pinned host)
-    float4 *stats_dst;
-    int stats_n4;
-};
-
 constexpr int SCORE_THREADS = 256;
 
 __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
@@ -747,117 +867,20 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
     __shared__ double s_red[4][SCORE_THREADS / 64];
     __shared__ uint32_t s_cnt[2][SCORE_THREADS / 64];
 
-    const int K = a.K, S = a.S, KS = K + S;
-    const int L = NVRX_TABLE_LEN(K, S);
-    const int W = NVRX_SCORE_LEN(S);
     const int r = blockIdx.x;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const float *__restrict__ row = a.table + (size_t)r * L;
-    float *__restrict__ out = a.scores + (size_t)r * W;
-    uint8_t *__restrict__ fl = a.flags ? a.flags + (size_t)r * W : nullptr;
-    const float NaN = __builtin_nanf("");
 
     // forward the local statistics rows next to the scores (keeps PCIe stores out of k_row_stats)
     for (int i = r * SCORE_THREADS + tid; i < a.stats_n4; i += a.R * SCORE_THREADS) a.stats_dst[i] = a.stats_src[i];
 
     const float *minmed = a.minmed_pre;
     if (!minmed) {
-        // all_reduce(MIN) of the f32 MED tensor with -1 sentinels (reporting.py:273-295)
-        for (int j = tid; j < KS; j += SCORE_THREADS) {
-            float m = INFINITY;
-            for (int q = 0; q < a.R; q++) {
-                const float v = a.table[(size_t)q * L + j];
-                if (v < m) m = v;
-            }
-            s_min[j] = m >= 0.0f ? m : NaN;
-        }
+        score_colmin(a, tid, SCORE_THREADS, s_min);
         __syncthreads();
         minmed = s_min;
     }
-
-    // section scores: reference / MED (reporting.py:196-217), rounded to f32 (reporting.py:352)
-    for (int s = tid; s < S; s += SCORE_THREADS) {
-        const float med = row[K + s];
-        float si = NaN, sr = NaN;
-        if (med >= 0.0f) {
-            if (a.do_indiv) si = (float)((double)row[KS + K + s] / (double)med);
-            if (a.do_rel) sr = (float)((double)minmed[K + s] / (double)med);
-        }
-        out[2 + s] = si;
-        out[2 + S + s] = sr;
-        if (fl) {
-            fl[2 + s] = ((double)si < a.thr[3]) ? 1 : 0;
-            fl[2 + S + s] = ((double)sr < a.thr[1]) ? 1 : 0;
-        }
-    }
-
-    // GPU score: weighted mean of per-kernel ratios (reporting.py:219-253)
-    double wi = 0.0, si = 0.0, wr = 0.0, sr = 0.0;
-    uint32_t nk = 0, ncommon = 0;
-    for (int k = tid; k < K; k += SCORE_THREADS) {
-        const float medf = row[k];
-        if (!(medf >= 0.0f)) continue;
-        const double med = (double)medf;
-        const double w = (double)row[2 * KS + k];
-        nk++;
-        si += ((double)row[KS + k] / med) * w;
-        wi += w;
-        const float mm = minmed[k];
-        if (mm == mm) {
-            ncommon++;
-            sr += ((double)mm / med) * w;
-            wr += w;
-        }
-    }
-    wi = wave_sum_f64(wi);
-    si = wave_sum_f64(si);
-    wr = wave_sum_f64(wr);
-    sr = wave_sum_f64(sr);
-    nk = wave_sum_u32(nk);
-    ncommon = wave_sum_u32(ncommon);
-    if (lane == 0) {
-        s_red[0][wave] = wi;
-        s_red[1][wave] = si;
-        s_red[2][wave] = wr;
-        s_red[3][wave] = sr;
-        s_cnt[0][wave] = nk;
-        s_cnt[1][wave] = ncommon;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        wi = si = wr = sr = 0.0;
-        nk = ncommon = 0;
-        for (int w = 0; w < SCORE_THREADS / 64; w++) {
-            wi += s_red[0][w];
-            si += s_red[1][w];
-            wr += s_red[2][w];
-            sr += s_red[3][w];
-            nk += s_cnt[0][w];
-            ncommon += s_cnt[1][w];
-        }
-        const float gi = (a.do_indiv && nk > 0) ? (float)(si / wi) : NaN;
-        const float gr = (a.do_rel && ncommon > 0) ? (float)(sr / wr) : NaN;
-        out[0] = gi;
-        out[1] = gr;
-        if (fl) {
-            fl[0] = ((double)gi < a.thr[2]) ? 1 : 0;
-            fl[1] = ((double)gr < a.thr[0]) ? 1 : 0;
-        }
-    }
-
-    if (r == 0 && a.meta && wave == 1) {
-        // is_all_true(has_all_names) (name_mapper.py:68-69, dist_utils.py:107-115) folded into the table
-        uint32_t bad = 0;
-        for (int q = lane; q < a.R; q += 64) bad += (a.table[(size_t)q * L + (L - 1)] > 0.0f) ? 0u : 1u;
-        bad = wave_sum_u32(bad);
-        if (lane == 0) {
-            a.meta[0] = bad ? 0u : 1u;
-            a.meta[1] = (uint32_t)a.R;
-            a.meta[2] = (uint32_t)K;
-            a.meta[3] = (uint32_t)S;
-        }
-    }
+    score_rank<SCORE_THREADS>(a, r, tid, minmed, s_red, s_cnt);
+    if (r == 0 && a.meta && (tid >> 6) == 1) score_meta(a, tid & 63);
 
     if (a.done_counter) {
         // Completion word for a polling host (results may live in pinned host memory): every block
@@ -878,7 +901,7 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
 // ------------------------------------------------------------------------------------------------
 // launch-shape selection for k_row_stats
 // ------------------------------------------------------------------------------------------------
-using StatsKernel = void (*)(const float *, const uint32_t *, const uint8_t *, int, float *, Epilogue);
+using StatsKernel = void (*)(const float *, const uint32_t *, const uint8_t *, int, float *, Epilogue, int);
 
 struct StatsVariant {
     int threads;
@@ -930,7 +953,7 @@ const StatsVariant *pick_variant(int row_stride) {
 // (hipExtLaunchKernel: the dispatch's profiling timestamps, the same clock rocprofv3 reports).
 int launch_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8_t *d_kinds, int rows,
                      int row_stride, float *d_stats, const Epilogue &ep, hipStream_t stream,
-                     hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
+                     hipEvent_t start = nullptr, hipEvent_t stop = nullptr, int uniform_n = -1) {
     if (rows == 0) return NVRX_OK;
     const StatsVariant *v = pick_variant(row_stride);
     if (!v)
@@ -938,10 +961,10 @@ int launch_row_stats(const float *d_samples, const uint32_t *d_counts, const uin
                     NVRX_MAX_RING_CAP);
     if (start || stop) {
         hipExtLaunchKernelGGL(v->fn, dim3(rows), dim3(v->threads), 0, stream, start, stop, 0, d_samples, d_counts,
-                              d_kinds, row_stride, d_stats, ep);
+                              d_kinds, row_stride, d_stats, ep, uniform_n);
     } else {
         hipLaunchKernelGGL(v->fn, dim3(rows), dim3(v->threads), 0, stream, d_samples, d_counts, d_kinds, row_stride,
-                           d_stats, ep);
+                           d_stats, ep, uniform_n);
     }
     HIP_TRY(hipGetLastError());
     return NVRX_OK;
@@ -1028,8 +1051,28 @@ int ctx_set_device(const nvrx_ctx *ctx) {
     return NVRX_OK;
 }
 
-int flush_locked(nvrx_ctx *ctx, hipStream_t stream) {
+// `uniform_n` (optional, report path only): when nothing but the counts changed and every one of the
+// `rows_active` rows per rank about to be launched holds the same number of samples, that number is
+// returned through it and NOTHING is launched -- k_row_stats takes it as a kernel argument instead of
+// reading d_counts (which stays marked dirty until a later flush uploads it).
+int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, int rows_active = 0) {
+    if (uniform_n) *uniform_n = -1;
     if (ctx->n_staged == 0 && !ctx->meta_dirty && !ctx->counts_dirty) return NVRX_OK;
+    if (uniform_n && ctx->n_staged == 0 && !ctx->meta_dirty) {
+        const uint64_t cap = (uint64_t)ctx->ring_cap;
+        const uint64_t first = std::min<uint64_t>(ctx->total[0], cap);
+        bool same = true;
+        for (int lr = 0; lr < ctx->local_ranks && same; lr++)
+            for (int r = 0; r < rows_active; r++)
+                if (std::min<uint64_t>(ctx->total[(size_t)lr * ctx->rows_per_rank + r], cap) != first) {
+                    same = false;
+                    break;
+                }
+        if (same) {
+            *uniform_n = (int)first;
+            return NVRX_OK;
+        }
+    }
     StageBuf &b = ctx->buf[ctx->cur];
     for (int r = 0; r < ctx->rows; r++)
         b.h_counts[r] = (uint32_t)std::min<uint64_t>(ctx->total[r], (uint64_t)ctx->ring_cap);
@@ -1489,6 +1532,7 @@ int nvrx_event_harvest(nvrx_ctx *ctx, int wait) {
 // ------------------------------------------------------------------------------------------------
 int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
                       void *stream) {
+    hipStream_t st = as_stream(stream);
     if (!ctx || !d_stats) return fail(NVRX_ERR_INVALID, "null argument");
     if (K < 0 || S < 0) return fail(NVRX_ERR_INVALID, "bad K/S");
     if (rows_active < 0 || rows_active > ctx->rows_per_rank) return fail(NVRX_ERR_INVALID, "rows_active %d outside [0,%d]", rows_active, ctx->rows_per_rank);
@@ -1496,8 +1540,8 @@ int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S
     std::lock_guard<std::mutex> lk(ctx->mu);
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
-    hipStream_t st = as_stream(stream);
-    rc = flush_locked(ctx, st);
+    int uniform_n = -1;
+    rc = flush_locked(ctx, st, &uniform_n, rows_active);
     if (rc) return rc;
     Epilogue ep{};
     ep.gid = ctx->d_gid;
@@ -1519,7 +1563,7 @@ int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S
         ev_stop = ctx->timing_pairs[(size_t)pair].end;
     }
     rc = launch_row_stats(ctx->d_samples, ctx->d_counts, ctx->d_kinds, ctx->local_ranks * rows_active, ctx->row_stride,
-                          d_stats, ep, st, ev_start, ev_stop);
+                          d_stats, ep, st, ev_start, ev_stop, uniform_n);
     if (rc) return rc;
     if (pair >= 0) ctx->timing_used.push_back(pair);
     return NVRX_OK;

@@ -474,11 +474,12 @@ class ReportGenerator:
             with be.stream_context():  # the collective must queue behind the statistics kernel
                 rings.report_local(ws, True, rows_active=plan.rows_used)
                 table = dist_utils.all_gather_rows(ws.send, ws.table, self.group)
+            be.score(ws, table, self.is_computing_indiv_scores, self.is_computing_rel_scores, self.thresholds,
+                     wait=True, stats_rows=plan.stats_needed)
         else:
             rings.report_local(ws, True, rows_active=plan.rows_used)
-            table = ws.send
-        be.score(ws, table, self.is_computing_indiv_scores, self.is_computing_rel_scores, self.thresholds,
-                 wait=True, stats_rows=plan.stats_needed)
+            be.score(ws, ws.send, self.is_computing_indiv_scores, self.is_computing_rel_scores, self.thresholds,
+                     wait=True, stats_rows=plan.stats_needed)
         if ws.meta[0] != 1:
             return False  # another rank met a new name: fall back to the general (name-syncing) path
         if self.gather_on_rank0 and self.rank != 0:

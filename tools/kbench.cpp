@@ -94,7 +94,7 @@ int main(int argc, char **argv) {
         CK(hipMemset(d_wsh, 0xFF, rows * 4));
         auto launch = [&]() -> float {
             hipExtLaunchKernelGGL(best->fn, dim3(rows), dim3(best->threads), 0, nullptr, a, b, 0, (const float *)d_s,
-                                  (const uint32_t *)d_c, (const uint8_t *)nullptr, stride, d_stats, ep);
+                                  (const uint32_t *)d_c, (const uint8_t *)nullptr, stride, d_stats, ep, -1);
             CK(hipEventSynchronize(b));
             float ms;
             CK(hipEventElapsedTime(&ms, a, b));
