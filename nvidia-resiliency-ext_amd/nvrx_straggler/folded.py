@@ -64,4 +64,5 @@ class FoldedJob:
         return rep
 
     def close(self) -> None:
+        self.reporter.close()
         self.rings.close()

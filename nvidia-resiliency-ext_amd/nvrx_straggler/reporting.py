@@ -304,6 +304,10 @@ class ReportGenerator:
         self.rank_to_node: Dict[int, str] = collections.defaultdict(lambda: "<unk>")
         self._ring_gid_state = None
         self._ring_plan = None
+        # the per-report all-gather straight into RCCL on our own stream (rccl_direct.py); created
+        # collectively on the first multi-rank report, None = stay on torch.distributed
+        self._direct = None
+        self._direct_tried = False
 
     # ---- pieces kept from the reference's host logic ----------------------------------------------
     @staticmethod
@@ -332,6 +336,29 @@ class ReportGenerator:
     def _exchanged(self) -> bool:
         return self.is_computing_rel_scores or self.gather_on_rank0
 
+    def _maybe_create_direct_exchange(self) -> None:
+        """Collective, once: every rank calls this at the top of its first exchanging report."""
+        if self._direct_tried or self.world_size == 1 or not self._exchanged():
+            return
+        self._direct_tried = True
+        from . import rccl_direct
+
+        self._direct = rccl_direct.create(self.group)
+
+    def _exchange(self, be, ws):
+        """The report's one collective: this rank's rows -> the [R, L] table, on the backend's stream."""
+        if self._direct is not None:
+            self._direct.all_gather(ws.send_ptr, ws.table_ptr, ws.local_ranks * ws.L, be.stream_handle)
+            return ws.table
+        with be.stream_context():  # the collective must queue behind the statistics kernel
+            return dist_utils.all_gather_rows(ws.send, ws.table, self.group)
+
+    def close(self) -> None:
+        """Release the direct-exchange communicator (collective-free; safe to call more than once)."""
+        if self._direct is not None:
+            self._direct.close()
+            self._direct = None
+
     def _score_round(self, kernel_names: List[str], section_names: List[str], fill_send, local_ranks: int = 1,
                      stats_rows: int = 0, stats_rows_used: Optional[int] = None, resync_first: bool = False):
         """pack -> all-gather -> score, repeated once after a name sync if any rank met a new name.
@@ -359,9 +386,9 @@ class ReportGenerator:
             world = self.world_size if exchanged else 1
             ws = be.workspace(world * local_ranks, K, S, local_ranks, stats_rows)
             if world > 1:
-                with be.stream_context():  # the collective must queue behind the statistics kernel
+                with be.stream_context():  # host-packed rows are copied on the stream the report runs on
                     fill_send(ws, mapper, names_ok)
-                    table = dist_utils.all_gather_rows(ws.send, ws.table, self.group)
+                table = self._exchange(be, ws)
             else:
                 fill_send(ws, mapper, names_ok)
                 table = ws.send
@@ -471,9 +498,8 @@ class ReportGenerator:
         be = _backend_mod.get_backend()
         ws = plan.ws
         if self.world_size > 1 and self._exchanged():
-            with be.stream_context():  # the collective must queue behind the statistics kernel
-                rings.report_local(ws, True, rows_active=plan.rows_used)
-                table = dist_utils.all_gather_rows(ws.send, ws.table, self.group)
+            rings.report_local(ws, True, rows_active=plan.rows_used)
+            table = self._exchange(be, ws)
             be.score(ws, table, self.is_computing_indiv_scores, self.is_computing_rel_scores, self.thresholds,
                      wait=True, stats_rows=plan.stats_needed)
         else:
@@ -536,6 +562,8 @@ class ReportGenerator:
         t0 = time.perf_counter_ns()
         self.world_size = dist_utils.get_world_size(self.group)
         self.rank = dist_utils.get_rank(self.group)
+        if not self._direct_tried:
+            self._maybe_create_direct_exchange()
         kernel_summaries = self._filter_out_nccl_kernels(kernel_summaries)
         self._maybe_gather_rank_to_node()
         if self.is_computing_indiv_scores:
@@ -578,6 +606,8 @@ class ReportGenerator:
         t0 = time.perf_counter_ns()
         self.world_size = dist_utils.get_world_size(self.group)
         self.rank = dist_utils.get_rank(self.group)
+        if not self._direct_tried:
+            self._maybe_create_direct_exchange()
         # steady state: same name tables as last time -> run the cached plan
         key = (id(section_rows), len(section_rows), id(kernel_rows), len(kernel_rows), self.name_mapper.version,
                self._private_mapper.version, self.world_size, self.rank, rings.rows_used, local_ranks, id(rings))

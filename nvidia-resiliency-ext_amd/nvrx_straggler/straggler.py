@@ -191,6 +191,8 @@ class Detector:
         if cls.rings is not None:
             cls.rings.close()
             cls.rings = None
+        if getattr(cls, "reporter", None) is not None:
+            cls.reporter.close()
         cls.initialized = False
 
     # ---- summaries (host-visible form; the report path itself keeps them on the device) -------------
