@@ -19,6 +19,9 @@ Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
                   local_ranks * 64 * 10000 * 4 per launch, duration from hipEvent pairs recorded
                   around every launch on the launch stream during a second, instrumented pass of the
                   same K steps (the headline pass runs without the extra event records).
+  per_step_overhead -- BASELINE.json's second figure (config #4): the real Detector around a fixed
+                  bf16 matmul workload with a hipEvent pair per entry and a collective report EVERY
+                  step; % = (t_with - t_without) / t_without, A/B blocks alternating in one process.
   cpu_baseline -- the reference's CPU path restated in Python (oracle/, kind "port"), timed on this
                   host: one rank's 64 x 10000 samples from Python deques -> torch.tensor + 5 torch
                   reductions per section, + dict scoring; 1 core.
@@ -92,6 +95,69 @@ def _cpu_baseline(reps: int):
     }
 
 
+def _per_step_overhead(world: int, rank: int, steps: int, blocks: int):
+    """BASELINE.json config #4: the real ``Detector`` around a fixed GPU workload (10 x 4096^3 bf16
+    matmul), ``profile_cuda=True`` (hipEvent pair per entry), individual scores, a collective
+    ``generate_report()`` EVERY step.  A/B blocks of ``steps`` steps alternate in the same process;
+    overhead = (t_with - t_without) / t_without on the per-step medians of the blocks."""
+    from nvrx_straggler import Detector
+
+    x = torch.randn(4096, 4096, dtype=torch.bfloat16, device="cuda")
+
+    def work():
+        y = x
+        for _ in range(10):
+            y = torch.matmul(x, y)
+        return y
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    Detector.initialize(scores_to_compute=["individual_perf_scores"], gather_on_rank0=True, node_name=f"node{rank}")
+    try:
+        def step_with():
+            with Detector.detection_section("train_step", profile_cuda=True):
+                work()
+            return Detector.generate_report()
+
+        for _ in range(10):
+            work()
+            step_with()
+        t_without, t_with = [], []
+        for _ in range(blocks):
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                work()
+            sync_all()
+            t_without.append((time.perf_counter() - t0) / steps)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_with()
+            sync_all()
+            t_with.append((time.perf_counter() - t0) / steps)
+    finally:
+        Detector.shutdown()
+    a, b = float(np.median(t_without)), float(np.median(t_with))
+    t = torch.tensor([a, b], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    a, b = t.tolist()
+    return {
+        "pct": round((b - a) / a * 100.0, 3),
+        "step_ms_without": round(a * 1e3, 4),
+        "step_ms_with": round(b * 1e3, 4),
+        "added_us_per_step": round((b - a) * 1e6, 1),
+        "steps_per_block": steps,
+        "blocks": blocks,
+        "workload": "Detector.detection_section(profile_cuda=True) around 10 x matmul(4096^2, bf16) + generate_report() "
+                    "every step, individual_perf_scores, gather_on_rank0",
+    }
+
+
 def _pmc_traffic(local_ranks: int):
     """HBM bytes per k_row_stats launch from the committed rocprofv3 PMC summary, if one exists for
     this shape (collected in its own run; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM)."""
@@ -111,6 +177,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-reps", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overhead", action="store_true", help="skip the per-step overhead leg (config #4)")
+    ap.add_argument("--overhead-steps", type=int, default=100)
+    ap.add_argument("--overhead-blocks", type=int, default=5)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,6 +239,11 @@ def main():
     kern_total_us, kern_launches = job.rings.timing_read(reset=True)
     job.rings.timing_enable(False)
 
+    overhead = None
+    if not args.no_overhead:
+        job.backend.synchronize()
+        overhead = _per_step_overhead(world, rank, args.overhead_steps, args.overhead_blocks)
+
     times = torch.tensor([elapsed, elapsed_instr], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
@@ -216,6 +290,8 @@ def main():
                 "launches_timed": kern_launches,
             },
         }
+        if overhead is not None:
+            out["per_step_overhead"] = overhead
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = _cpu_baseline(args.cpu_reps)
         print(json.dumps(out), flush=True)

@@ -167,6 +167,16 @@ int nvrx_event_end(nvrx_ctx *ctx, int row, void *stream);
  * Returns the number of pairs still pending (>=0) or a negative error. */
 int nvrx_event_harvest(nvrx_ctx *ctx, int wait);
 
+/* GPU time of a code region measured on the device (replaces the CUPTI activity records of
+ * cupti_src/CuptiProfiler.cpp:168-207 without a hipEvent read-back): nvrx_stamp_begin enqueues a one-thread
+ * kernel on `stream` that stores the constant-rate wall clock; nvrx_stamp_end enqueues one that appends the
+ * elapsed MICROSECONDS (CuptiProfiler.cpp:191) to `row`'s ring and, when cpu_row >= 0, also appends the
+ * host-measured `cpu_value` to `cpu_row`'s ring (the section's wall time, straggler.py:343), so a profiled
+ * section entry costs no pinned-memory staging.  Reports are ordered after these kernels on the device;
+ * the host never waits for them.  Regions on one row nest LIFO. */
+int nvrx_stamp_begin(nvrx_ctx *ctx, int row, void *stream);
+int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *stream);
+
 /* Local half of a report: flush -> row statistics for every row -> write this GPU's
  * `local_ranks` exchange rows.
  *   d_stats [local_ranks*rows_per_rank][NVRX_STATS_STRIDE] out

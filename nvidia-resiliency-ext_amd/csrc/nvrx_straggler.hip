@@ -825,6 +825,22 @@ __global__ void k_scatter(const uint32_t *__restrict__ h_counts, const StagedSam
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_stamp_begin / k_stamp_end: GPU time of a code region measured ON the device.  One-thread kernels
+// on the user's stream read the constant-rate wall clock (s_memrealtime, 100 MHz on MI355X) when the
+// region's work starts and ends in stream order; the end kernel writes the elapsed microseconds straight
+// into the region's ring slot (and, optionally, the section's host-measured CPU sample into its slot),
+// so no hipEvent pair has to be waited for and read back and no sample is staged through pinned memory.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_stamp_begin(unsigned long long *slot) { *slot = wall_clock64(); }
+
+__global__ void k_stamp_end(const unsigned long long *slot, float us_per_tick, float *dst_gpu, float *dst_cpu,
+                            float cpu_value) {
+    const unsigned long long t = wall_clock64();
+    *dst_gpu = (float)(t - *slot) * us_per_tick;  // microseconds, as CuptiProfiler.cpp:191
+    if (dst_cpu) *dst_cpu = cpu_value;
+}
+
 __global__ void k_fill_f32(float *p, size_t n, float v) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -885,9 +901,12 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
     if (a.done_counter) {
         // Completion word for a polling host (results may live in pinned host memory): every block
         // makes its stores visible system-wide, then takes a ticket; the last one publishes `seq`.
+        __threadfence_system();  // every wave: its stores into the pinned result block have landed
         __syncthreads();
-        if (tid == 0) {
-            __threadfence_system();
+        if (tid == 0 && a.R == 1) {
+            // one workgroup: nobody to wait for
+            __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (tid == 0) {
             const uint32_t ticket = atomicAdd(a.done_counter, 1u);
             if (ticket == (uint32_t)a.R - 1u) {
                 *a.done_counter = 0u;  // ready for the next launch (launches on one stream are ordered)
@@ -1041,6 +1060,19 @@ struct nvrx_ctx {
     hipEvent_t copy_done = nullptr;
     bool copy_pending = false;
 
+    // device-side region timing (k_stamp_begin / k_stamp_end)
+    static constexpr int NSTAMP = 256;
+    unsigned long long *d_stamps = nullptr;  // [NSTAMP] begin timestamps, handed out round-robin
+    int stamp_next = 0;
+    float us_per_tick = 0.01f;
+    struct OpenStamp {
+        int row;
+        int slot;
+    };
+    std::vector<OpenStamp> open_stamps;
+    std::vector<hipStream_t> stamp_streams;  // user streams with stamp kernels the rings have not been ordered after
+    hipEvent_t stamp_ev = nullptr;
+
     std::mutex mu;
 };
 
@@ -1051,12 +1083,28 @@ int ctx_set_device(const nvrx_ctx *ctx) {
     return NVRX_OK;
 }
 
+// Samples written by stamp kernels on user streams must be in the rings before anything on `stream`
+// reads them: one event per such stream, waited for on the device (the host does not block).
+int order_after_stamps(nvrx_ctx *ctx, hipStream_t stream) {
+    for (hipStream_t s : ctx->stamp_streams) {
+        if (s == stream) continue;
+        HIP_TRY(hipEventRecord(ctx->stamp_ev, s));
+        HIP_TRY(hipStreamWaitEvent(stream, ctx->stamp_ev, 0));
+    }
+    ctx->stamp_streams.clear();
+    return NVRX_OK;
+}
+
 // `uniform_n` (optional, report path only): when nothing but the counts changed and every one of the
 // `rows_active` rows per rank about to be launched holds the same number of samples, that number is
 // returned through it and NOTHING is launched -- k_row_stats takes it as a kernel argument instead of
 // reading d_counts (which stays marked dirty until a later flush uploads it).
 int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, int rows_active = 0) {
     if (uniform_n) *uniform_n = -1;
+    if (!ctx->stamp_streams.empty()) {
+        int rc = order_after_stamps(ctx, stream);
+        if (rc) return rc;
+    }
     if (ctx->n_staged == 0 && !ctx->meta_dirty && !ctx->counts_dirty) return NVRX_OK;
     if (uniform_n && ctx->n_staged == 0 && !ctx->meta_dirty) {
         const uint64_t cap = (uint64_t)ctx->ring_cap;
@@ -1266,6 +1314,14 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
         CTX_TRY(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
     }
     CTX_TRY(hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
+    CTX_TRY(hipEventCreateWithFlags(&ctx->stamp_ev, hipEventDisableTiming));
+    CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
+    CTX_TRY(hipMemset(ctx->d_stamps, 0, nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
+            ctx->us_per_tick = 1000.0f / (float)khz;
+    }
     CTX_TRY(hipDeviceSynchronize());
 #undef CTX_TRY
     *out = ctx;
@@ -1297,6 +1353,8 @@ int nvrx_ctx_destroy(nvrx_ctx *ctx) {
         (void)hipEventDestroy(p.end);
     }
     if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
+    if (ctx->stamp_ev) (void)hipEventDestroy(ctx->stamp_ev);
+    if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
     delete ctx;
     return NVRX_OK;
 }
@@ -1525,6 +1583,50 @@ int nvrx_event_harvest(nvrx_ctx *ctx, int wait) {
         if (rc) return rc;
     }
     return (int)ctx->pending.size();
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-side region timing
+// ------------------------------------------------------------------------------------------------
+int nvrx_stamp_begin(nvrx_ctx *ctx, int row, void *stream) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if ((int)ctx->open_stamps.size() >= nvrx_ctx::NSTAMP / 2) return fail(NVRX_ERR_STATE, "too many open GPU-timed regions");
+    const int slot = ctx->stamp_next;
+    ctx->stamp_next = (ctx->stamp_next + 1) % nvrx_ctx::NSTAMP;
+    hipLaunchKernelGGL(k_stamp_begin, dim3(1), dim3(1), 0, as_stream(stream), ctx->d_stamps + slot);
+    HIP_TRY(hipGetLastError());
+    ctx->open_stamps.push_back({row, slot});
+    return NVRX_OK;
+}
+
+int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *stream) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (cpu_row >= ctx->rows) return fail(NVRX_ERR_INVALID, "cpu_row %d out of range [0,%d)", cpu_row, ctx->rows);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (int i = (int)ctx->open_stamps.size() - 1; i >= 0; i--) {
+        if (ctx->open_stamps[(size_t)i].row != row) continue;
+        const int slot = ctx->open_stamps[(size_t)i].slot;
+        ctx->open_stamps.erase(ctx->open_stamps.begin() + i);
+        const uint64_t cap = (uint64_t)ctx->ring_cap;
+        float *dst_gpu = ctx->d_samples + (size_t)row * (size_t)ctx->row_stride + (size_t)(ctx->total[(size_t)row] % cap);
+        ctx->total[(size_t)row]++;
+        float *dst_cpu = nullptr;
+        if (cpu_row >= 0) {
+            dst_cpu = ctx->d_samples + (size_t)cpu_row * (size_t)ctx->row_stride + (size_t)(ctx->total[(size_t)cpu_row] % cap);
+            ctx->total[(size_t)cpu_row]++;
+        }
+        ctx->counts_dirty = true;
+        hipStream_t st = as_stream(stream);
+        hipLaunchKernelGGL(k_stamp_end, dim3(1), dim3(1), 0, st, ctx->d_stamps + slot, ctx->us_per_tick, dst_gpu, dst_cpu,
+                           cpu_value);
+        HIP_TRY(hipGetLastError());
+        if (std::find(ctx->stamp_streams.begin(), ctx->stamp_streams.end(), st) == ctx->stamp_streams.end())
+            ctx->stamp_streams.push_back(st);
+        return NVRX_OK;
+    }
+    return fail(NVRX_ERR_STATE, "nvrx_stamp_end(row=%d) without a matching nvrx_stamp_begin", row);
 }
 
 // ------------------------------------------------------------------------------------------------

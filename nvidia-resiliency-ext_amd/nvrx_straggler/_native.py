@@ -48,6 +48,8 @@ SYMBOLS = [
     ("nvrx_event_begin", c_int, [c_void_p, c_int, c_void_p]),
     ("nvrx_event_end", c_int, [c_void_p, c_int, c_void_p]),
     ("nvrx_event_harvest", c_int, [c_void_p, c_int]),
+    ("nvrx_stamp_begin", c_int, [c_void_p, c_int, c_void_p]),
+    ("nvrx_stamp_end", c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     ("nvrx_report_local", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("nvrx_send_init", c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     ("nvrx_timing_enable", c_int, [c_void_p, c_int]),

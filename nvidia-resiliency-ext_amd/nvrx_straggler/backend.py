@@ -33,6 +33,16 @@ DEFAULT_THRESHOLDS = (0.75, 0.75, 0.75, 0.75)  # gpu_rel, section_rel, gpu_indiv
 _backend = None
 _backend_lock = threading.Lock()
 
+# torch.cuda.current_stream() builds a Stream object through several Python layers (~3 us); the raw
+# handle is one C call.  Private API, so fall back to the public one if it ever goes away.
+_raw_stream_fn = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _raw_current_stream(device_index: int) -> int:
+    if _raw_stream_fn is not None:
+        return _raw_stream_fn(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
 
 def set_backend(backend) -> None:
     """Install a backend object (tests only; pass ``None`` to go back to the HIP engine)."""
@@ -146,10 +156,9 @@ class HipBackend:
     def stream_context(self):
         return torch.cuda.stream(self.stream)
 
-    @staticmethod
-    def current_stream_handle() -> int:
+    def current_stream_handle(self) -> int:
         """hipStream_t of the stream user code is currently launching on (for region timing)."""
-        return torch.cuda.current_stream().cuda_stream
+        return _raw_current_stream(self.device.index)
 
     def workspace(self, R: int, K: int, S: int, local_ranks: int = 1, stats_rows: int = 0) -> Workspace:
         key = (R, K, S, local_ranks, stats_rows)
@@ -323,6 +332,18 @@ class HipRings:
 
     def harvest(self, wait: bool) -> int:
         return _native.check(self.lib.nvrx_event_harvest(self.ctx, int(wait)))
+
+    # device-side timing: the elapsed time is written into the ring by a kernel on the user's stream
+    def stamp_begin(self, row: int, stream_handle: int, lr: int = 0) -> None:
+        rc = self.lib.nvrx_stamp_begin(self.ctx, lr * self.rows_per_rank + row, stream_handle)
+        if rc < 0:
+            _native.check(rc)
+
+    def stamp_end(self, row: int, stream_handle: int, cpu_row: int = -1, cpu_value: float = 0.0, lr: int = 0) -> None:
+        base = lr * self.rows_per_rank
+        rc = self.lib.nvrx_stamp_end(self.ctx, base + row, base + cpu_row if cpu_row >= 0 else -1, cpu_value, stream_handle)
+        if rc < 0:
+            _native.check(rc)
 
     # ---- report ----------------------------------------------------------------------------------
     def report_local(self, ws: Workspace, names_ok: bool, rows_active: int = 0) -> None:

@@ -58,14 +58,19 @@ class CuptiManager:
                     self.cupti_ext.start(key)
             self.started_cnt += 1
 
-    def stop_profiling(self):
+    def stop_profiling(self, cpu_row: int = -1, cpu_value: float = 0.0) -> bool:
+        """Leave a GPU-timed region.  ``cpu_row`` / ``cpu_value`` (optional): a host-measured sample the
+        closing device kernel may append for the caller; True is returned when it was taken."""
         with self.lock:
             self._ensure_initialized()
             if self.started_cnt <= 0:
                 raise RuntimeError("No active profiling run.")
             self.started_cnt -= 1
             if self.started_cnt == 0:
+                if cpu_row >= 0:
+                    return bool(self.cupti_ext.stop(cpu_row, cpu_value))
                 self.cupti_ext.stop()
+            return False
 
     def get_results(self):
         with self.lock:

@@ -1,4 +1,4 @@
-"""GPU-time profiler module of the straggler path: hipEvent pairs instead of CUPTI activity records.
+"""GPU-time profiler module of the straggler path: device timestamps instead of CUPTI activity records.
 
 Presents the interface of the reference's pybind11 module ``nvrx_cupti_module``
 (cupti_src/cupti_module_py.cpp:33-55) -- ``CuptiProfiler(bufferSize, numBuffers,
@@ -7,10 +7,12 @@ statsMaxLenPerKernel)`` with ``initialize / shutdown / start / stop / get_stats 
 The alias module ``nvrx_cupti_module`` re-exports it under the reference's import name.
 
 What changes on MI355X: there is no CUPTI, and tracing every kernel through rocprofiler would put a
-tool thread and a string hash on every launch.  Instead ``start(key)`` / ``stop()`` record a
-hipEvent pair on the caller's current HIP stream around the profiled region; the elapsed GPU time
-(microseconds, f32, as CuptiProfiler.cpp:191) lands in a device ring keyed by ``key`` when the events
-complete.  Statistics over a ring follow the reference's native conventions (mean-of-middles median,
+tool thread and a string hash on every launch.  Instead ``start(key)`` / ``stop()`` bracket the
+profiled region on the caller's current HIP stream: by default with two one-thread kernels that read
+the device's constant-rate wall clock in stream order, the second of which writes the elapsed GPU
+time (microseconds, f32, as CuptiProfiler.cpp:191) straight into the device ring keyed by ``key`` --
+nothing is read back and the host never waits (``NVRX_GPU_TIMING=event`` selects the older hipEvent
+pair, whose elapsed time is harvested by the host when the events complete).  Statistics over a ring follow the reference's native conventions (mean-of-middles median,
 population stddev; CuptiProfiler.cpp:44-74) and are computed by the HIP statistics kernel.
 Granularity is therefore one timing row per profiled REGION rather than per kernel name
 (documented deviation; per-kernel names are SURVEY section 8(f) row 1).
@@ -18,6 +20,7 @@ Granularity is therefore one timing row per profiled REGION rather than per kern
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Dict, Optional
 
@@ -64,6 +67,8 @@ class CuptiProfiler:
         self._started = False
         self._active_row: Optional[int] = None
         self._closed = False
+        # device timestamps unless asked otherwise (or the backend cannot: the CPU test backend)
+        self._stamps = os.environ.get("NVRX_GPU_TIMING", "stamp") != "event" and hasattr(rings, "stamp_begin")
         CuptiProfiler._live = weakref.ref(self)
 
     # ---- lifecycle -----------------------------------------------------------------------------
@@ -95,17 +100,29 @@ class CuptiProfiler:
         if self._started:
             return  # reference prints "subsequent call" and carries on (CuptiProfiler.cpp:121-123)
         row = self._rings.row_for(_native.KIND_KERNEL, key)
-        self._rings.event_begin(row, self._stream_handle())
+        if self._stamps:
+            self._rings.stamp_begin(row, self._stream_handle())
+        else:
+            self._rings.event_begin(row, self._stream_handle())
         self._active_row = row
         self._started = True
 
-    def stop(self) -> None:
-        """Close the region opened by ``start`` (reference: cuptiActivityDisable)."""
+    def stop(self, cpu_row: int = -1, cpu_value: float = 0.0) -> bool:
+        """Close the region opened by ``start`` (reference: cuptiActivityDisable).
+
+        With device timestamps the closing kernel can also append ``cpu_value`` to ring row ``cpu_row``
+        (the enclosing section's wall time); returns True when it did."""
         if not self._started:
-            return
-        self._rings.event_end(self._active_row, self._stream_handle())
+            return False
+        took = False
+        if self._stamps:
+            self._rings.stamp_end(self._active_row, self._stream_handle(), cpu_row, cpu_value)
+            took = cpu_row >= 0
+        else:
+            self._rings.event_end(self._active_row, self._stream_handle())
         self._active_row = None
         self._started = False
+        return took
 
     # ---- results -----------------------------------------------------------------------------------
     def harvest(self, wait: bool = True) -> int:

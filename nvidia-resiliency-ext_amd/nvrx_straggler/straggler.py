@@ -313,9 +313,9 @@ class Detector:
                 cls.cupti_manager.stop_profiling()
             raise
         elapsed_ms = (time.perf_counter_ns() - t0) * 1e-6
-        cls.rings.push(section.row, elapsed_ms)
-        if profile_cuda:
-            cls.cupti_manager.stop_profiling()
+        # with device timestamps the kernel that closes the GPU region also appends this sample
+        if not (profile_cuda and cls.cupti_manager.stop_profiling(section.row, elapsed_ms)):
+            cls.rings.push(section.row, elapsed_ms)
 
     # ---- callable wrapping -------------------------------------------------------------------------
     @classmethod

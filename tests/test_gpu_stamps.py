@@ -1,0 +1,94 @@
+"""Device-timestamp region timing (k_stamp_begin / k_stamp_end) through the C ABI: the elapsed GPU time
+lands in the ring without any host wait, agrees with a hipEvent pair around the same region, carries the
+section's CPU sample along, and is ordered before the report that reads it."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _spin(ms: float):
+    torch.cuda._sleep(int(ms * 1e-3 * 2.0e9))  # ~cycles; only the order of magnitude matters
+
+
+def test_stamp_pair_matches_event_pair_and_appends_cpu_sample():
+    from nvrx_straggler import _native
+    from nvrx_straggler.backend import get_backend
+
+    be = get_backend()
+    rings = be.make_rings(1, 8, 64)
+    try:
+        gpu_row = rings.row_for(_native.KIND_KERNEL, "region")
+        cpu_row = rings.row_for(_native.KIND_SECTION, "section")
+        st = be.current_stream_handle()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _spin(0.1)  # first use of the sleep kernel loads its code object
+        torch.cuda.synchronize()
+        want_us = []
+        for i in range(5):
+            ev0.record()
+            rings.stamp_begin(gpu_row, st)
+            _spin(0.2 * (i + 1))
+            rings.stamp_end(gpu_row, st, cpu_row, 1.5 + i)
+            ev1.record()
+            ev1.synchronize()
+            want_us.append(ev0.elapsed_time(ev1) * 1e3)
+        assert rings.count(gpu_row) == 5 and rings.count(cpu_row) == 5
+        got = rings.read_row(gpu_row)[:5]  # flush orders the read after the stamp kernels
+        cpu = rings.read_row(cpu_row)[:5]
+        assert np.array_equal(cpu, np.array([1.5, 2.5, 3.5, 4.5, 5.5], dtype=np.float32))
+        # the stamp pair sits INSIDE the event pair: never longer, and close to it
+        for g, w in zip(got, want_us):
+            assert 0.0 < g <= w + 5.0, (got, want_us)
+            assert g >= 0.6 * w - 20.0, (got, want_us)
+    finally:
+        rings.close()
+
+
+def test_report_is_ordered_after_stamps_without_a_host_wait():
+    """generate_report right after a long GPU region: the statistics must see that region's time."""
+    from nvrx_straggler import Detector, Statistic
+
+    Detector.initialize(scores_to_compute=["individual_perf_scores"], gather_on_rank0=True, node_name="n0")
+    try:
+        for _ in range(3):
+            with Detector.detection_section("step", profile_cuda=True):
+                _spin(2.0)
+            t0 = time.perf_counter()
+            rep = Detector.generate_report()
+            dt = time.perf_counter() - t0
+            key = next(k for k in rep.local_kernel_summaries if k.endswith("step"))
+            gpu_us = rep.local_kernel_summaries[key][Statistic.MED]
+            assert rep.local_kernel_summaries[key][Statistic.NUM] == 1
+            assert gpu_us > 200.0, gpu_us  # the region really ran ~ms before the report read its ring
+            assert rep.local_section_summaries["step"][Statistic.NUM] == 1
+            assert dt > 0.0
+    finally:
+        Detector.shutdown()
+
+
+def test_nested_regions_and_unmatched_end():
+    from nvrx_straggler import _native
+    from nvrx_straggler.backend import get_backend
+
+    be = get_backend()
+    rings = be.make_rings(1, 4, 16)
+    try:
+        a = rings.row_for(_native.KIND_KERNEL, "a")
+        b = rings.row_for(_native.KIND_KERNEL, "b")
+        st = be.current_stream_handle()
+        rings.stamp_begin(a, st)
+        rings.stamp_begin(b, st)
+        _spin(0.1)
+        rings.stamp_end(b, st)
+        _spin(0.1)
+        rings.stamp_end(a, st)
+        va, vb = rings.read_row(a)[0], rings.read_row(b)[0]
+        assert va > vb > 0.0
+        with pytest.raises(_native.NativeError):
+            rings.stamp_end(a, st)
+    finally:
+        rings.close()
