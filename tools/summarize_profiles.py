@@ -15,6 +15,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -22,7 +23,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for k in ("k_row_stats", "k_score", "k_scatter", "k_colmin", "k_send_init", "k_fill_f32"):
+    m = re.search(r"k_row_stats<(\d+), (\d+)>", name)
+    if m and m.group(2) != "5":  # <512,5> is the bench shape; other tiles come from the overhead leg
+        return f"k_row_stats<{m.group(1)},{m.group(2)}>"
+    for k in ("k_row_stats", "k_score", "k_scatter", "k_colmin", "k_send_init", "k_fill_f32", "k_stamp_begin", "k_stamp_end"):
         if k in name:
             return k
     return name[:40]
@@ -30,7 +34,7 @@ def short(name):
 
 def pmc(dirname, counter):
     vals = collections.defaultdict(list)
-    for path in glob.glob(os.path.join(dirname, "*counter_collection.csv")):
+    for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
             if row["Counter_Name"] == counter:
                 vals[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
@@ -47,7 +51,7 @@ def main():
     tag, stats_dir = argv[0], argv[1]
     out = os.path.join(REPO, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats_csv = glob.glob(os.path.join(stats_dir, "*kernel_stats.csv"))[0]
+    stats_csv = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)[0]
     shutil.copy(stats_csv, os.path.join(out, f"{tag}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats_csv)))
     lines = [f"# rocprofv3 summary `{tag}`", "",
