@@ -4,7 +4,10 @@
 //   tools/kbench.cpp -o tools/bin/kbench ; run: kbench [rows] [n] [threads] [dist]
 // dist: 0 = N(10,0.3) (bench shape), 1 = lognormal heavy tail, 2 = few distinct values, 3 = drifting ramp + noise
 // Includes the library source directly so ablation builds need no second copy of the kernel.
-#include "../nvidia-resiliency-ext_amd/csrc/nvrx_straggler.hip"
+#ifndef NVRX_SRC
+#define NVRX_SRC "../nvidia-resiliency-ext_amd/csrc/nvrx_straggler.hip"
+#endif
+#include NVRX_SRC
 
 #include <random>
 
@@ -18,6 +21,30 @@
     } while (0)
 
 static std::mt19937 g_rng(1);
+
+// what runs between two timed launches (argv[6]): 0 nothing, 1 a one-workgroup kernel that stores to pinned host
+// memory behind a system-scope fence (what k_score does between two reports), 2 a 1 GiB read sweep that evicts L2 and
+// the Infinity Cache (true cold-HBM reads), 3 = 1 + a 30 us host pause
+__global__ void k_between_fence(uint32_t *host_word, uint32_t v) {
+    if (threadIdx.x == 0) host_word[1] = v;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_between_release(uint32_t *host_word, uint32_t v) {  // between=4: release-only publication
+    if (threadIdx.x == 0) host_word[1] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_between_sweep(const float4 *p, size_t n4, float *sink) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = p[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123.456f) *sink = acc;
+}
 
 static void gen(std::vector<float> &h, int rows, int n, int stride, int dist, float scale) {
     std::normal_distribution<float> nd(10.f, 0.3f);
@@ -68,6 +95,12 @@ int main(int argc, char **argv) {
     const int only_threads = argc > 3 ? atoi(argv[3]) : 0;
     const int dist = argc > 4 ? atoi(argv[4]) : 0;
     const int use_win = argc > 5 ? atoi(argv[5]) : 1;
+    const int between = argc > 6 ? atoi(argv[6]) : 0;
+    uint32_t *h_word = nullptr;
+    CK(hipHostMalloc(&h_word, 64, hipHostMallocMapped));
+    float4 *d_sweep = nullptr;
+    const size_t sweep_n4 = (size_t)1 << 26;  // 1 GiB
+    if (between == 2) CK(hipMalloc(&d_sweep, sweep_n4 * 16));
     const int stride = (n + 3) & ~3;
     std::vector<float> h((size_t)rows * stride, 0.f);
     float *d_s, *d_stats;
@@ -104,18 +137,20 @@ int main(int argc, char **argv) {
         int total_bad = 0;
         auto check = [&](const Expect &e, const char *what) {
             CK(hipMemcpy(st.data(), d_stats, st.size() * 4, hipMemcpyDeviceToHost));
-            int bad = 0, hits = 0;
+            int bad = 0, hits = 0, radix = 0, rebinned = 0;
             double worst_avg = 0, worst_std = 0;
             for (int r = 0; r < rows; r++) {
                 const float *o = &st[(size_t)r * 8];
                 if (NVRX_ABLATE == 0 && o[2] != e.med[r]) bad++;
                 if (o[0] != e.mn[r] || o[1] != e.mx[r]) bad++;
                 hits += o[7] == 1.0f;  // estimate held, no refinement
+                radix += ((int)o[7] & 8) != 0;  // integer radix fallback
+                rebinned += ((int)o[7] & 6) != 0 && ((int)o[7] & 8) == 0;  // re-binned in the float domain, then ranked
                 worst_avg = std::max(worst_avg, fabs(o[3] - e.avg[r]) / fabs(e.avg[r]));
                 worst_std = std::max(worst_std, fabs(o[4] - e.sd[r]) / fabs(e.sd[r]));
             }
             total_bad += bad;
-            printf("  %-28s mismatches %d  fast path %d/%d  avg_err %.1e std_err %.1e\n", what, bad, hits, rows, worst_avg, worst_std);
+            printf("  %-28s mismatches %d  fast path %d/%d rebinned %d radix %d  avg_err %.1e std_err %.1e\n", what, bad, hits, rows, rebinned, radix, worst_avg, worst_std);
         };
         // fresh draws of the same distribution: report 0 is cold, later ones should hit the window
         float ms_seq[6];
@@ -132,6 +167,15 @@ int main(int argc, char **argv) {
         float mn = 1e9f;
         const int reps = 50;
         for (int i = 0; i < reps + 5; i++) {
+            if (between == 1 || between == 3) hipLaunchKernelGGL(k_between_fence, dim3(1), dim3(256), 0, nullptr, h_word, (uint32_t)i);
+            if (between == 4) hipLaunchKernelGGL(k_between_release, dim3(8), dim3(256), 0, nullptr, h_word, (uint32_t)i);
+            if (between == 5) hipLaunchKernelGGL(k_between_fence, dim3(8), dim3(256), 0, nullptr, h_word, (uint32_t)i);
+            if (between == 2) hipLaunchKernelGGL(k_between_sweep, dim3(2048), dim3(256), 0, nullptr, (const float4 *)d_sweep, sweep_n4, d_stats);
+            if (between == 3) {
+                CK(hipDeviceSynchronize());
+                const auto t0 = std::chrono::steady_clock::now();
+                while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) {}
+            }
             const float ms = launch();
             if (i >= 5) {
                 tot += ms;
@@ -139,6 +183,7 @@ int main(int argc, char **argv) {
             }
         }
         check(e, "steady state (same data)");
+        printf("between=%d ", between);
         printf("ablate=%d dist=%d win=%d threads=%4d vpt=%2d rows=%d n=%d : avg %.2f us  min %.2f us  -> %.0f GB/s\n", NVRX_ABLATE, dist,
                use_win, best->threads, best->vpt, rows, n, tot / reps * 1e3, mn * 1e3, (double)rows * n * 4 / (tot / reps * 1e-3) / 1e9);
 #ifdef NVRX_PHASE_CLOCKS
