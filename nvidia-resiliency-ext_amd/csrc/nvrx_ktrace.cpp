@@ -1,0 +1,315 @@
+// nvrx_ktrace.cpp -- implementation of include/nvrx_ktrace.h on rocprofiler-sdk (host code only).
+//
+// Role in the straggler path: the reference's CuptiProfiler (cupti_src/CuptiProfiler.cpp) keeps, per kernel
+// key "<name>_blk_x_y_z_grid_x_y_z", a ring of durations fed from CUPTI activity records on CUPTI's thread.
+// Here the rocprofiler-sdk buffered KERNEL_DISPATCH service plays CUPTI's part; the rings and their
+// statistics live on the device (libnvrx_straggler_hip.so), so this file only turns dispatch records into
+// (key id, microseconds) pairs and hands them to whoever drains them.
+//
+// Threads: the SDK's callback thread runs on_records() / on_code_object(); the application thread calls the
+// exported functions.  One mutex guards the shared state (the reference: _kernelDurationsMutex,
+// CuptiProfiler.cpp:174).  nvrx_ktrace_flush() calls rocprofiler_flush_buffer WITHOUT holding it, as the
+// reference flushes before taking its mutex (CuptiProfiler.cpp:138-139,149-150).
+#include <rocprofiler-sdk/buffer.h>
+#include <rocprofiler-sdk/buffer_tracing.h>
+#include <rocprofiler-sdk/callback_tracing.h>
+#include <rocprofiler-sdk/context.h>
+#include <rocprofiler-sdk/fwd.h>
+#include <rocprofiler-sdk/internal_threading.h>
+#include <rocprofiler-sdk/registration.h>
+#include <rocprofiler-sdk/rocprofiler.h>
+
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "nvrx_ktrace.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define SDK_TRY(expr)                                                                              \
+    do {                                                                                           \
+        rocprofiler_status_t s_ = (expr);                                                          \
+        if (s_ != ROCPROFILER_STATUS_SUCCESS)                                                      \
+            return fail(NVRX_KTRACE_ERR_SDK, "%s failed: %s", #expr, rocprofiler_get_status_string(s_)); \
+    } while (0)
+
+struct State {
+    std::mutex mu;
+    // kernel_id -> mangled name (code-object callbacks arrive before the first dispatch of the kernel)
+    std::unordered_map<uint64_t, std::string> kernel_names;
+    // key string -> dense id; names are never moved once created (nvrx_ktrace_key_name hands out pointers)
+    std::unordered_map<std::string, uint32_t> key_ids;
+    std::deque<std::string> key_names;
+    std::deque<nvrx_ktrace_record> pending;
+    size_t max_pending = 1u << 20;
+    uint64_t dropped = 0;
+    uint64_t received = 0;  // records seen by the callback thread, dropped or not
+
+    rocprofiler_context_id_t names_ctx{0};  // code-object callbacks: active for the whole process
+    rocprofiler_context_id_t ctx{0};        // kernel-dispatch tracing: active between start and stop
+    rocprofiler_buffer_id_t buffer{0};
+    std::atomic<int> setup_done{0};  // force_configure has been issued
+    std::atomic<int> ready{0};       // tool_init ran and the context is valid
+    std::atomic<int> running{0};
+};
+
+State &st() {
+    static State *s = new State();  // leaked on purpose: SDK threads may outlive static destruction
+    return *s;
+}
+
+void on_code_object(rocprofiler_callback_tracing_record_t record, rocprofiler_user_data_t *, void *) {
+    if (record.kind != ROCPROFILER_CALLBACK_TRACING_CODE_OBJECT ||
+        record.operation != ROCPROFILER_CODE_OBJECT_DEVICE_KERNEL_SYMBOL_REGISTER ||
+        record.phase != ROCPROFILER_CALLBACK_PHASE_LOAD)
+        return;
+    auto *data = static_cast<rocprofiler_callback_tracing_code_object_kernel_symbol_register_data_t *>(record.payload);
+    if (!data || !data->kernel_name) return;
+    std::string name(data->kernel_name);
+    // the code object names a kernel's descriptor symbol: "<mangled name>.kd"
+    if (name.size() > 3 && name.compare(name.size() - 3, 3, ".kd") == 0) name.resize(name.size() - 3);
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    s.kernel_names[data->kernel_id] = std::move(name);
+}
+
+void on_records(rocprofiler_context_id_t, rocprofiler_buffer_id_t, rocprofiler_record_header_t **headers,
+                size_t num_headers, void *, uint64_t) {
+    State &s = st();
+    char key[4096];  // KERNEL_NAME_BUF_LEN of the reference (CuptiProfiler.cpp:172)
+    std::lock_guard<std::mutex> lk(s.mu);
+    for (size_t i = 0; i < num_headers; i++) {
+        rocprofiler_record_header_t *h = headers[i];
+        if (h->category != ROCPROFILER_BUFFER_CATEGORY_TRACING || h->kind != ROCPROFILER_BUFFER_TRACING_KERNEL_DISPATCH)
+            continue;
+        auto *rec = static_cast<rocprofiler_buffer_tracing_kernel_dispatch_record_t *>(h->payload);
+        if (rec->start_timestamp == 0 || rec->end_timestamp == 0) continue;  // CuptiProfiler.cpp:182-184
+        const auto &d = rec->dispatch_info;
+        auto it = s.kernel_names.find(d.kernel_id);
+        const char *name = it != s.kernel_names.end() ? it->second.c_str() : "unknown_kernel";
+        // CUDA's gridDim counts blocks; HSA's grid counts work-items
+        const unsigned bx = d.workgroup_size.x ? d.workgroup_size.x : 1, by = d.workgroup_size.y ? d.workgroup_size.y : 1,
+                       bz = d.workgroup_size.z ? d.workgroup_size.z : 1;
+        snprintf(key, sizeof(key), "%s_blk_%u_%u_%u_grid_%u_%u_%u", name, bx, by, bz, (d.grid_size.x + bx - 1) / bx,
+                 (d.grid_size.y + by - 1) / by, (d.grid_size.z + bz - 1) / bz);
+        uint32_t id;
+        auto kit = s.key_ids.find(key);
+        if (kit != s.key_ids.end()) {
+            id = kit->second;
+        } else {
+            id = (uint32_t)s.key_names.size();
+            s.key_names.emplace_back(key);
+            s.key_ids.emplace(s.key_names.back(), id);
+        }
+        s.received++;
+        if (s.pending.size() >= s.max_pending) {
+            s.dropped++;
+            continue;
+        }
+        // nanoseconds -> microseconds exactly as the reference: integer difference, one f32 division
+        const float us = (float)(rec->end_timestamp - rec->start_timestamp) / 1000.0f;
+        s.pending.push_back(nvrx_ktrace_record{id, us});
+    }
+}
+
+#define KT_DBG(msg)                                                        \
+    do {                                                                   \
+        if (getenv("NVRX_KTRACE_DEBUG")) {                                 \
+            fprintf(stderr, "[nvrx_ktrace] %s\n", msg);                    \
+            fflush(stderr);                                                \
+        }                                                                  \
+    } while (0)
+
+int tool_init(rocprofiler_client_finalize_t, void *) {
+    State &s = st();
+    KT_DBG("tool_init: enter");
+    // Two contexts: kernel names come from code-object load callbacks, which only fire while their context is
+    // active -- and PyTorch loads code objects lazily, at a kernel's first launch -- so that context runs for the
+    // whole process (a callback per code object, nothing per launch).  The dispatch-tracing context is the one
+    // start / stop switch, so launches outside profiled sections cost nothing.
+    if (rocprofiler_create_context(&s.names_ctx) != ROCPROFILER_STATUS_SUCCESS) return -1;
+    rocprofiler_tracing_operation_t ops[] = {ROCPROFILER_CODE_OBJECT_DEVICE_KERNEL_SYMBOL_REGISTER};
+    if (rocprofiler_configure_callback_tracing_service(s.names_ctx, ROCPROFILER_CALLBACK_TRACING_CODE_OBJECT, ops, 1,
+                                                       on_code_object, nullptr) != ROCPROFILER_STATUS_SUCCESS)
+        return -1;
+    KT_DBG("tool_init: names context configured");
+    if (rocprofiler_create_context(&s.ctx) != ROCPROFILER_STATUS_SUCCESS) return -1;
+    constexpr size_t kBufBytes = 256 * 1024;
+    if (rocprofiler_create_buffer(s.ctx, kBufBytes, kBufBytes - kBufBytes / 8, ROCPROFILER_BUFFER_POLICY_LOSSLESS,
+                                  on_records, nullptr, &s.buffer) != ROCPROFILER_STATUS_SUCCESS)
+        return -1;
+    if (rocprofiler_configure_buffer_tracing_service(s.ctx, ROCPROFILER_BUFFER_TRACING_KERNEL_DISPATCH, nullptr, 0,
+                                                     s.buffer) != ROCPROFILER_STATUS_SUCCESS)
+        return -1;
+    KT_DBG("tool_init: dispatch service configured");
+    rocprofiler_callback_thread_t thr{};
+    if (rocprofiler_create_callback_thread(&thr) != ROCPROFILER_STATUS_SUCCESS) return -1;
+    if (rocprofiler_assign_callback_thread(s.buffer, thr) != ROCPROFILER_STATUS_SUCCESS) return -1;
+    int valid = 0;
+    if (rocprofiler_context_is_valid(s.names_ctx, &valid) != ROCPROFILER_STATUS_SUCCESS || !valid) return -1;
+    if (rocprofiler_context_is_valid(s.ctx, &valid) != ROCPROFILER_STATUS_SUCCESS || !valid) return -1;
+    KT_DBG("tool_init: callback thread assigned, starting names context");
+    if (rocprofiler_start_context(s.names_ctx) != ROCPROFILER_STATUS_SUCCESS) return -1;
+    s.ready.store(1, std::memory_order_release);
+    KT_DBG("tool_init: done");
+    return 0;
+}
+
+void tool_fini(void *) { st().ready.store(0, std::memory_order_release); }
+
+}  // namespace
+
+extern "C" rocprofiler_tool_configure_result_t *rocprofiler_configure(uint32_t, const char *, uint32_t,
+                                                                      rocprofiler_client_id_t *id) {
+    id->name = "nvrx_ktrace";
+    KT_DBG("rocprofiler_configure called");
+    static rocprofiler_tool_configure_result_t cfg{sizeof(rocprofiler_tool_configure_result_t), &tool_init, &tool_fini,
+                                                   nullptr};
+    st().setup_done.store(1, std::memory_order_release);
+    return &cfg;
+}
+
+extern "C" {
+
+const char *nvrx_ktrace_last_error(void) { return g_err.c_str(); }
+
+int nvrx_ktrace_setup(int max_pending) {
+    State &s = st();
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.max_pending = max_pending > 0 ? (size_t)max_pending : (size_t)1 << 20;
+    }
+    if (s.setup_done.load(std::memory_order_acquire)) return NVRX_KTRACE_OK;  // already registered (or via ROCP_TOOL_LIBRARIES)
+    int status = 0;
+    KT_DBG("setup: enter");
+    rocprofiler_is_initialized(&status);
+    if (status != 0)
+        return fail(NVRX_KTRACE_ERR_STATE,
+                    "rocprofiler-sdk is already configured (the HIP runtime initialised before nvrx_ktrace_setup): import "
+                    "nvrx_straggler with NVRX_GPU_TIMING=kernels before the first HIP call, or name libnvrx_ktrace.so in "
+                    "ROCP_TOOL_LIBRARIES");
+    KT_DBG("setup: calling rocprofiler_force_configure");
+    rocprofiler_status_t rs = rocprofiler_force_configure(&rocprofiler_configure);
+    KT_DBG("setup: rocprofiler_force_configure returned");
+    if (rs != ROCPROFILER_STATUS_SUCCESS)
+        return fail(rs == ROCPROFILER_STATUS_ERROR_CONFIGURATION_LOCKED ? NVRX_KTRACE_ERR_STATE : NVRX_KTRACE_ERR_SDK,
+                    "rocprofiler_force_configure failed: %s", rocprofiler_get_status_string(rs));
+    return NVRX_KTRACE_OK;
+}
+
+int nvrx_ktrace_ready(void) { return st().ready.load(std::memory_order_acquire); }
+
+int nvrx_ktrace_start(void) {
+    State &s = st();
+    if (!s.ready.load(std::memory_order_acquire)) return fail(NVRX_KTRACE_ERR_STATE, "kernel tracing is not set up");
+    if (s.running.exchange(1)) return NVRX_KTRACE_OK;  // "subsequent call", CuptiProfiler.cpp:121-123
+    int active = 0;
+    SDK_TRY(rocprofiler_context_is_active(s.ctx, &active));
+    if (!active) SDK_TRY(rocprofiler_start_context(s.ctx));
+    return NVRX_KTRACE_OK;
+}
+
+int nvrx_ktrace_stop(void) {
+    State &s = st();
+    if (!s.ready.load(std::memory_order_acquire)) return fail(NVRX_KTRACE_ERR_STATE, "kernel tracing is not set up");
+    if (!s.running.exchange(0)) return NVRX_KTRACE_OK;
+    int active = 0;
+    SDK_TRY(rocprofiler_context_is_active(s.ctx, &active));
+    if (active) SDK_TRY(rocprofiler_stop_context(s.ctx));
+    return NVRX_KTRACE_OK;
+}
+
+int nvrx_ktrace_flush(void) {
+    State &s = st();
+    if (!s.ready.load(std::memory_order_acquire)) return fail(NVRX_KTRACE_ERR_STATE, "kernel tracing is not set up");
+    // A dispatch record is written by the SDK's completion handler, which may run a moment after the stream that
+    // launched the kernel reports it finished: flush until two consecutive flushes bring nothing new.
+    uint64_t last = ~0ull;
+    for (int i = 0; i < 50; i++) {
+        rocprofiler_status_t rs = rocprofiler_flush_buffer(s.buffer);
+        if (rs != ROCPROFILER_STATUS_SUCCESS && rs != ROCPROFILER_STATUS_ERROR_BUFFER_BUSY)
+            return fail(NVRX_KTRACE_ERR_SDK, "rocprofiler_flush_buffer failed: %s", rocprofiler_get_status_string(rs));
+        uint64_t now;
+        {
+            std::lock_guard<std::mutex> lk(s.mu);
+            now = s.received;
+        }
+        if (rs == ROCPROFILER_STATUS_SUCCESS && now == last) break;
+        last = now;
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+    return NVRX_KTRACE_OK;
+}
+
+int nvrx_ktrace_drain(nvrx_ktrace_record *out, int cap) {
+    if (!out || cap < 0) return fail(NVRX_KTRACE_ERR_INVALID, "bad drain buffer");
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    int n = 0;
+    while (n < cap && !s.pending.empty()) {
+        out[n++] = s.pending.front();
+        s.pending.pop_front();
+    }
+    return n;
+}
+
+int nvrx_ktrace_pending(void) {
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    return (int)s.pending.size();
+}
+
+uint64_t nvrx_ktrace_dropped(void) {
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    return s.dropped;
+}
+
+int nvrx_ktrace_num_keys(void) {
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    return (int)s.key_names.size();
+}
+
+const char *nvrx_ktrace_key_name(uint32_t key) {
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    return key < s.key_names.size() ? s.key_names[key].c_str() : nullptr;
+}
+
+int nvrx_ktrace_reset(void) {
+    State &s = st();
+    if (s.ready.load(std::memory_order_acquire)) {
+        int rc = nvrx_ktrace_flush();
+        if (rc < 0) return rc;
+    }
+    std::lock_guard<std::mutex> lk(s.mu);
+    s.pending.clear();
+    return NVRX_KTRACE_OK;
+}
+
+}  // extern "C"

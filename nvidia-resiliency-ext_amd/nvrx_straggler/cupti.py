@@ -8,6 +8,7 @@ hipEvent profiler (``hip_profiler.CuptiProfiler``; import name ``nvrx_cupti_modu
 """
 from __future__ import annotations
 
+import os
 import threading
 
 
@@ -22,7 +23,11 @@ class CuptiManager:
         import nvrx_cupti_module as profiler_module  # lazy, like the reference (cupti.py:35)
 
         kwargs = {} if rings is None else {"rings": rings}
-        self.cupti_ext = profiler_module.CuptiProfiler(
+        # NVRX_GPU_TIMING=kernels: per-kernel durations by kernel name through rocprofiler-sdk (ktrace.py);
+        # otherwise one GPU-time row per profiled region (hip_profiler.py)
+        self.per_kernel = os.environ.get("NVRX_GPU_TIMING", "stamp") == "kernels"
+        profiler_cls = profiler_module.KernelTraceProfiler if self.per_kernel else profiler_module.CuptiProfiler
+        self.cupti_ext = profiler_cls(
             bufferSize=bufferSize, numBuffers=numBuffers, statsMaxLenPerKernel=statsMaxLenPerKernel, **kwargs
         )
         self.is_initialized = False
@@ -71,6 +76,12 @@ class CuptiManager:
                     return bool(self.cupti_ext.stop(cpu_row, cpu_value))
                 self.cupti_ext.stop()
             return False
+
+    def harvest(self, wait: bool = True) -> int:
+        """Bring every finished GPU measurement into the device rings (report time)."""
+        with self.lock:
+            self._ensure_initialized()
+            return self.cupti_ext.harvest(wait)
 
     def get_results(self):
         with self.lock:

@@ -1,0 +1,291 @@
+"""Per-kernel GPU timing with real kernel names: the CUPTI-activity equivalent on MI355X.
+
+``NVRX_GPU_TIMING=kernels`` selects this profiler instead of the per-region device timestamps of
+``hip_profiler``.  It keeps the interface of the reference's native module (``CuptiProfiler`` with
+``initialize / shutdown / start / stop / get_stats / reset``, cupti_src/cupti_module_py.cpp:33-55) and its
+data model: while a profiled section is open every kernel the process launches is recorded under the key
+``<mangled name>_blk_x_y_z_grid_x_y_z`` with its duration in microseconds (CuptiProfiler.cpp:186-191), so
+the rank's GPU score is the kernel-weighted mean of reporting.py:219-253 over real kernels, and RCCL's
+``ncclDev*`` kernels are left out exactly as in the reference (reporting.py:330-336).
+
+Underneath, ``libnvrx_ktrace.so`` (include/nvrx_ktrace.h) is a rocprofiler-sdk tool: dispatch records are
+collected on the SDK's thread, ``harvest()`` drains them and appends each kernel's durations to its DEVICE
+ring row, and the statistics (mean-of-middles median, population stddev; CuptiProfiler.cpp:44-74) are
+computed by the same HIP kernel as every other row.
+
+The SDK only accepts tools before the HIP runtime initialises.  Importing ``nvrx_straggler`` with
+``NVRX_GPU_TIMING=kernels`` set adds the library to ``ROCP_TOOL_LIBRARIES`` at import time, so the SDK picks it up
+when HIP starts; if HIP was initialised earlier the profiler raises with the advice to set the variable (or the
+import order) accordingly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+import warnings
+import weakref
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_uint32, c_uint64
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _native
+from . import backend as _backend_mod
+from .hip_profiler import KernelStats
+
+_LIB_NAME = "libnvrx_ktrace.so"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
+
+
+class Record(Structure):
+    _fields_ = [("key", c_uint32), ("us", c_float)]
+
+
+RECORD_DTYPE = np.dtype([("key", np.uint32), ("us", np.float32)])
+
+# every symbol include/nvrx_ktrace.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("nvrx_ktrace_setup", c_int, [c_int]),
+    ("nvrx_ktrace_ready", c_int, []),
+    ("nvrx_ktrace_start", c_int, []),
+    ("nvrx_ktrace_stop", c_int, []),
+    ("nvrx_ktrace_flush", c_int, []),
+    ("nvrx_ktrace_drain", c_int, [POINTER(Record), c_int]),
+    ("nvrx_ktrace_pending", c_int, []),
+    ("nvrx_ktrace_dropped", c_uint64, []),
+    ("nvrx_ktrace_num_keys", c_int, []),
+    ("nvrx_ktrace_key_name", c_char_p, [c_uint32]),
+    ("nvrx_ktrace_reset", c_int, []),
+    ("nvrx_ktrace_last_error", c_char_p, []),
+]
+
+_lib = None
+_lock = threading.Lock()
+_setup_error: Optional[str] = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load libnvrx_ktrace.so (once); raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise RuntimeError(f"{_LIB_NAME} not found at {_LIB_PATH}; build it with `make -C nvidia-resiliency-ext_amd/csrc`")
+            lib = ctypes.CDLL(_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+            for name, restype, argtypes in SYMBOLS:
+                fn = getattr(lib, name)
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _lib = lib
+    return _lib
+
+
+def _check(rc: int) -> int:
+    if rc < 0:
+        msg = load().nvrx_ktrace_last_error()
+        raise RuntimeError(f"nvrx_ktrace error {rc}: {msg.decode() if msg else '?'}")
+    return rc
+
+
+def setup(max_pending: int = 0) -> None:
+    """Register the tool with rocprofiler-sdk.  Call before the first HIP call of the process.
+
+    Default: name the library in ``ROCP_TOOL_LIBRARIES`` -- the SDK then loads it when the HIP runtime
+    initialises, the same route ``rocprofv3`` uses for its own tool.  ``NVRX_KTRACE_FORCE=1`` registers
+    immediately through ``rocprofiler_force_configure`` instead.  Either way the SDK's own start-up is slow the
+    first time on a freshly booted machine (~50 s measured on ROCm 7.2 while it pages its libraries in, ~3 s
+    afterwards); the default route pays that inside the first HIP call rather than inside ``import``."""
+    global _setup_error
+    if os.environ.get("NVRX_KTRACE_FORCE", "") == "1":
+        try:
+            _check(load().nvrx_ktrace_setup(int(max_pending)))
+            _setup_error = None
+        except RuntimeError as e:
+            _setup_error = str(e)
+            raise
+        return
+    libs = [p for p in os.environ.get("ROCP_TOOL_LIBRARIES", "").split(":") if p]
+    if _LIB_PATH not in libs:
+        if not os.path.exists(_LIB_PATH):
+            _setup_error = f"{_LIB_NAME} not found at {_LIB_PATH}; build it with `make -C nvidia-resiliency-ext_amd/csrc`"
+            raise RuntimeError(_setup_error)
+        os.environ["ROCP_TOOL_LIBRARIES"] = ":".join(libs + [_LIB_PATH])
+    _setup_error = None
+
+
+def setup_from_env() -> None:
+    """Import-time hook: register early when ``NVRX_GPU_TIMING=kernels`` (errors surface at first use)."""
+    if os.environ.get("NVRX_GPU_TIMING", "") == "kernels":
+        try:
+            setup()
+        except Exception:  # noqa: BLE001  (reported by KernelTraceProfiler.__init__)
+            pass
+
+
+def drain_all() -> np.ndarray:
+    """Flush, then pop every pending record: structured array with fields ``key`` (u32) and ``us`` (f32)."""
+    lib = load()
+    _check(lib.nvrx_ktrace_flush())
+    chunks = []
+    cap = 1 << 16
+    buf = (Record * cap)()
+    while True:
+        n = _check(lib.nvrx_ktrace_drain(buf, cap))
+        if n == 0:
+            break
+        chunks.append(np.frombuffer(buf, dtype=RECORD_DTYPE, count=n).copy())
+        if n < cap:
+            break
+    return np.concatenate(chunks) if chunks else np.empty(0, dtype=RECORD_DTYPE)
+
+
+def key_name(key: int) -> str:
+    name = load().nvrx_ktrace_key_name(int(key))
+    return name.decode() if name else f"unknown_key_{key}"
+
+
+class KernelTraceProfiler:
+    """rocprofiler-sdk stand-in for the CUPTI profiler object; one live instance per process."""
+
+    _live: Optional["weakref.ReferenceType[KernelTraceProfiler]"] = None
+
+    def __init__(self, bufferSize: int = 1024 * 1024 * 8, numBuffers: int = 8, statsMaxLenPerKernel: int = 1024,
+                 rings=None, max_keys: int = 4096):
+        live = KernelTraceProfiler._live() if KernelTraceProfiler._live is not None else None
+        if live is not None and not live._closed:
+            raise RuntimeError("Only one CuptiProfiler instance is allowed.")
+        self._lib = load()
+        if _setup_error is not None and not self._lib.nvrx_ktrace_ready():
+            raise RuntimeError(_setup_error)
+        if not self._lib.nvrx_ktrace_ready():
+            setup()  # no-op when the import hook already ran; too late if HIP is already up (checked in initialize)
+        self._owns_rings = rings is None
+        if rings is None:
+            rings = _backend_mod.get_backend().make_rings(1, int(max_keys), int(statsMaxLenPerKernel))
+        self._rings = rings
+        self._initialized = False
+        self._started = False
+        self._closed = False
+        self._key_rows: Dict[int, int] = {}  # tracer key id -> ring row (-1: no row left)
+        self.keys_without_row = 0
+        KernelTraceProfiler._live = weakref.ref(self)
+
+    # ---- lifecycle -----------------------------------------------------------------------------
+    def _ensure_ready(self) -> None:
+        if not self._lib.nvrx_ktrace_ready():
+            import torch
+
+            torch.cuda.init()  # the SDK calls the tool's initialiser when the runtime comes up
+            if not self._lib.nvrx_ktrace_ready():
+                raise RuntimeError(
+                    "kernel tracing did not come up: rocprofiler-sdk was configured before nvrx_ktrace registered. "
+                    "Import nvrx_straggler with NVRX_GPU_TIMING=kernels before the first HIP call, or set "
+                    f"ROCP_TOOL_LIBRARIES={_LIB_PATH}"
+                )
+
+    def initialize(self) -> None:
+        self._ensure_ready()
+        self._initialized = True
+
+    def shutdown(self) -> None:
+        if self._started:
+            self.stop()
+        self._initialized = False
+
+    def close(self) -> None:
+        if not self._closed:
+            self._closed = True
+            if self._owns_rings:
+                self._rings.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tracing window ----------------------------------------------------------------------------
+    def start(self, key: str = "") -> None:
+        """Trace every kernel launched from now on (reference: cuptiActivityEnable); ``key`` is unused --
+        kernels name themselves."""
+        if self._started:
+            return
+        _check(self._lib.nvrx_ktrace_start())
+        self._started = True
+
+    def stop(self, cpu_row: int = -1, cpu_value: float = 0.0) -> bool:
+        if not self._started:
+            return False
+        _check(self._lib.nvrx_ktrace_stop())
+        self._started = False
+        return False  # the section's wall-time sample is the caller's to push
+
+    # ---- results -----------------------------------------------------------------------------------
+    def harvest(self, wait: bool = True) -> int:
+        """Move the recorded kernel durations into their device ring rows.  ``wait``: let the device finish
+        first, as the reference does before it reads its statistics (straggler.py:234)."""
+        if wait:
+            import torch
+
+            torch.cuda.synchronize()
+        recs = drain_all()
+        if recs.size == 0:
+            return 0
+        order = np.argsort(recs["key"], kind="stable")  # stable: samples stay in launch order inside a key
+        keys = recs["key"][order]
+        us = np.ascontiguousarray(recs["us"][order])
+        bounds = np.flatnonzero(np.diff(keys)) + 1
+        starts = np.concatenate(([0], bounds))
+        ends = np.concatenate((bounds, [keys.size]))
+        rings = self._rings
+        for a, b in zip(starts.tolist(), ends.tolist()):
+            k = int(keys[a])
+            row = self._key_rows.get(k)
+            if row is None:
+                try:
+                    row = rings.row_for(_native.KIND_KERNEL, key_name(k))
+                except RuntimeError:
+                    row = -1
+                    self.keys_without_row += 1
+                    if self.keys_without_row == 1:
+                        warnings.warn("straggler rings are full: further kernel names are not recorded "
+                                      "(raise max_rows in Detector.initialize)")
+                self._key_rows[k] = row
+            if row >= 0:
+                rings.push_many(row, us[a:b])
+        return 0
+
+    def active_rows(self) -> Dict[str, int]:
+        r = self._rings
+        return {k: row for k, row in r.kernel_row_names.items() if r.count(row) > 0}
+
+    def get_stats(self) -> Dict[str, KernelStats]:
+        self.harvest(wait=True)
+        rows = self.active_rows()
+        out: Dict[str, KernelStats] = {}
+        if not rows:
+            return out
+        stats = self._rings.peek_stats()
+        for key, row in rows.items():
+            v = stats[row]
+            ks = KernelStats()
+            ks.min, ks.max, ks.median, ks.avg, ks.stddev = (float(v[i]) for i in range(5))
+            ks.num_calls = int(v[5])
+            out[key] = ks
+        return out
+
+    def reset(self) -> None:
+        _check(self._lib.nvrx_ktrace_reset())
+        for row in self._rings.kernel_row_names.values():
+            self._rings.set_count(row, 0)
+
+    @property
+    def dropped(self) -> int:
+        return int(self._lib.nvrx_ktrace_dropped())

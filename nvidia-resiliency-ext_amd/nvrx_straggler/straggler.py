@@ -22,6 +22,7 @@ from __future__ import annotations
 import dataclasses
 import functools
 import inspect
+import os
 import socket
 import sys
 import time
@@ -169,6 +170,8 @@ class Detector:
         cls.custom_sections = {}
         cls._occupied_key = None
         ring_cap = int(CustomSection.max_elapseds_len)
+        if os.environ.get("NVRX_GPU_TIMING", "") == "kernels" and int(max_rows) == 256:
+            max_rows = 4096  # one row per distinct kernel key; 4096 x 8192 f32 = 128 MB of 288 GB
         cls.rings = _backend_mod.get_backend().make_rings(1, int(max_rows), ring_cap)
         cls.cupti_manager = CuptiManager(statsMaxLenPerKernel=ring_cap, rings=cls.rings)
         cls.cupti_manager.initialize()
@@ -233,7 +236,8 @@ class Detector:
         assert cls.initialized
         rings = cls.rings
         # the recorded GPU regions must have finished; nothing else on the device is waited for
-        rings.harvest(wait=True)
+        # (per-kernel tracing: the device is synchronised and the traced durations move into their rows)
+        cls.cupti_manager.harvest(wait=True)
         # which rows hold samples this window (one C call); the name tables are rebuilt only when
         # that set changes, so a steady-state report does no per-section Python work
         occupied = (rings.counts() > 0).tobytes()

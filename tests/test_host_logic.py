@@ -36,6 +36,31 @@ def test_library_exports_every_symbol_in_the_header():
     assert lib.nvrx_last_error() is not None
 
 
+def test_ktrace_library_exports_every_symbol_in_its_header():
+    """libnvrx_ktrace.so (per-kernel tracing, include/nvrx_ktrace.h): loads without a GPU and exports every
+    declared entry point plus the rocprofiler-sdk tool hook; nothing is registered or traced here."""
+    import ctypes
+
+    from nvrx_straggler import ktrace
+
+    header = open(os.path.join(REPO, "include", "nvrx_ktrace.h")).read()
+    declared = set(re.findall(r"^(?:int|uint64_t|const char \*)\s*(nvrx_ktrace_\w+)\s*\(", header, flags=re.M))
+    assert len(declared) == 12, declared
+    lib = ktrace.load()
+    assert declared == {name for name, _, _ in ktrace.SYMBOLS}
+    for name in declared:
+        assert hasattr(lib, name)
+    assert hasattr(lib, "rocprofiler_configure")  # what ROCP_TOOL_LIBRARIES / force_configure bind
+    assert lib.nvrx_ktrace_ready() == 0
+    assert lib.nvrx_ktrace_num_keys() == 0 and lib.nvrx_ktrace_pending() == 0 and lib.nvrx_ktrace_dropped() == 0
+    assert lib.nvrx_ktrace_key_name(0) is None
+    assert lib.nvrx_ktrace_start() == -1 and b"not set up" in lib.nvrx_ktrace_last_error()
+    assert lib.nvrx_ktrace_drain(None, 4) == -22
+    buf = (ktrace.Record * 4)()
+    assert lib.nvrx_ktrace_drain(buf, 4) == 0
+    assert ctypes.sizeof(ktrace.Record) == 8 and ktrace.RECORD_DTYPE.itemsize == 8
+
+
 def test_abi_argument_validation_without_a_gpu():
     """Pure argument checks return -EINVAL before any HIP call."""
     from nvrx_straggler import _native
