@@ -341,6 +341,40 @@ def test_all_gather_object_only_when_names_change():
     assert counts[0] == [2, 0, 1, 0, 1] and counts[1] == [2, 0, 1, 0, 1]
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_name_exchange_digests_give_the_ids_of_the_string_exchange(world):
+    """the digest wire format assigns exactly the ids of the reference's string exchange
+    (first appearance, rank-major), every rank ends up with every name, and strings only travel for digests
+    some rank cannot resolve."""
+    ref = run_ranks(workers.name_exchange, world, mode="strings")
+    for mode in ("auto", "digests"):
+        got = run_ranks(workers.name_exchange, world, mode=mode)
+        for r in range(world):
+            assert got[r]["kernel_ids"] == ref[0]["kernel_ids"], (mode, r)
+            assert got[r]["section_ids"] == ref[0]["section_ids"]
+            assert got[r]["id_to_kernel"] == ref[0]["id_to_kernel"]
+            assert got[r]["counter"] == 300 + 40 * world + 52 + 1
+    assert all(r["kernel_ids"] == ref[0]["kernel_ids"] for r in ref)
+    assert ref[0]["calls"] == [1, 1, 1, 1]
+    auto = run_ranks(workers.name_exchange, world, mode="auto")[0]["calls"]
+    # SPMD bulk: digests only; private bulk: owners spell them out; mixed: the digests only ranks >= 1 hold
+    # need spelling when world > 2 (with two ranks rank 1 is the only one missing nothing but rank 0 is);
+    # a single late name travels as a string at once
+    assert auto[0] == 1 and auto[1] == 2 and auto[2] == 2 and auto[3] == 1, auto
+
+
+def test_name_digest_is_stable_and_collisions_raise(monkeypatch):
+    from nvrx_straggler import name_mapper
+
+    assert name_mapper.name_digest("kernel0") == 0xC5BDBC0080D9652  # BLAKE2b-64, little endian: same in every process
+    assert name_mapper.name_digest("a") != name_mapper.name_digest("b")
+    m = name_mapper.NameMapper()
+    monkeypatch.setattr(name_mapper, "name_digest", lambda name: 7)
+    m.sync_names(["x"], [])
+    with pytest.raises(RuntimeError, match="digest collision"):
+        m.sync_names(["y"], [])
+
+
 def test_detector_plumbing_two_gloo_ranks_sleep_sections():
     """BASELINE config #1: 2 CPU ranks, Detector wrapping 2 time.sleep sections, relative scores on
     rank 0; the slow rank's section is flagged at the default threshold."""

@@ -75,6 +75,44 @@ def gather_object_call_counts(rank, world, n_kernels):
     return counts
 
 
+def name_exchange(rank, world, mode):
+    """Cold-path name exchange (name_mapper.sync_names): ids, resolved names and all_gather_object call counts
+    for `mode` in {"strings", "auto", "digests"} over four syncs that cover SPMD bulk sets, a rank-private bulk
+    set, a mixed small/bulk sync and a single late name."""
+    import os
+
+    import torch
+
+    os.environ["NVRX_NAME_EXCHANGE"] = mode
+    from nvrx_straggler.name_mapper import NameMapper
+
+    long = "Cijk_Ailk_Bljk_" + "X" * 500
+    m = NameMapper()
+    calls = []
+
+    def sync(kernels, sections):
+        with mock.patch("torch.distributed.all_gather_object", wraps=torch.distributed.all_gather_object) as g:
+            m.sync_names(kernels, sections)
+            calls.append(g.call_count)
+
+    # 1: SPMD -- every rank holds the same 300 kernel keys (in a rank-dependent order) + rank-specific sections
+    common = [f"{long}_{i}_blk_256_1_1_grid_{i}_1_1" for i in range(300)]
+    mine = common[rank:] + common[:rank]
+    sync(mine, ["fwd", f"only_rank{rank}"])
+    # 2: every rank brings 40 private keys on top (nobody else can resolve their digests)
+    private = [f"private_r{rank}_{i}" for i in range(40)]
+    sync(mine + private, ["fwd", "bwd"])
+    # 3: mixed: rank 0 sends 3 strings, the others 50 digests of keys that overlap between the others only
+    if rank == 0:
+        sync(["late_a", "late_b", "shared_0"], ["fwd"])
+    else:
+        sync([f"shared_{i}" for i in range(50)], ["fwd"])
+    # 4: one late name on the last rank only (reference contract: one call)
+    sync(["only_last"] if rank == world - 1 else [], [])
+    return {"kernel_ids": dict(m.kernel_name_to_id), "section_ids": dict(m.section_name_to_id),
+            "id_to_kernel": dict(m.id_to_kernel_name), "calls": calls, "counter": m.kernel_counter}
+
+
 def detector_sleep_sections(rank, world, slow_rank, iters):
     """BASELINE config #1: Detector wrapping time.sleep sections on gloo ranks (plumbing, no GPU)."""
     from nvrx_straggler import Detector
