@@ -132,6 +132,11 @@ class StragglerDetectionCallback(Callback):
             self.logger.warning(
                 f"STRAGGLER DETECTION WARNING: Some GPUs performance dropped. Affected ranks: {indiv}"
             )
+        # MI355X extra: when the reporting rank itself is flagged, say what ROCm SMI sees on its GPU
+        # (clock below peak, hot junction, power) -- the first things to rule out for a slow GPU
+        me = getattr(straggler.Detector.reporter, "rank", None) if straggler.Detector.initialized else None
+        if me is not None and any(getattr(s, "rank", None) == me for s in list(rel) + list(indiv)):
+            self.logger.warning(f"rank {me}: {straggler.Detector.gpu_telemetry_line()}")
 
     @staticmethod
     def _format_gpu_scores(rank_to_score, rank_to_node, num_best=3, num_worst=3) -> str:

@@ -198,6 +198,26 @@ class Detector:
             cls.reporter.close()
         cls.initialized = False
 
+    # ---- system-side context (not in the reference) --------------------------------------------------
+    @classmethod
+    def gpu_telemetry(cls) -> dict:
+        """Clocks / temperatures / power / utilisation of this rank's GPU from ROCm SMI (``gpu_telemetry.sample``):
+        what to look at next to a low individual GPU score.  Raises if ROCm SMI is unavailable."""
+        from . import gpu_telemetry
+
+        return gpu_telemetry.sample(_backend_mod.get_backend().device.index)
+
+    @classmethod
+    def gpu_telemetry_line(cls) -> str:
+        """The same as one log line; never raises."""
+        from . import gpu_telemetry
+
+        try:
+            index = _backend_mod.get_backend().device.index
+        except Exception as e:  # noqa: BLE001
+            return f"gpu telemetry unavailable: {e}"
+        return gpu_telemetry.describe(index)
+
     # ---- summaries (host-visible form; the report path itself keeps them on the device) -------------
     @classmethod
     def _get_section_summaries(cls):

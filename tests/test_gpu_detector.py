@@ -166,3 +166,21 @@ def test_profiler_module_twin_of_reference_cupti_tests():
     mgr.reset_results()
     assert mgr.get_results() == {}
     mgr.shutdown()
+
+
+@pytest.mark.gpu
+def test_gpu_telemetry_reads_rocm_smi():
+    """ROCm SMI side of the profiling backend: clocks, temperatures and power of this rank's GPU."""
+    from nvrx_straggler import Detector, gpu_telemetry
+
+    assert gpu_telemetry.num_devices() >= 1
+    s = gpu_telemetry.sample(0)
+    assert 100.0 <= s["sclk_peak_mhz"] <= 4000.0 and 0.0 < s["sclk_frac"] <= 1.0, s
+    assert s["sclk_mhz"] <= s["sclk_peak_mhz"]
+    assert 500.0 <= s["mclk_peak_mhz"] <= 4000.0, s
+    temps = [v for k, v in s.items() if k.startswith("temp_")]
+    assert temps and all(5.0 < t < 120.0 for t in temps), s
+    if "power_w" in s:
+        assert 10.0 < s["power_w"] < 2000.0, s
+    line = Detector.gpu_telemetry_line()
+    assert line.startswith("gpu telemetry: sclk_mhz="), line

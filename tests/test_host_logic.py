@@ -93,6 +93,17 @@ def test_product_fails_loudly_without_gpu():
         Detector()
 
 
+@pytest.mark.skipif(torch.cuda.is_available(), reason="needs a box WITHOUT a GPU")
+def test_gpu_telemetry_degrades_to_a_message_without_a_gpu():
+    from nvrx_straggler import Detector, gpu_telemetry
+
+    line = gpu_telemetry.describe(0)
+    assert line.startswith("gpu telemetry unavailable")
+    assert Detector.gpu_telemetry_line().startswith("gpu telemetry unavailable")
+    with pytest.raises(RuntimeError):
+        gpu_telemetry.sample(0)
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(REPO, "nvidia-resiliency-ext_amd")
     for root, _, files in os.walk(pkg):
