@@ -56,7 +56,7 @@ def main():
     rows = list(csv.DictReader(open(stats_csv)))
     lines = [f"# rocprofv3 summary `{tag}`", "",
              "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20 "
-             f"--no-cpu-baseline` (N=1: {local_ranks} logical ranks x 64 sections x 10000 samples on one MI355X)", "",
+             f"--no-cpu-baseline --no-overhead` (N=1: {local_ranks} logical ranks x 64 sections x 10000 samples on one MI355X)", "",
              "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
     for r in rows:
         lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | "
