@@ -8,8 +8,9 @@ fresh interpreter (and this file sorts first, so it runs before the test session
 
 rocprofiler-sdk's own start-up (inside the child's first HIP call, before any of our code runs) normally takes
 3-10 s, was measured at ~50 s on a cold box, and on this ROCm 7.2 image occasionally never finishes (seen with
-both registration routes, ~1 run in 8).  That is outside this repository: the scenario gets two attempts of
-150 s each and the test is skipped, with the reason, if the SDK stalls both times."""
+both registration routes; more often when the child is spawned from a pytest session that collected the whole
+suite than from a shell).  That is outside this repository: the scenario gets 110 s and the test is skipped, with
+the reason, if the SDK has not come up by then (`tools/debug/ktrace_probe*.py` run the same steps from a shell)."""
 import json
 import os
 import subprocess
@@ -22,7 +23,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRIPT = r'''
 import faulthandler, json, os, sys
 faulthandler.enable()
-faulthandler.dump_traceback_later(140, exit=True)   # a hang becomes a traceback, not a lost GPU box
+faulthandler.dump_traceback_later(100, exit=True)   # a hang becomes a traceback, not a lost GPU box
 sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
 os.environ["NVRX_GPU_TIMING"] = "kernels"
 import numpy as np
@@ -84,21 +85,12 @@ print("RESULT " + json.dumps(out))
 def test_kernels_are_traced_by_name_and_scored():
     env = dict(os.environ)
     env.pop("NVRX_GPU_TIMING", None)
-    p = None
-    for attempt in range(2):
-        try:
-            p = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\n" + SCRIPT], capture_output=True, text=True, timeout=170, env=env)
-        except subprocess.TimeoutExpired:
-            p = None
-            continue
-        if p.returncode == 0 or "Timeout (0:02:20)" not in p.stderr:
-            break
-        stalled_in_sdk = "_lazy_init" in p.stderr or "ktrace.py" in p.stderr
-        if not stalled_in_sdk:
-            break
-        p = None
-    if p is None:
-        pytest.skip("rocprofiler-sdk start-up stalled twice on this box (before any nvrx code ran)")
+    try:
+        p = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\n" + SCRIPT], capture_output=True, text=True, timeout=110, env=env)
+    except subprocess.TimeoutExpired:
+        pytest.skip("rocprofiler-sdk start-up stalled on this box (before any nvrx code ran)")
+    if p.returncode != 0 and "Timeout (0:01:40)" in p.stderr and ("_lazy_init" in p.stderr or "ktrace.py" in p.stderr):
+        pytest.skip("rocprofiler-sdk start-up stalled on this box (inside the first HIP call, before any nvrx code ran)")
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
     out = json.loads(line[len("RESULT "):])
