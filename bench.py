@@ -22,6 +22,9 @@ Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
   per_step_overhead -- BASELINE.json's second figure (config #4): the real Detector around a fixed
                   bf16 matmul workload with a hipEvent pair per entry and a collective report EVERY
                   step; % = (t_with - t_without) / t_without, A/B blocks alternating in one process.
+  host_inputs  -- the PCIe-inclusive figure (never `value`): the same report when the 8 x 64 x 10 000 samples start in
+                  pageable HOST memory and are handed over per logical rank ([64, 10000] f32 arrays -> one H2D copy +
+                  64 device-to-device ring appends each) before the report runs; N=1 only, a few repetitions.
   cpu_baseline -- the reference's CPU path restated in Python (oracle/, kind "port"), timed on this
                   host: one rank's 64 x 10000 samples from Python deques -> torch.tensor + 5 torch
                   reductions per section, + dict scoring; 1 core.
@@ -178,6 +181,7 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overhead", action="store_true", help="skip the per-step overhead leg (config #4)")
+    ap.add_argument("--no-host-inputs", action="store_true", help="skip the PCIe-inclusive leg (samples handed over from host memory)")
     ap.add_argument("--overhead-steps", type=int, default=100)
     ap.add_argument("--overhead-blocks", type=int, default=5)
     args = ap.parse_args()
@@ -239,6 +243,23 @@ def main():
     kern_total_us, kern_launches = job.rings.timing_read(reset=True)
     job.rings.timing_enable(False)
 
+    host_inputs = None
+    if world == 1 and not args.no_host_inputs:
+        host = [synth.stress_samples(r, SECTIONS, SAMPLES, slow_rank=3, slow_factor=1.5) for r in job.logical_ranks()]
+        t_host = []
+        for _ in range(6):
+            job.rings.reset()
+            sync_all()
+            t0 = time.perf_counter()
+            for lr in range(job.local_ranks):
+                job.load(lr, host[lr])
+            job.report()
+            t_host.append(time.perf_counter() - t0)
+        nbytes = job.local_ranks * SECTIONS * SAMPLES * 4
+        us = float(np.median(t_host[1:])) * 1e6
+        host_inputs = {"us_per_report": round(us, 1), "host_bytes": nbytes, "gb_per_s": round(nbytes / us / 1e3, 2),
+                       "note": "samples start in pageable host memory; H2D + ring appends + report; not the headline value"}
+
     overhead = None
     if not args.no_overhead:
         job.backend.synchronize()
@@ -292,6 +313,8 @@ def main():
         }
         if overhead is not None:
             out["per_step_overhead"] = overhead
+        if host_inputs is not None:
+            out["host_inputs"] = host_inputs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = _cpu_baseline(args.cpu_reps)
         print(json.dumps(out), flush=True)
