@@ -115,7 +115,18 @@ class NameMapper:
         new_sections = [n for n in section_names if n not in self.section_name_to_id]
         new_kernels = [n for n in kernel_names if n not in self.kernel_name_to_id]
         mode = os.environ.get("NVRX_NAME_EXCHANGE", "auto")
-        as_digests = mode == "digests" or (mode != "strings" and len(new_kernels) >= BULK_NAMES)
+        if mode == "strings":
+            # the reference's exchange, verbatim (no digest is ever computed: the escape hatch for a digest collision);
+            # the variable must be set on every rank
+            gathered = all_gather_object((new_sections, new_kernels), self.group)
+            for sections, _ in gathered:
+                for name in sections:
+                    self._assign_section_id(name)
+            for _, kernels in gathered:
+                for name in kernels:
+                    self._assign_kernel_id(name)
+            return
+        as_digests = mode == "digests" or len(new_kernels) >= BULK_NAMES
         my_digests = [self._remember_digest(n) for n in new_kernels]
         if as_digests:
             payload = ("d", np.asarray(my_digests, dtype=np.uint64).tobytes())
