@@ -25,9 +25,10 @@ Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
   host_inputs  -- the PCIe-inclusive figure (never `value`): the same report when the 8 x 64 x 10 000 samples start in
                   pageable HOST memory and are handed over per logical rank ([64, 10000] f32 arrays -> one H2D copy +
                   64 device-to-device ring appends each) before the report runs; N=1 only, a few repetitions.
-  cpu_baseline -- the reference's CPU path restated in Python (oracle/, kind "port"), timed on this
-                  host: one rank's 64 x 10000 samples from Python deques -> torch.tensor + 5 torch
-                  reductions per section, + dict scoring; 1 core.
+  cpu_baseline -- the reference's CPU path restated in Python (oracle/, kind "port"), timed on this host: the whole job
+                  as 8 gloo processes (one per rank, 8 cores): per report torch.tensor(deque) + 5 torch reductions per
+                  section, the flag / MIN all-reduces, scores, gather to rank 0; the all_gather_object of the summary
+                  dicts is timed next to it; the single-rank, no-collective figure is kept as a sub-object.
 """
 import argparse
 import json
@@ -83,7 +84,7 @@ def _cpu_baseline(reps: int):
     t_c = (time.perf_counter() - t0) / 5
     summaries_us = float(np.median(t_sum)) * 1e6
     scoring_us = float(np.median(t_sc)) * 1e6 / TOTAL_RANKS
-    return {
+    single = {
         "value": round(summaries_us + scoring_us, 1),
         "unit": "us",
         "cores": 1,
@@ -94,6 +95,31 @@ def _cpu_baseline(reps: int):
         "summaries_us": round(summaries_us, 1),
         "scoring_us_per_rank": round(scoring_us, 1),
         "c_oracle_stats_us": round(t_c * 1e6, 1),
+        "host_cpus": os.cpu_count(),
+    }
+    # the whole job on the host cores: 8 processes (one per rank, one torch thread each) on gloo, doing what the
+    # reference does per report -- summaries, flag + MIN all-reduce, scores, gather to rank 0 -- and, timed separately,
+    # the all_gather_object of the summary dicts that BASELINE.json's wording names
+    try:
+        from oracle import port_mp
+
+        mp_reps = max(5, min(20, reps // 3))
+        r = port_mp.run(world=TOTAL_RANKS, sections=SECTIONS, samples=SAMPLES, reps=mp_reps)
+    except Exception as e:  # noqa: BLE001  (the single-rank figure still stands)
+        single["gloo_job_error"] = str(e)[-300:]
+        return single
+    return {
+        "value": round(r["report_us"], 1),
+        "unit": "us",
+        "cores": TOTAL_RANKS,
+        "kind": "port",
+        "sample": f"{TOTAL_RANKS} gloo ranks (one process and one torch thread each) x {SECTIONS} sections x {SAMPLES} samples from "
+                  f"Python deques: per report torch.tensor + 5 torch reductions per section, flag + MIN all-reduce, scores, "
+                  f"gather to rank 0; max over ranks of the per-rank median of {mp_reps} reports",
+        "summaries_us": round(r["summaries_us"], 1),
+        "exchange_scoring_us": round(r["exchange_scoring_us"], 1),
+        "all_gather_object_of_summaries_us": round(r["all_gather_object_us"], 1),
+        "single_rank_no_collectives": single,
         "host_cpus": os.cpu_count(),
     }
 

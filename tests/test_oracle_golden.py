@@ -214,3 +214,14 @@ def test_stress_golden_vs_oracle():
             flagged_ind = {n: sorted(int(r) for r in range(W) if out[r, 2 + j] < float(thr)) for n, j in sid.items()}
             flagged_ind = {n: v for n, v in flagged_ind.items() if v}
             assert flagged_ind == exp["stragglers"][thr]["straggler_sections_individual"], (var["name"], thr)
+
+
+def test_port_job_on_gloo_ranks_runs_and_reports_times():
+    """The bench's CPU baseline with real collectives (oracle/port_mp.py): two gloo ranks, tiny shape."""
+    from oracle import port_mp
+
+    r = port_mp.run(world=2, sections=4, samples=200, reps=3, timeout=120)
+    assert r["ranks"] == 2 and r["reps"] == 3
+    for k in ("summaries_us", "exchange_scoring_us", "all_gather_object_us", "report_us"):
+        assert r[k] > 0.0
+    assert r["report_us"] >= 0.5 * (r["summaries_us"] + r["exchange_scoring_us"])
