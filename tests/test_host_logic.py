@@ -61,6 +61,81 @@ def test_ktrace_library_exports_every_symbol_in_its_header():
     assert ctypes.sizeof(ktrace.Record) == 8 and ktrace.RECORD_DTYPE.itemsize == 8
 
 
+def test_kernel_trace_profiler_host_logic_with_a_fake_tracer(monkeypatch):
+    """KernelTraceProfiler.harvest / get_stats / reset on CPU: drained (key, us) records are appended to one ring
+    row per kernel key in launch order, statistics follow computeStats (mean-of-middles median, population
+    stddev), a full ring table drops further keys with a warning instead of failing the report."""
+    import ctypes
+
+    from nvrx_straggler import backend, ktrace
+    from oracle_backend import OracleBackend
+
+    class FakeLib:
+        def __init__(self):
+            self.started = 0
+            self.resets = 0
+
+        def nvrx_ktrace_ready(self):
+            return 1
+
+        def nvrx_ktrace_start(self):
+            self.started += 1
+            return 0
+
+        def nvrx_ktrace_stop(self):
+            self.started -= 1
+            return 0
+
+        def nvrx_ktrace_reset(self):
+            self.resets += 1
+            return 0
+
+        def nvrx_ktrace_dropped(self):
+            return 0
+
+    fake = FakeLib()
+    names = {0: "gemm_blk_256_1_1_grid_64_1_1", 1: "relu_blk_256_1_1_grid_1024_1_1", 2: "ncclDevKernel_blk_1_1_1_grid_1_1_1",
+             3: "late_blk_1_1_1_grid_1_1_1"}
+    recs = np.array([(0, 10.0), (1, 2.0), (0, 30.0), (2, 99.0), (1, 4.0), (0, 20.0), (0, 40.0)], dtype=ktrace.RECORD_DTYPE)
+    queue = [recs]
+    monkeypatch.setattr(ktrace, "load", lambda: fake)
+    monkeypatch.setattr(ktrace, "drain_all", lambda: queue.pop(0) if queue else np.empty(0, dtype=ktrace.RECORD_DTYPE))
+    monkeypatch.setattr(ktrace, "key_name", lambda k: names[int(k)])
+    monkeypatch.setattr(ktrace, "_setup_error", None)
+    monkeypatch.setattr(ktrace.KernelTraceProfiler, "_live", None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)  # harvest(wait=True) on a box without a GPU
+    backend.set_backend(OracleBackend())
+    try:
+        rings = backend.get_backend().make_rings(1, 3, 16)
+        prof = ktrace.KernelTraceProfiler(statsMaxLenPerKernel=16, rings=rings)
+        with pytest.raises(RuntimeError, match="Only one"):
+            ktrace.KernelTraceProfiler(rings=rings)
+        prof.initialize()
+        prof.start("ignored")
+        prof.start("ignored")  # "subsequent call": no second enable
+        assert fake.started == 1
+        assert prof.stop(5, 1.0) is False and fake.started == 0
+        assert prof.stop() is False
+        stats = prof.get_stats()  # harvest(wait=True) needs no device with the fake
+        assert set(stats) == {names[0], names[1], names[2]}
+        g = stats[names[0]]
+        assert (g.num_calls, g.min, g.max, g.median, g.avg) == (4, 10.0, 40.0, 25.0, 25.0)  # mean of the two middles
+        assert abs(g.stddev - np.std([10, 30, 20, 40])) < 1e-5                            # population
+        assert stats[names[1]].median == 3.0 and stats[names[1]].num_calls == 2
+        # the rings are full (3 rows): a fourth key is dropped with one warning, the others keep recording
+        queue.append(np.array([(3, 1.0), (0, 50.0)], dtype=ktrace.RECORD_DTYPE))
+        with pytest.warns(UserWarning, match="rings are full"):
+            prof.harvest(wait=False)
+        assert prof.keys_without_row == 1
+        assert prof.get_stats()[names[0]].num_calls == 5
+        prof.reset()
+        assert fake.resets == 1 and prof.get_stats() == {}
+        prof.shutdown()
+        prof.close()
+    finally:
+        backend.set_backend(None)
+
+
 def test_abi_argument_validation_without_a_gpu():
     """Pure argument checks return -EINVAL before any HIP call."""
     from nvrx_straggler import _native
