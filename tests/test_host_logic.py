@@ -136,6 +136,65 @@ def test_kernel_trace_profiler_host_logic_with_a_fake_tracer(monkeypatch):
         backend.set_backend(None)
 
 
+def test_detection_section_api_contract():
+    """Twin of the reference's tests/straggler/unit/test_det_section_api.py on the injected CPU backend: a name
+    reused at another location is accepted (the reference ships with that check switched off, straggler.py:317-321;
+    the checker itself is kept), default names are file:line of the `with` statement, profiling_interval
+    keeps every n-th entry, profile_cuda=False records no GPU row, an entry that raises records no sample, and
+    reports over empty rings do not crash."""
+    import inspect
+
+    from nvrx_straggler import Detector, Statistic, backend
+    from oracle_backend import OracleBackend
+
+    with pytest.raises(RuntimeError, match="Detector is not initialized."):
+        with Detector.detection_section("section00"):
+            pass
+    backend.set_backend(OracleBackend())
+    try:
+        Detector.initialize(scores_to_compute="all", gather_on_rank0=False, profiling_interval=2, node_name="n0")
+        with pytest.raises(AssertionError):
+            Detector.initialize()
+        with Detector.detection_section("section00", profile_cuda=False):
+            pass
+        with Detector.detection_section("section00", profile_cuda=False):  # same name, another line: same section
+            pass
+        assert Detector.custom_sections["section00"].total_entry_cnt == 2
+        with pytest.raises(ValueError, match="already used"):
+            Detector._ensure_section_name_is_valid("section00", "elsewhere.py:1")
+        for _ in range(2):
+            with Detector.detection_section(profile_cuda=False):  # default name: this line, both times
+                pass
+        frame = inspect.getframeinfo(inspect.currentframe())
+        with Detector.detection_section(profile_cuda=False):
+            pass
+        defaults = [s for n, s in Detector.custom_sections.items() if n != "section00"]
+        assert len(defaults) == 2 and defaults[0].name != defaults[1].name
+        assert defaults[0].location.endswith(f"{frame.filename}:{frame.lineno - 2}") and defaults[0].name == defaults[0].location
+        assert defaults[1].location.endswith(f"{frame.filename}:{frame.lineno + 1}")
+        # periodic capture: 2 of 4 entries; an entry that raises is not recorded
+        for i in range(4):
+            with Detector.detection_section("one", profile_cuda=False):
+                pass
+        with pytest.raises(KeyError):
+            with Detector.detection_section("boom", profile_cuda=False):
+                raise KeyError("x")
+        assert Detector.custom_sections["boom"].total_entry_cnt == 1 and len(Detector.custom_sections["boom"].cpu_elapsed_times) == 0
+        rep = Detector.generate_report()
+        assert rep.local_section_summaries["one"][Statistic.NUM] == 2
+        assert "boom" not in rep.local_section_summaries
+        assert len(rep.local_kernel_summaries) == 0  # profile_cuda=False everywhere
+        assert all(len(s.cpu_elapsed_times) == 0 for s in Detector.custom_sections.values())  # report emptied the rings
+        rep2 = Detector.generate_report()  # nothing recorded since: must not crash
+        assert rep2 is not None and len(rep2.local_section_summaries) == 0
+        with pytest.raises(RuntimeError, match="should not be instantiated"):
+            Detector()
+    finally:
+        if Detector.initialized:
+            Detector.shutdown()
+        backend.set_backend(None)
+
+
 def test_abi_argument_validation_without_a_gpu():
     """Pure argument checks return -EINVAL before any HIP call."""
     from nvrx_straggler import _native
