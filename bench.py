@@ -206,6 +206,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-reps", type=int, default=60)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo lets the N > 1 flow "
+                    "be exercised with several ranks sharing one GPU)")
     ap.add_argument("--no-overhead", action="store_true", help="skip the per-step overhead leg (config #4)")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the PCIe-inclusive leg (samples handed over from host memory)")
     ap.add_argument("--overhead-steps", type=int, default=100)
@@ -220,9 +222,13 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if TOTAL_RANKS % world:
         raise SystemExit(f"--gpus must divide {TOTAL_RANKS}")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % max(torch.cuda.device_count(), 1)  # == local_rank on a node with one GPU per rank
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(args.backend)
 
     import synth
     from nvrx_straggler.folded import FoldedJob
@@ -269,6 +275,26 @@ def main():
     kern_total_us, kern_launches = job.rings.timing_read(reset=True)
     job.rings.timing_enable(False)
 
+    # the report's one collective on its own (N > 1): enqueue on the detector's stream, wait for that stream
+    exchange = None
+    if world > 1:
+        try:
+            ws = job.reporter._ring_plan.ws
+            for _ in range(10):
+                job.reporter._exchange(job.backend, ws)
+            job.backend.synchronize()
+            t_ex = []
+            for _ in range(100):
+                t0 = time.perf_counter()
+                job.reporter._exchange(job.backend, ws)
+                job.backend.synchronize()
+                t_ex.append(time.perf_counter() - t0)
+            exchange = {"us_median": float(np.median(t_ex)) * 1e6,
+                        "route": "ncclAllGather on the detector's stream" if job.reporter._direct is not None else "torch.distributed",
+                        "bytes_per_rank": int(ws.local_ranks * ws.L * 4)}
+        except Exception as e:  # noqa: BLE001  (deterministic on every rank: same state everywhere)
+            exchange = {"error": str(e)[-200:]}
+
     host_inputs = None
     if world == 1 and not args.no_host_inputs:
         host = [synth.stress_samples(r, SECTIONS, SAMPLES, slow_rank=3, slow_factor=1.5) for r in job.logical_ranks()]
@@ -291,10 +317,11 @@ def main():
         job.backend.synchronize()
         overhead = _per_step_overhead(world, rank, args.overhead_steps, args.overhead_blocks)
 
-    times = torch.tensor([elapsed, elapsed_instr], dtype=torch.float64, device="cuda")
+    ex_us = exchange.get("us_median", 0.0) if exchange else 0.0
+    times = torch.tensor([elapsed, elapsed_instr, ex_us], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    elapsed, elapsed_instr = times.tolist()
+    elapsed, elapsed_instr, ex_us = times.tolist()
 
     if rank == 0:
         us_per_report = elapsed / args.steps * 1e6
@@ -319,7 +346,7 @@ def main():
                             "relative+individual scores, gather_on_rank0",
                 "logical_ranks_per_gpu": job.local_ranks,
                 "rows_per_gpu": job.local_ranks * SECTIONS,
-                "exchange": "none (single process)" if world == 1 else f"1 all_gather_into_tensor of {job.local_ranks}x{2 * SECTIONS + 1} f32 per rank (RCCL)",
+                "exchange": "none (single process)" if world == 1 else f"1 all-gather of {job.local_ranks}x{2 * SECTIONS + 1} f32 per rank ({'RCCL' if args.backend == 'nccl' else args.backend})",
                 "target_us": 50,
             },
             "reports_per_s": round(1e6 / us_per_report, 1),
@@ -341,6 +368,12 @@ def main():
             out["per_step_overhead"] = overhead
         if host_inputs is not None:
             out["host_inputs"] = host_inputs
+        if exchange is not None:
+            # latency-bound: 516 B x local ranks per rank over xGMI is far below a microsecond of wire time, so this
+            # is RCCL's small-message launch + completion latency, not a bandwidth figure
+            exchange["us_median"] = round(ex_us, 2) if "us_median" in exchange else None
+            exchange["note"] = "enqueue + stream wait of one all-gather of the exchange rows, max over ranks; latency-bound"
+            out["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = _cpu_baseline(args.cpu_reps)
         print(json.dumps(out), flush=True)
