@@ -23,7 +23,6 @@ from __future__ import annotations
 import collections
 import dataclasses
 import time
-from collections.abc import Mapping as _MappingABC
 from typing import Any, Dict, Iterator, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -47,124 +46,54 @@ class StragglerId:
 
 
 # --------------------------------------------------------------------------------------------------
-# lazy views over the score arrays
+# Report: a frozen record of plain dicts, some of them built on first read
 # --------------------------------------------------------------------------------------------------
-def _resolve(x):
-    """Arrays may be handed to the views as zero-argument callables and are materialised on first use."""
-    return x() if callable(x) else x
+def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray) -> Dict[str, Dict[Statistic, Any]]:
+    """``name -> {Statistic: value}`` from device statistics rows (``_get_section_summaries``' result shape,
+    straggler.py:185-195)."""
+    out: Dict[str, Dict[Statistic, Any]] = {}
+    for name, row in rows.items():
+        vals = stats[row].tolist()
+        d: Dict[Statistic, Any] = {stat: vals[col] for stat, col in STAT_COLUMNS}
+        d[Statistic.NUM] = int(vals[5])
+        out[name] = d
+    return out
 
 
-class RankScores(_MappingABC):
-    """``rank -> score`` view over one column of the score array."""
+class _ScoreSource:
+    """What a steady-state report keeps of the result block: a private copy of the score / statistics
+    arrays plus the (shared, immutable) name tables of the plan.  The six mapping fields of ``Report`` are
+    built from it as PLAIN dicts the first time each one is read; a report whose scores are only
+    thresholded (``identify_stragglers`` with the kernel's thresholds) never builds any."""
 
-    __slots__ = ("_ranks", "_src")
+    __slots__ = ("scores", "stats", "S", "ranks", "names", "cols", "has_rel", "has_indiv", "section_rows", "kernel_rows")
 
-    def __init__(self, ranks: Sequence[int], values):
-        self._ranks = ranks
-        self._src = values  # ndarray, or callable returning it
+    def build(self, field: str):
+        S = self.S
+        if field == "gpu_relative_perf_scores":
+            return dict(zip(self.ranks, self.scores[:, 1].tolist())) if self.has_rel else {}
+        if field == "gpu_individual_perf_scores":
+            return dict(zip(self.ranks, self.scores[:, 0].tolist())) if self.has_indiv else {}
+        if field == "section_relative_perf_scores":
+            return self._sections(2 + S) if (self.has_rel and self.names) else {}
+        if field == "section_individual_perf_scores":
+            return self._sections(2) if (self.has_indiv and self.names) else {}
+        if field == "local_section_summaries":
+            return _summaries_from_rows(self.section_rows, self.stats)
+        if field == "local_kernel_summaries":
+            return _summaries_from_rows(self.kernel_rows, self.stats)
+        raise AttributeError(field)
 
-    @property
-    def _values(self) -> np.ndarray:
-        v = self._src
-        if callable(v):
-            v = self._src = v()
-        return v
-
-    def __getitem__(self, rank: int) -> float:
-        try:
-            return float(self._values[self._ranks.index(rank)])
-        except ValueError:
-            raise KeyError(rank) from None
-
-    def __iter__(self) -> Iterator[int]:
-        return iter(self._ranks)
-
-    def __len__(self) -> int:
-        return len(self._ranks)
-
-    def __repr__(self) -> str:
-        return repr(dict(self.items()))
-
-    def __reduce__(self):
-        return (dict, (dict(self.items()),))
-
-    def below(self, threshold: float) -> List[int]:
-        """Ranks whose score is strictly below ``threshold`` (NaN never qualifies)."""
-        with np.errstate(invalid="ignore"):
-            hit = np.nonzero(self._values.astype(np.float64) < threshold)[0]
-        return [self._ranks[int(i)] for i in hit]
+    def _sections(self, first_col: int) -> Dict[str, Dict[int, float]]:
+        ranks, cols = self.ranks, self.cols
+        by_col = self.scores[:, first_col : first_col + self.S].T.tolist()  # one C-level conversion
+        return {name: dict(zip(ranks, by_col[cols[name]])) for name in self.names}
 
 
-class SectionScores(_MappingABC):
-    """``section name -> (rank -> score)`` view over a [ranks, sections] block of the score array."""
-
-    __slots__ = ("_names", "_cols", "_ranks", "_src")
-
-    def __init__(self, names: Sequence[str], cols, ranks: Sequence[int], block):
-        self._names = names
-        self._cols = cols if isinstance(cols, dict) else {n: c for n, c in zip(names, cols)}
-        self._ranks = ranks
-        self._src = block  # ndarray [ranks, S], or callable returning it
-
-    @property
-    def _block(self) -> np.ndarray:
-        b = self._src
-        if callable(b):
-            b = self._src = b()
-        return b
-
-    def __getitem__(self, name: str) -> RankScores:
-        return RankScores(self._ranks, self._block[:, self._cols[name]])
-
-    def __iter__(self) -> Iterator[str]:
-        return iter(self._names)
-
-    def __len__(self) -> int:
-        return len(self._names)
-
-    def __repr__(self) -> str:
-        return repr({k: dict(v.items()) for k, v in self.items()})
-
-    def __reduce__(self):
-        return (dict, ({k: dict(v.items()) for k, v in self.items()},))
-
-
-class StatSummaries(_MappingABC):
-    """``name -> {Statistic: value}`` built from device statistics rows on first access."""
-
-    __slots__ = ("_rows", "_src", "_cache")
-
-    def __init__(self, rows: Mapping[str, int], stats):
-        self._rows = rows  # name -> row index, only rows that hold samples (treated as immutable)
-        self._src = stats  # ndarray [rows, 8], or callable returning it
-        self._cache: Optional[Dict[str, Dict[Statistic, Any]]] = None
-
-    def _materialise(self) -> Dict[str, Dict[Statistic, Any]]:
-        if self._cache is None:
-            stats = _resolve(self._src)
-            out = {}
-            for name, row in self._rows.items():
-                vals = stats[row]
-                d = {stat: float(vals[col]) for stat, col in STAT_COLUMNS}
-                d[Statistic.NUM] = int(vals[5])
-                out[name] = d
-            self._cache = out
-        return self._cache
-
-    def __getitem__(self, name: str):
-        return self._materialise()[name]
-
-    def __iter__(self):
-        return iter(self._rows)
-
-    def __len__(self) -> int:
-        return len(self._rows)
-
-    def __repr__(self) -> str:
-        return repr(self._materialise())
-
-    def __reduce__(self):
-        return (dict, (self._materialise(),))
+_LAZY_FIELDS = frozenset((
+    "gpu_relative_perf_scores", "section_relative_perf_scores", "gpu_individual_perf_scores",
+    "section_individual_perf_scores", "local_section_summaries", "local_kernel_summaries",
+))
 
 
 @dataclasses.dataclass(frozen=True)
@@ -185,6 +114,11 @@ class Report:
     score; ``gpu_individual_perf_scores``; ``section_individual_perf_scores``; ``rank_to_node``;
     ``local_section_summaries`` / ``local_kernel_summaries`` this rank's timing statistics;
     ``generate_report_elapsed_time`` [ms]; ``gather_on_rank0``; ``rank``.
+
+    Every mapping is a plain ``dict`` (of plain dicts / floats), as in the reference, so reports can be
+    pickled, sent through ``multiprocessing`` queues, deep-copied and ``json.dumps``-ed.  Reports that come
+    straight from the device build each mapping on first read (``_from_device``); nothing about that is
+    visible from outside except that an unread mapping costs nothing.
     """
 
     gpu_relative_perf_scores: Mapping[int, float]
@@ -198,13 +132,50 @@ class Report:
     gather_on_rank0: bool
     rank: Optional[int]
 
+    # ---- construction from the device result block -------------------------------------------------
+    @classmethod
+    def _from_device(cls, source: _ScoreSource, rank_to_node, elapsed_ms: float, gather_on_rank0: bool,
+                     rank: Optional[int], device_flags: "Optional[_DeviceFlags]") -> "Report":
+        self = object.__new__(cls)
+        d = self.__dict__
+        d["rank_to_node"] = rank_to_node
+        d["generate_report_elapsed_time"] = elapsed_ms
+        d["gather_on_rank0"] = gather_on_rank0
+        d["rank"] = rank
+        d["_src"] = source
+        d["_device_flags"] = device_flags
+        return self
+
+    def __getattr__(self, name: str):
+        # reached only when normal lookup fails, i.e. for a mapping field that has not been built yet
+        if name in _LAZY_FIELDS:
+            src = self.__dict__.get("_src")
+            if src is not None:
+                value = self.__dict__[name] = src.build(name)
+                return value
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
+
+    def _materialise(self) -> None:
+        for name in _LAZY_FIELDS:
+            getattr(self, name)
+
+    def __getstate__(self):
+        """Plain fields only (every mapping built): what pickle / copy / multiprocessing queues carry."""
+        self._materialise()
+        state = {f.name: self.__dict__[f.name] for f in dataclasses.fields(self)}
+        flags = self.__dict__.get("_device_flags")
+        if flags is not None:
+            state["_device_flags"] = flags
+        return state
+
+    def __setstate__(self, state) -> None:
+        self.__dict__.update(state)
+
     def _ids(self, ranks) -> set:
         return {StragglerId(rank=r, node=self.rank_to_node[r]) for r in ranks}
 
     @staticmethod
     def _below(scores: Mapping[int, float], threshold: float):
-        if isinstance(scores, RankScores):
-            return scores.below(threshold)
         return [r for r, s in scores.items() if s < threshold]
 
     def identify_stragglers(
@@ -220,7 +191,7 @@ class Report:
         'straggler_sections_relative': {section: set}, 'straggler_sections_individual': {section:
         set}}``; a section appears only if at least one rank is flagged for it.
         """
-        flags = getattr(self, "_device_flags", None)
+        flags = self.__dict__.get("_device_flags")
         if flags is not None and flags.matches(
             gpu_rel_threshold, section_rel_threshold, gpu_indiv_threshold, section_indiv_threshold
         ):
@@ -240,17 +211,27 @@ class Report:
 
 
 class _DeviceFlags:
-    """Below-threshold bytes written by the score kernel, with the thresholds they were computed for."""
+    """Below-threshold bytes written by the score kernel, with the thresholds they were computed for.
+    Holds a private ndarray (never a view of the live result block, never a callable): picklable."""
+
+    __slots__ = ("thresholds", "flags", "ranks", "names", "cols", "S", "has_rel", "has_indiv")
 
     def __init__(self, thresholds, flags: np.ndarray, ranks, names, cols, S, has_rel, has_indiv):
-        self.thresholds = thresholds  # (gpu_rel, sec_rel, gpu_indiv, sec_indiv) as floats
-        self._flags = flags  # ndarray [ranks, 2+2S] u8, or callable returning it
+        self.thresholds = tuple(float(t) for t in thresholds)  # (gpu_rel, sec_rel, gpu_indiv, sec_indiv)
+        self.flags = flags  # ndarray [ranks, 2+2S] u8
         self.ranks = ranks
         self.names = names
         self.cols = cols if isinstance(cols, dict) else dict(zip(names, cols))
         self.S = S
         self.has_rel = has_rel
         self.has_indiv = has_indiv
+
+    def __getstate__(self):
+        return {k: getattr(self, k) for k in self.__slots__}
+
+    def __setstate__(self, state) -> None:
+        for k, v in state.items():
+            setattr(self, k, v)
 
     def matches(self, gpu_rel, sec_rel, gpu_indiv, sec_indiv) -> bool:
         return (float(gpu_rel), float(sec_rel), float(gpu_indiv), float(sec_indiv)) == self.thresholds
@@ -259,9 +240,11 @@ class _DeviceFlags:
         return [self.ranks[int(i)] for i in np.nonzero(column)[0]]
 
     def decode(self):
-        f, S = _resolve(self._flags), self.S
+        f, S = self.flags, self.S
         gi = self._ranks_of(f[:, 0]) if self.has_indiv else []
         gr = self._ranks_of(f[:, 1]) if self.has_rel else []
+        if not f[:, 2:].any():  # the common case: no section of any rank is flagged
+            return gr, gi, {}, {}
         cols = self.cols
         si = {n: self._ranks_of(f[:, 2 + cols[n]]) for n in self.names} if self.has_indiv else {}
         sr = {n: self._ranks_of(f[:, 2 + S + cols[n]]) for n in self.names} if self.has_rel else {}
@@ -401,45 +384,38 @@ class ReportGenerator:
 
     # ---- report assembly --------------------------------------------------------------------------
     def _assemble(self, ws, mapper, local_section_names: Sequence[str], section_summaries, kernel_summaries,
-                  t_start_ns: int, local_ranks: int = 1):
+                  t_start_ns: int, local_ranks: int = 1, stats: Optional[np.ndarray] = None):
+        """Report of the general (name-syncing / dict-input) path.  ``section_summaries`` / ``kernel_summaries``
+        are either the caller's dicts (handed on as they are, reporting.py:541-542) or name -> ring row
+        tables to be resolved against ``stats``."""
         S = ws.S
-        scores = ws.scores.copy()
-        flags = ws.flags.copy()
-        has_rel, has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
-        empty: Dict = {}
         if self.gather_on_rank0:
             if self.rank != 0:
                 return None
+            lo, hi = 0, ws.R
             ranks = range(ws.R)
             names = [mapper.get_section_name(i) for i in range(S)]
             cols = {n: i for i, n in enumerate(names)}
         else:
-            me = self.rank * local_ranks if self._exchanged() else 0
-            scores = scores[me : me + local_ranks]
-            flags = flags[me : me + local_ranks]
+            lo = self.rank * local_ranks if self._exchanged() else 0
+            hi = lo + local_ranks
             ranks = range(self.rank * local_ranks, (self.rank + 1) * local_ranks)
             names = list(local_section_names)
             cols = {n: mapper.get_section_id(n) for n in names}
-        gpu_i = RankScores(ranks, scores[:, 0]) if has_indiv else empty
-        gpu_r = RankScores(ranks, scores[:, 1]) if has_rel else empty
-        sec_i = SectionScores(names, cols, ranks, scores[:, 2 : 2 + S]) if (has_indiv and names) else empty
-        sec_r = SectionScores(names, cols, ranks, scores[:, 2 + S : 2 + 2 * S]) if (has_rel and names) else empty
-        elapsed_ms = (time.perf_counter_ns() - t_start_ns) * 1e-6
-        report = Report(
-            gpu_relative_perf_scores=gpu_r,
-            section_relative_perf_scores=sec_r,
-            gpu_individual_perf_scores=gpu_i,
-            section_individual_perf_scores=sec_i,
-            rank_to_node=dict(self.rank_to_node),
-            local_section_summaries=section_summaries,
-            local_kernel_summaries=kernel_summaries,
-            generate_report_elapsed_time=elapsed_ms,
-            gather_on_rank0=self.gather_on_rank0,
-            rank=self.rank,
-        )
-        object.__setattr__(
-            report, "_device_flags", _DeviceFlags(self.thresholds, flags, ranks, names, cols, S, has_rel, has_indiv)
-        )
+        src = _ScoreSource()
+        src.scores = ws.scores[lo:hi].copy()
+        src.S, src.ranks, src.names, src.cols = S, ranks, names, cols
+        src.has_rel, src.has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
+        src.stats = stats
+        src.section_rows = section_summaries if stats is not None else None
+        src.kernel_rows = kernel_summaries if stats is not None else None
+        flags = _DeviceFlags(self.thresholds, ws.flags[lo:hi].copy(), ranks, names, cols, S, src.has_rel, src.has_indiv)
+        report = Report._from_device(src, dict(self.rank_to_node), (time.perf_counter_ns() - t_start_ns) * 1e-6,
+                                     self.gather_on_rank0, self.rank, flags)
+        if stats is None:
+            # the caller's own summaries travel with the report, untouched
+            report.__dict__["local_section_summaries"] = section_summaries
+            report.__dict__["local_kernel_summaries"] = kernel_summaries
         return report
 
     # ---- steady-state plan of the ring path ---------------------------------------------------------
@@ -511,44 +487,20 @@ class ReportGenerator:
         if self.gather_on_rank0 and self.rank != 0:
             return None
         S, W, R = ws.S, ws.W, ws.R
-        blob = ws.host_block()  # one memcpy out of the pinned block; everything below views into it
+        blob = ws.host_block()  # one memcpy out of the pinned block; everything below views into the copy
         lo, hi = plan.row_lo, plan.row_hi
         off_s, off_f, off_t = ws._off_scores, ws._off_flags, ws._off_stats
-        cache = {}
-
-        def scores():
-            a = cache.get("s")
-            if a is None:
-                a = cache["s"] = blob[off_s : off_s + R * W * 4].view(np.float32).reshape(R, W)[lo:hi]
-            return a
-
-        def flags():
-            return blob[off_f : off_f + R * W].reshape(R, W)[lo:hi]
-
-        def stats():
-            return blob[off_t : off_t + plan.stats_needed * 32].view(np.float32).reshape(plan.stats_needed, 8)
-
-        has_rel, has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
-        ranks, names, cols = plan.ranks, plan.names, plan.cols
-        empty: Dict = {}
-        report = Report(
-            gpu_relative_perf_scores=RankScores(ranks, lambda: scores()[:, 1]) if has_rel else empty,
-            section_relative_perf_scores=(SectionScores(names, cols, ranks, lambda: scores()[:, 2 + S : 2 + 2 * S])
-                                          if (has_rel and names) else empty),
-            gpu_individual_perf_scores=RankScores(ranks, lambda: scores()[:, 0]) if has_indiv else empty,
-            section_individual_perf_scores=(SectionScores(names, cols, ranks, lambda: scores()[:, 2 : 2 + S])
-                                            if (has_indiv and names) else empty),
-            rank_to_node=self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
-            local_section_summaries=StatSummaries(plan.section_rows, stats),
-            local_kernel_summaries=StatSummaries(plan.kernel_rows, stats),
-            generate_report_elapsed_time=(time.perf_counter_ns() - t0) * 1e-6,
-            gather_on_rank0=self.gather_on_rank0,
-            rank=self.rank,
-        )
-        object.__setattr__(
-            report, "_device_flags", _DeviceFlags(self.thresholds, flags, ranks, names, cols, S, has_rel, has_indiv)
-        )
-        return report
+        src = _ScoreSource()
+        src.scores = blob[off_s : off_s + R * W * 4].view(np.float32).reshape(R, W)[lo:hi]
+        src.stats = blob[off_t : off_t + plan.stats_needed * 32].view(np.float32).reshape(plan.stats_needed, 8)
+        src.S, src.ranks, src.names, src.cols = S, plan.ranks, plan.names, plan.cols
+        src.has_rel, src.has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
+        src.section_rows, src.kernel_rows = plan.section_rows, plan.kernel_rows
+        flags = _DeviceFlags(self.thresholds, blob[off_f : off_f + R * W].reshape(R, W)[lo:hi], plan.ranks, plan.names,
+                             plan.cols, S, src.has_rel, src.has_indiv)
+        return Report._from_device(
+            src, self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
+            (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank, flags)
 
     # ---- public: summaries given as dicts (reference signature) -------------------------------------
     def generate_report(self, section_summaries: Mapping[str, _SummaryType],
@@ -649,10 +601,8 @@ class ReportGenerator:
 
         ws, mapper = self._score_round(knames, snames, fill_send, local_ranks=local_ranks, stats_rows=total_rows,
                                        stats_rows_used=stats_needed, resync_first=resync_first)
-        stats = ws.stats[:stats_needed].copy()
-        sec_summ = StatSummaries(dict(section_rows), stats)
-        ker_summ = StatSummaries(dict(kernel_rows), stats)
-        report = self._assemble(ws, mapper, snames, sec_summ, ker_summ, t0, local_ranks=local_ranks)
+        report = self._assemble(ws, mapper, snames, dict(section_rows), dict(kernel_rows), t0, local_ranks=local_ranks,
+                                stats=ws.stats[:stats_needed].copy())
         # names are settled now: the next report with the same tables takes the planned path
         key = (id(section_rows), len(section_rows), id(kernel_rows), len(kernel_rows), self.name_mapper.version,
                self._private_mapper.version, self.world_size, self.rank, rings.rows_used, local_ranks, id(rings))

@@ -221,3 +221,40 @@ def detector_name_change_midway(rank, world):
                 "ids": dict(Detector.reporter.name_mapper.section_name_to_id)}
     finally:
         Detector.shutdown()
+
+
+def detector_reports_pickle(rank, world):
+    """First, second (cached plan) and third report of a Detector run all pickle / deep-copy / json-dump."""
+    import copy
+    import json
+    import pickle as pk
+
+    from nvrx_straggler import Detector
+
+    Detector.initialize(node_name="nodeX")
+    out = []
+    try:
+        for rep_no in range(3):
+            for i in range(4):
+                for name in ("a", "b"):
+                    with Detector.detection_section(name, profile_cuda=False):
+                        pass
+            report = Detector.generate_report()
+            if rank != 0:
+                assert report is None
+                continue
+            back = pk.loads(pk.dumps(report))
+            deep = copy.deepcopy(report)
+            for r in (report, back, deep):
+                assert type(r.section_relative_perf_scores) is dict and set(r.section_relative_perf_scores) == {"a", "b"}
+                assert set(r.section_relative_perf_scores["a"]) == set(range(world))
+                assert type(r.local_section_summaries) is dict and set(r.local_section_summaries) == {"a", "b"}
+                json.dumps(r.gpu_relative_perf_scores), json.dumps(r.section_individual_perf_scores)
+                r.identify_stragglers()
+            assert back.section_relative_perf_scores == report.section_relative_perf_scores
+            assert {str(k): v for k, v in back.local_section_summaries["a"].items()} == \
+                   {str(k): v for k, v in report.local_section_summaries["a"].items()}
+            out.append(rep_no)
+    finally:
+        Detector.shutdown()
+    return out

@@ -1,0 +1,28 @@
+"""Injected (via PYTHONPATH) into every interpreter that tools/run_reference_tests.sh starts -- including the
+``spawn`` children of the reference's multi-process tests -- so that the reference's OWN unit tests run
+unmodified against this package on a box without a GPU.
+
+* the package directory goes first on ``sys.path``: ``nvidia_resiliency_ext.attribution.straggler`` then resolves to
+  the MI355X implementation (``nvidia-resiliency-ext_amd/nvidia_resiliency_ext`` aliases ``nvrx_straggler``);
+* when no HIP device is visible the CPU checker backend (tests/oracle_backend.py, built on oracle/) is installed
+  with ``backend.set_backend`` -- test infrastructure, exactly as the repo's own CPU tests do.  With a GPU the
+  product's HIP backend is left alone.
+"""
+import os
+import sys
+
+_repo = os.environ.get("NVRX_REPO")
+if _repo and os.environ.get("NVRX_REFTEST") == "1":
+    for _p in (os.path.join(_repo, "tests"), _repo, os.path.join(_repo, "nvidia-resiliency-ext_amd")):
+        if _p not in sys.path:
+            sys.path.insert(0, _p)
+    try:
+        import torch
+
+        if not torch.cuda.is_available():
+            from nvrx_straggler import backend as _backend
+            from oracle_backend import OracleBackend
+
+            _backend.set_backend(OracleBackend())
+    except Exception as _e:  # noqa: BLE001  (never break interpreter start-up; the tests will say what is wrong)
+        sys.stderr.write(f"[reftests sitecustomize] backend hook failed: {_e!r}\n")
