@@ -187,16 +187,124 @@ def _per_step_overhead(world: int, rank: int, steps: int, blocks: int):
     }
 
 
-def _pmc_traffic(local_ranks: int):
-    """HBM bytes per k_row_stats launch from the committed rocprofv3 PMC summary, if one exists for
-    this shape (collected in its own run; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM)."""
+def _kernel_source_sha() -> str:
+    import hashlib
+
+    with open(os.path.join(REPO, "nvidia-resiliency-ext_amd", "csrc", "nvrx_straggler.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def _pmc_traffic(rows: int):
+    """HBM bytes per k_row_stats launch from the rocprofv3 PMC pass of tools/run_gpu_round.sh (separate run, --pmc
+    FETCH_SIZE with --kernel-trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM).  The summary
+    records the sha of the kernel source it was measured on: a summary of any other source is stale and reported as
+    null rather than quoted."""
     path = os.path.join(REPO, "profiles", "pmc_row_stats.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get(str(local_ranks), {}).get("hbm_bytes_per_launch")
+        if d.get("kernel_source_sha16") != _kernel_source_sha():
+            return None
+        return d.get("rows", {}).get(str(rows), {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def _kernel_leg(job, steps, samples, cold=False, sweep=None):
+    """Average k_row_stats duration over `steps` reports of `job` (hipExtLaunchKernel start/stop events on the launch
+    stream).  cold=True: a 1 GiB sweep between reports evicts L2 and the Infinity Cache, so the rows come from HBM."""
+    job.rings.timing_enable(True)
+    job.rings.timing_read(reset=True)
+    for _ in range(steps):
+        if cold:
+            sweep.add_(1.0)
+            torch.cuda.synchronize()
+        job.rearm(samples)
+        job.report()
+    torch.cuda.synchronize()
+    total_us, launches = job.rings.timing_read(reset=True)
+    job.rings.timing_enable(False)
+    return total_us / max(launches, 1), launches
+
+
+def _roof(kern_us, alg_bytes):
+    achieved = alg_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+    return {"kernel_us_avg": round(kern_us, 3), "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4)}
+
+
+def _n8_shape_leg(steps, warmup):
+    """The per-GPU work of the 8-GPU production shape on this GPU: ONE logical rank, 64 rows x 10 000 samples (2.56 MB).
+    Report latency without an exchange + the statistics kernel against the roofline at that shape."""
+    import synth
+    from nvrx_straggler.folded import FoldedJob
+
+    job = FoldedJob(total_ranks=1, section_names=[synth.section_name(s) for s in range(SECTIONS)], ring_cap=SAMPLES,
+                    node_name="node0")
+    try:
+        job.load(0, synth.stress_samples(0, SECTIONS, SAMPLES))
+        for _ in range(warmup):
+            job.rearm(SAMPLES)
+            job.report()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.rearm(SAMPLES)
+            job.report()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / steps * 1e6
+        kern_us, launches = _kernel_leg(job, steps, SAMPLES)
+        alg = SECTIONS * SAMPLES * 4
+        out = {"workload": f"1 rank x {SECTIONS} sections x {SAMPLES} samples (what ONE GPU holds at 8 GPUs), no exchange",
+               "report_us": round(us, 2), "bound": "hbm", "kernel": "k_row_stats", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "algorithmic_bytes_per_launch": alg, "launches_timed": launches, "traffic": _pmc_traffic(SECTIONS)}
+        out.update(_roof(kern_us, alg))
+        return out
+    finally:
+        job.close()
+
+
+def _detector_leg(steps, warmup):
+    """Detector-level latency: the real ``Detector.generate_report()`` (harvest of GPU regions, occupancy check,
+    report, ring reset -- straggler.py:228-244) over one rank's 64 resident sections x 10 000 samples."""
+    import synth
+    from nvrx_straggler import Detector
+    from nvrx_straggler.straggler import CustomSection
+
+    old_cap = CustomSection.max_elapseds_len
+    CustomSection.max_elapseds_len = SAMPLES
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="node0")
+    try:
+        x = torch.from_numpy(synth.stress_samples(0, SECTIONS, SAMPLES)).cuda()
+        for s in range(SECTIONS):
+            with Detector.detection_section(synth.section_name(s), profile_cuda=False):
+                pass
+        Detector._reset_sections_elapseds()
+        rings = Detector.rings
+        for s in range(SECTIONS):
+            rings.push_device(Detector.custom_sections[synth.section_name(s)].row, x[s].contiguous())
+        torch.cuda.synchronize()
+        rings.backend.synchronize()
+
+        def step():
+            for row in range(rings.rows_used):
+                rings.set_count(row, SAMPLES)
+            return Detector.generate_report()
+
+        for _ in range(warmup):
+            step()
+        t = []
+        for _ in range(steps):
+            for row in range(rings.rows_used):
+                rings.set_count(row, SAMPLES)
+            t0 = time.perf_counter()
+            Detector.generate_report()
+            t.append(time.perf_counter() - t0)
+        return {"us_median": round(float(np.median(t)) * 1e6, 2), "us_p95": round(float(np.percentile(t, 95)) * 1e6, 2),
+                "workload": f"Detector.generate_report() incl. harvest / occupancy check / ring reset, 1 rank x {SECTIONS} "
+                            f"sections x {SAMPLES} resident samples, relative+individual scores"}
+    finally:
+        Detector.shutdown()
+        CustomSection.max_elapseds_len = old_cap
 
 
 def main():
@@ -210,6 +318,7 @@ def main():
                     "be exercised with several ranks sharing one GPU)")
     ap.add_argument("--no-overhead", action="store_true", help="skip the per-step overhead leg (config #4)")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the PCIe-inclusive leg (samples handed over from host memory)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the N=8-shape, cold-cache and Detector-level legs")
     ap.add_argument("--overhead-steps", type=int, default=100)
     ap.add_argument("--overhead-blocks", type=int, default=5)
     args = ap.parse_args()
@@ -295,6 +404,20 @@ def main():
         except Exception as e:  # noqa: BLE001  (deterministic on every rank: same state everywhere)
             exchange = {"error": str(e)[-200:]}
 
+    # the same kernel with its rows coming from HBM: a 1 GiB sweep between reports evicts L2 and the Infinity Cache
+    cold = None
+    n8 = None
+    detector_leg = None
+    if world == 1 and not args.no_extra_legs:
+        sweep = torch.zeros(1 << 28, dtype=torch.float32, device="cuda")
+        cold_us, cold_n = _kernel_leg(job, min(args.steps, 30), SAMPLES, cold=True, sweep=sweep)
+        del sweep
+        cold = _roof(cold_us, job.local_ranks * SECTIONS * SAMPLES * 4)
+        cold["launches_timed"] = cold_n
+        cold["note"] = "1 GiB device sweep between reports: rows fetched from HBM, not from L2 / Infinity Cache"
+        n8 = _n8_shape_leg(args.steps, args.warmup)
+        detector_leg = _detector_leg(args.steps, args.warmup)
+
     host_inputs = None
     if world == 1 and not args.no_host_inputs:
         host = [synth.stress_samples(r, SECTIONS, SAMPLES, slow_rank=3, slow_factor=1.5) for r in job.logical_ranks()]
@@ -358,12 +481,18 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": _pmc_traffic(job.local_ranks),
+                "traffic": _pmc_traffic(job.local_ranks * SECTIONS),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_us_avg": round(kern_us, 3),
                 "launches_timed": kern_launches,
             },
         }
+        if cold is not None:
+            out["roofline"]["cold"] = cold
+        if n8 is not None:
+            out["roofline_n8_shape"] = n8
+        if detector_leg is not None:
+            out["detector_report"] = detector_leg
         if overhead is not None:
             out["per_step_overhead"] = overhead
         if host_inputs is not None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NVRX_ABI_VERSION 1
+#define NVRX_ABI_VERSION 2
 
 #define NVRX_OK 0
 #define NVRX_ERR_INVALID (-22) /* bad argument (EINVAL) */
@@ -95,7 +95,9 @@ int nvrx_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8
  *      flag [L-1]               1.0 if rank r has ids for all its names, else 0.0
  *   thresholds[4] = {gpu_rel, section_rel, gpu_indiv, section_indiv} (Report.identify_stragglers
  *      argument order, reporting.py:84-90); NULL => 0.75 each;
- *   d_scores [R][NVRX_SCORE_LEN(S)] f32 out, NaN where the reference reports NaN / nothing;
+ *   d_scores [R][NVRX_SCORE_LEN(S)] f32 out, NaN where the reference reports NaN / nothing.  For R <= 64 one
+ *      workgroup scores the whole table and writes d_scores / d_flags in 16-byte units when both are 16-byte
+ *      aligned: pad each array to a multiple of 16 bytes;
  *   d_flags  [R][NVRX_SCORE_LEN(S)] u8 out, 1 where score < threshold (strict; NaN never flagged);
  *   d_meta   [NVRX_META_WORDS] u32 out: {all ranks' name flags set, R, K, S, seq, 0, 0, 0};
  *   d_done_counter  device word (zero before the first launch) or NULL.  When given, d_scores /
@@ -188,6 +190,42 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
  * _update_local_min_times (reporting.py:298-314): hmin[row] = min(hmin[row], MED). */
 int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok,
                       int rows_active, void *stream);
+/* A whole report in ONE call: flush -> row statistics -> [all-gather of the exchange rows] -> scoring of the
+ * table -> (optionally) wait for the completion word.  The descriptor is filled once per report shape and reused;
+ * the library advances `seq` itself, so a steady-state report is a single FFI crossing.
+ * Replaces Detector.generate_report's body (straggler.py:236-239) + ReportGenerator.generate_report
+ * (reporting.py:421-554) for the case where the summaries never leave the device. */
+typedef struct nvrx_report_desc {
+    int32_t R, K, S;          /* table shape: ranks, kernel ids, section ids */
+    int32_t names_ok;         /* this process has ids for all of its names */
+    int32_t rows_active;      /* rows per logical rank to process (0 = all) */
+    int32_t do_indiv, do_rel; /* score families to compute */
+    int32_t stats_rows;       /* statistics rows to forward to d_stats_dst */
+    double thresholds[4];     /* gpu_rel, section_rel, gpu_indiv, section_indiv */
+    float *d_stats;           /* [local_ranks*rows_per_rank][NVRX_STATS_STRIDE] device */
+    float *d_send;            /* [local_ranks][L] device: this process' exchange rows */
+    float *d_table;           /* [R][L] device: all ranks' rows (ignored when allgather_fn is NULL) */
+    float *d_scores;          /* result block, device-visible addresses (nvrx_host_alloc's *out_device):    */
+    uint8_t *d_flags;         /*   16-byte aligned, each array padded to a multiple of 16 bytes              */
+    uint32_t *d_meta;         /*   NVRX_META_WORDS words; [4] is the completion word                         */
+    float *d_stats_dst;       /*   or NULL                                                                   */
+    uint32_t *d_done_counter; /* device word, zero before the first report */
+    void *allgather_fn;       /* NULL = single process, no exchange; else an ncclAllGather-compatible function
+                                 int (*)(const void *send, void *recv, size_t count, int dtype, void *comm, void *stream) */
+    void *comm;               /* its communicator */
+    int32_t send_count;       /* floats this process contributes (local_ranks * L) */
+    uint32_t seq;             /* last published sequence number (in/out) */
+    const uint32_t *h_seq_word; /* host address of meta[4]; NULL = do not wait */
+    double timeout_s;         /* <= 0: wait for ever, like a blocking collective */
+    void *order_after_stream; /* hipStream_t whose already-enqueued work the report must follow (device-side wait,
+                                 the host does not block), or NULL; takes the place of torch.cuda.synchronize()
+                                 in straggler.py:234 for the collectives the caller has enqueued there */
+    int32_t order_after_enabled; /* 0: order_after_stream is ignored */
+    int32_t reserved;
+} nvrx_report_desc;
+int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *desc, void *stream);
+/* sizeof(nvrx_report_desc) as this library was compiled: lets an FFI binding check its own struct layout. */
+int nvrx_report_desc_size(void);
 /* Re-initialise an exchange buffer with the "no stats" sentinels (call when ids change). */
 int nvrx_send_init(float *d_send, int rows, int K, int S, void *stream);
 

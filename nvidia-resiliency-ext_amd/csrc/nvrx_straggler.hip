@@ -209,14 +209,12 @@ __device__ __forceinline__ void score_colmin(const ScoreArgs &a, int tid, int nt
 // Scores and flags of rank r, by all NTHR threads of the workgroup (contains one barrier).
 template <int NTHR>
 __device__ __forceinline__ void score_rank(const ScoreArgs &a, int r, int tid, const float *minmed,
-                                           double (*s_red)[NTHR / 64], uint32_t (*s_cnt)[NTHR / 64]) {
+                                           double (*s_red)[NTHR / 64], uint32_t (*s_cnt)[NTHR / 64],
+                                           float *__restrict__ out, uint8_t *__restrict__ fl) {
     const int K = a.K, S = a.S, KS = K + S;
     const int L = NVRX_TABLE_LEN(K, S);
-    const int W = NVRX_SCORE_LEN(S);
     const int lane = tid & 63, wave = tid >> 6;
     const float *__restrict__ row = a.table + (size_t)r * L;
-    float *__restrict__ out = a.scores + (size_t)r * W;
-    uint8_t *__restrict__ fl = a.flags ? a.flags + (size_t)r * W : nullptr;
     const float NaN = __builtin_nanf("");
 
     // section scores: reference / MED (reporting.py:196-217), rounded to f32 (reporting.py:352)
@@ -895,7 +893,8 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
         __syncthreads();
         minmed = s_min;
     }
-    score_rank<SCORE_THREADS>(a, r, tid, minmed, s_red, s_cnt);
+    score_rank<SCORE_THREADS>(a, r, tid, minmed, s_red, s_cnt, a.scores + (size_t)r * NVRX_SCORE_LEN(a.S),
+                              a.flags ? a.flags + (size_t)r * NVRX_SCORE_LEN(a.S) : nullptr);
     if (r == 0 && a.meta && (tid >> 6) == 1) score_meta(a, tid & 63);
 
     if (a.done_counter) {
@@ -914,6 +913,118 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
                 __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_score1: the whole table scored by ONE workgroup (R <= 64 ranks, results staged in LDS).
+//
+// The report's second kernel is pure latency (a few KB in, a few KB out over PCIe), so what counts is the
+// number of dependent steps between "table visible" and "host sees the completion word":
+//   * one workgroup -> no inter-workgroup ticket, no device-scope atomics;
+//   * scores and flag bytes are staged in LDS and leave as 16-byte stores (a byte store to host memory is one
+//     fabric write each; 1040 of them cost more than the arithmetic);
+//   * the result block lives in pinned host memory, which the GPU maps uncached: its stores go straight to
+//     the fabric, so instead of a system-scope release fence (an L2 write-back sweep per wave, ~1.7 us each
+//     on gfx950) every wave drains its own stores with s_waitcnt vmcnt(0), the workgroup meets at a barrier
+//     and lane 0 then stores the sequence word -- PCIe keeps posted writes of one requester in order.
+//     NVRX_SCORE_FENCE=1 (read by the host library) adds the release fence back in front of that store.
+// ------------------------------------------------------------------------------------------------
+constexpr int SCORE1_THREADS = 1024;
+constexpr int SCORE1_MAX_RANKS = 64;
+constexpr size_t SCORE1_MAX_LDS = 60 * 1024;
+
+typedef float nvrx_f4 __attribute__((ext_vector_type(4)));
+
+// 16-byte write-through store at system scope (sc0 sc1): not tracked by the compiler's waitcnt insertion,
+// the caller drains with s_waitcnt vmcnt(0) before publishing.
+__device__ __forceinline__ void store16_sys(void *dst, nvrx_f4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v) : "memory");
+}
+
+__host__ __device__ inline size_t score1_lds_bytes(int R, int K, int S) {
+    const size_t ks4 = (size_t)((K + S + 3) & ~3);
+    const size_t nout = (size_t)R * NVRX_SCORE_LEN(S);
+    return ks4 * 4 + ((nout + 3) & ~(size_t)3) * 4 + ((nout + 15) & ~(size_t)15);
+}
+
+__global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fence) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ double s_red[8][SCORE1_THREADS / 64];   // two alternating sets of 4 (see the rank loop)
+    __shared__ uint32_t s_cnt[4][SCORE1_THREADS / 64];
+
+    const int K = a.K, S = a.S, KS = K + S, R = a.R;
+    const int L = NVRX_TABLE_LEN(K, S);
+    const int W = NVRX_SCORE_LEN(S);
+    const int nout = R * W;
+    const int nout4 = (nout + 3) & ~3;
+    float *s_min = reinterpret_cast<float *>(s_raw);
+    float *s_out = s_min + ((KS + 3) & ~3);
+    uint8_t *s_fl = reinterpret_cast<uint8_t *>(s_out + nout4);
+    const int tid = threadIdx.x;
+    const float NaN = __builtin_nanf("");
+
+    // local statistics rows -> result block; issued first so the loads overlap everything below
+    for (int i = tid; i < a.stats_n4; i += SCORE1_THREADS) {
+        const float4 v = a.stats_src[i];
+        store16_sys(a.stats_dst + i, nvrx_f4{v.x, v.y, v.z, v.w});
+    }
+    score_colmin(a, tid, SCORE1_THREADS, s_min);
+    if (a.meta && (tid >> 6) == SCORE1_THREADS / 64 - 1) score_meta(a, tid & 63);
+    // zero the padding of the staged arrays (it is stored too)
+    if (tid < nout4 - nout) s_out[nout + tid] = 0.f;
+    if (tid < ((nout + 15) & ~15) - nout) s_fl[nout + tid] = 0;
+    __syncthreads();
+
+    if (K == 0) {
+        // no GPU-timed rows anywhere: every (rank, section) pair is independent -> one flat pass, no barriers
+        for (int idx = tid; idx < R * S; idx += SCORE1_THREADS) {
+            const int r = idx / S, sct = idx - r * S;
+            const float *__restrict__ row = a.table + (size_t)r * L;
+            const float med = row[sct];
+            float si = NaN, sr = NaN;
+            if (med >= 0.0f) {
+                if (a.do_indiv) si = (float)((double)row[KS + sct] / (double)med);
+                if (a.do_rel) sr = (float)((double)s_min[sct] / (double)med);
+            }
+            s_out[r * W + 2 + sct] = si;
+            s_out[r * W + 2 + S + sct] = sr;
+            s_fl[r * W + 2 + sct] = ((double)si < a.thr[3]) ? 1 : 0;
+            s_fl[r * W + 2 + S + sct] = ((double)sr < a.thr[1]) ? 1 : 0;
+        }
+        for (int r = tid; r < R; r += SCORE1_THREADS) {  // reporting.py:226-228: no kernels -> NaN, never flagged
+            s_out[r * W] = NaN;
+            s_out[r * W + 1] = NaN;
+            s_fl[r * W] = 0;
+            s_fl[r * W + 1] = 0;
+        }
+    } else {
+        // rank r's reduction scratch alternates between two sets: thread 0 may still be summing set r&1 while the
+        // other waves already fill set (r+1)&1; set r&1 is rewritten only after the barrier of rank r+1.
+        for (int r = 0; r < R; r++)
+            score_rank<SCORE1_THREADS>(a, r, tid, s_min, s_red + 4 * (r & 1), s_cnt + 2 * (r & 1), s_out + r * W, s_fl + r * W);
+    }
+    __syncthreads();
+
+    // staged results -> result block, 16 bytes per lane
+    {
+        const nvrx_f4 *src = reinterpret_cast<const nvrx_f4 *>(s_out);
+        nvrx_f4 *dst = reinterpret_cast<nvrx_f4 *>(a.scores);
+        for (int i = tid; i < nout4 / 4; i += SCORE1_THREADS) store16_sys(dst + i, src[i]);
+        if (a.flags) {
+            const nvrx_f4 *fsrc = reinterpret_cast<const nvrx_f4 *>(s_fl);
+            nvrx_f4 *fdst = reinterpret_cast<nvrx_f4 *>(a.flags);
+            for (int i = tid; i < (nout + 15) / 16; i += SCORE1_THREADS) store16_sys(fdst + i, fsrc[i]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores (asm and plain) have been accepted
+    __syncthreads();
+    if (tid == 0 && a.meta && a.done_counter) {
+        if (fence) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -987,6 +1098,25 @@ int launch_row_stats(const float *d_samples, const uint32_t *d_counts, const uin
     }
     HIP_TRY(hipGetLastError());
     return NVRX_OK;
+}
+
+// NVRX_SCORE_SINGLE_WG=0 keeps the one-workgroup-per-rank score kernel for every shape (A/B measurements);
+// NVRX_SCORE_FENCE=1 puts a system-scope release fence in front of the completion word of k_score1.
+int score_single_wg_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NVRX_SCORE_SINGLE_WG");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return v;
+}
+int score_fence_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NVRX_SCORE_FENCE");
+        v = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return v;
 }
 
 // scratch for the two-kernel scoring path (large R or K+S)
@@ -1072,6 +1202,7 @@ struct nvrx_ctx {
     std::vector<OpenStamp> open_stamps;
     std::vector<hipStream_t> stamp_streams;  // user streams with stamp kernels the rings have not been ordered after
     hipEvent_t stamp_ev = nullptr;
+    hipEvent_t order_ev = nullptr;  // nvrx_report: report stream ordered after the caller's stream
 
     std::mutex mu;
 };
@@ -1185,6 +1316,8 @@ extern "C" {
 
 int nvrx_abi_version(void) { return NVRX_ABI_VERSION; }
 
+int nvrx_report_desc_size(void) { return (int)sizeof(nvrx_report_desc); }
+
 const char *nvrx_last_error(void) { return g_err.c_str(); }
 
 // ------------------------------------------------------------------------------------------------
@@ -1224,6 +1357,15 @@ int nvrx_score(const float *d_table, int R, int K, int S, int do_indiv, int do_r
         a.stats_n4 = stats_rows * (NVRX_STATS_STRIDE / 4);
     }
     const int KS = K + S;
+    // One workgroup does it all when the staged results fit in LDS.  The result arrays are then written in 16-byte
+    // units: the caller's buffers must be 16-byte aligned and padded to a multiple of 16 bytes (the workspace is).
+    if (R <= SCORE1_MAX_RANKS && score1_lds_bytes(R, K, S) <= SCORE1_MAX_LDS &&
+        (reinterpret_cast<uintptr_t>(d_scores) & 15u) == 0 && (reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0 &&
+        score_single_wg_enabled()) {
+        hipLaunchKernelGGL(k_score1, dim3(1), dim3(SCORE1_THREADS), score1_lds_bytes(R, K, S), st, a, score_fence_enabled());
+        HIP_TRY(hipGetLastError());
+        return NVRX_OK;
+    }
     size_t lds = (size_t)KS * sizeof(float);
     if (R > 64 || lds > 48 * 1024) {
         // large jobs: column minima in their own pass over a coalesced grid
@@ -1315,6 +1457,7 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     }
     CTX_TRY(hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->stamp_ev, hipEventDisableTiming));
+    CTX_TRY(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
     CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
     CTX_TRY(hipMemset(ctx->d_stamps, 0, nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
     {
@@ -1354,6 +1497,7 @@ int nvrx_ctx_destroy(nvrx_ctx *ctx) {
     }
     if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
     if (ctx->stamp_ev) (void)hipEventDestroy(ctx->stamp_ev);
+    if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
     delete ctx;
     return NVRX_OK;
@@ -1668,6 +1812,39 @@ int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S
                           d_stats, ep, st, ev_start, ev_stop, uniform_n);
     if (rc) return rc;
     if (pair >= 0) ctx->timing_used.push_back(pair);
+    return NVRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// report (everything, one call)
+// ------------------------------------------------------------------------------------------------
+int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
+    if (!ctx || !d) return fail(NVRX_ERR_INVALID, "null argument");
+    if (!d->d_stats || !d->d_send || !d->d_scores || !d->d_meta) return fail(NVRX_ERR_INVALID, "null buffer in the report descriptor");
+    const bool exchanging = d->allgather_fn != nullptr;
+    if (exchanging && (!d->d_table || d->d_table == d->d_send || d->send_count <= 0))
+        return fail(NVRX_ERR_INVALID, "an exchange needs a separate table buffer and a positive send_count");
+    if (d->order_after_enabled && d->order_after_stream != stream) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIP_TRY(hipEventRecord(ctx->order_ev, as_stream(d->order_after_stream)));
+        HIP_TRY(hipStreamWaitEvent(as_stream(stream), ctx->order_ev, 0));
+    }
+    int rc = nvrx_report_local(ctx, d->d_stats, d->d_send, d->K, d->S, d->names_ok, d->rows_active, stream);
+    if (rc) return rc;
+    if (exchanging) {
+        // ncclAllGather(sendbuff, recvbuff, sendcount, ncclFloat32 = 7, comm, stream), enqueued between the two
+        // kernels on the same stream: this rank's rows -> every rank's [R, L] table (reporting.py:281,397)
+        using AllGatherFn = int (*)(const void *, void *, size_t, int, void *, void *);
+        const int nrc = reinterpret_cast<AllGatherFn>(d->allgather_fn)(d->d_send, d->d_table, (size_t)d->send_count, 7,
+                                                                       d->comm, stream);
+        if (nrc != 0) return fail(NVRX_ERR_HIP, "all-gather of the exchange rows failed (ncclResult %d)", nrc);
+    }
+    d->seq = (d->seq % 0x7FFFFFFFu) + 1u;
+    rc = nvrx_score(exchanging ? d->d_table : d->d_send, d->R, d->K, d->S, d->do_indiv, d->do_rel, d->thresholds,
+                    d->d_scores, d->d_flags, d->d_meta, d->d_done_counter, d->seq, d->d_stats, d->d_stats_dst,
+                    d->stats_rows, stream);
+    if (rc) return rc;
+    if (d->h_seq_word) return nvrx_poll_u32(d->h_seq_word, d->seq, d->timeout_s > 0.0 ? d->timeout_s : 1e30);
     return NVRX_OK;
 }
 

@@ -10,17 +10,36 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_uint32, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint32, c_void_p
 
 _LIB_NAME = "libnvrx_straggler_hip.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
 
-NVRX_ABI_VERSION = 1
+NVRX_ABI_VERSION = 2
 STATS_STRIDE = 8
 STAT_MIN, STAT_MAX, STAT_MED, STAT_AVG, STAT_STD, STAT_NUM, STAT_WEIGHT = range(7)
 KIND_SECTION, KIND_KERNEL = 0, 1
 MAX_RING_CAP = 65536
 META_WORDS = 8
+ERR_TIMEOUT = -62
+
+
+
+class ReportDesc(ctypes.Structure):
+    """``nvrx_report_desc`` (include/nvrx_straggler.h): one report's buffers and switches, filled once per shape."""
+
+    _fields_ = [
+        ("R", c_int32), ("K", c_int32), ("S", c_int32), ("names_ok", c_int32), ("rows_active", c_int32),
+        ("do_indiv", c_int32), ("do_rel", c_int32), ("stats_rows", c_int32),
+        ("thresholds", c_double * 4),
+        ("d_stats", c_void_p), ("d_send", c_void_p), ("d_table", c_void_p),
+        ("d_scores", c_void_p), ("d_flags", c_void_p), ("d_meta", c_void_p), ("d_stats_dst", c_void_p),
+        ("d_done_counter", c_void_p),
+        ("allgather_fn", c_void_p), ("comm", c_void_p), ("send_count", c_int32), ("seq", c_uint32),
+        ("h_seq_word", c_void_p), ("timeout_s", c_double),
+        ("order_after_stream", c_void_p), ("order_after_enabled", c_int32), ("reserved", c_int32),
+    ]
+
 
 # every symbol include/nvrx_straggler.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -51,6 +70,8 @@ SYMBOLS = [
     ("nvrx_stamp_begin", c_int, [c_void_p, c_int, c_void_p]),
     ("nvrx_stamp_end", c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     ("nvrx_report_local", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    ("nvrx_report", c_int, [c_void_p, POINTER(ReportDesc), c_void_p]),
+    ("nvrx_report_desc_size", c_int, []),
     ("nvrx_send_init", c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     ("nvrx_timing_enable", c_int, [c_void_p, c_int]),
     ("nvrx_timing_read", c_int, [c_void_p, POINTER(c_double), POINTER(c_int), c_int]),
@@ -100,6 +121,9 @@ def load() -> ctypes.CDLL:
             fn.argtypes = argtypes
         if lib.nvrx_abi_version() != NVRX_ABI_VERSION:
             raise RuntimeError(f"{_LIB_NAME} ABI {lib.nvrx_abi_version()} != expected {NVRX_ABI_VERSION}")
+        if lib.nvrx_report_desc_size() != ctypes.sizeof(ReportDesc):
+            raise RuntimeError(f"nvrx_report_desc is {lib.nvrx_report_desc_size()} bytes in {_LIB_NAME}, "
+                               f"{ctypes.sizeof(ReportDesc)} in the ctypes binding")
         _lib = lib
     return _lib
 

@@ -20,6 +20,7 @@ a report needs a single small D2H copy.
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 from typing import Optional, Sequence
 
@@ -29,6 +30,20 @@ import torch
 from . import _native
 
 DEFAULT_THRESHOLDS = (0.75, 0.75, 0.75, 0.75)  # gpu_rel, section_rel, gpu_indiv, section_indiv
+
+
+
+def report_timeout_s() -> float:
+    """How long a report waits for its completion word.  The score kernel is queued behind the report's
+    collective, so this bounds how late the slowest PEER may reach ``generate_report`` (first-report RCCL set-up,
+    a checkpoint or evaluation on one rank, an actual straggler).  The reference simply blocks in its collective
+    until the process group's timeout; the default here is c10d's 30 minutes.  ``NVRX_REPORT_TIMEOUT_S`` overrides
+    it, ``0`` waits for ever."""
+    try:
+        return float(os.environ.get("NVRX_REPORT_TIMEOUT_S", "1800"))
+    except ValueError:
+        return 1800.0
+
 
 _backend = None
 _backend_lock = threading.Lock()
@@ -109,6 +124,21 @@ class Workspace:
         self.seq = 0
         self.send_ptr = self.send.data_ptr()
         self.table_ptr = self.table.data_ptr()
+        # descriptor of the one-call report (nvrx_report); the library advances desc.seq itself
+        d = self.desc = _native.ReportDesc()
+        d.R, d.K, d.S = R, K, S
+        d.names_ok, d.rows_active, d.do_indiv, d.do_rel, d.stats_rows = 1, 0, 1, 1, 0
+        for i, t in enumerate(DEFAULT_THRESHOLDS):
+            d.thresholds[i] = t
+        d.d_stats, d.d_send, d.d_table = self.d_stats, self.send_ptr, self.table_ptr
+        d.d_scores, d.d_flags, d.d_meta, d.d_stats_dst = self.d_scores, self.d_flags, self.d_meta, self.h_stats_dst
+        d.d_done_counter = self.d_counter
+        d.allgather_fn, d.comm, d.send_count = None, None, local_ranks * self.L
+        d.seq = 0
+        d.h_seq_word = self.h_seq
+        d.timeout_s = report_timeout_s()
+        self.desc_ref = ctypes.byref(d)
+        self.desc_key = None
 
     def __del__(self):  # pragma: no cover
         try:
@@ -145,6 +175,7 @@ class HipBackend:
         # the report pipeline runs on its own stream so it never serialises with the training stream
         self.stream = torch.cuda.Stream(device=self.device)
         self._workspaces = {}
+        self._retired = []
         self._thr = (ctypes.c_double * 4)(*DEFAULT_THRESHOLDS)
         self._thr_src = DEFAULT_THRESHOLDS
         self._stream_handle = self.stream.cuda_stream
@@ -193,16 +224,26 @@ class HipBackend:
         lib = self.lib
         nrows = ws.stats_rows if stats_rows is None else min(stats_rows, ws.stats_rows)
         table_ptr = ws.table_ptr if table is ws.table else (ws.send_ptr if table is ws.send else table.data_ptr())
-        ws.seq = (ws.seq % 0x7FFFFFFF) + 1
+        ws.seq = ws.desc.seq = (max(ws.seq, ws.desc.seq) % 0x7FFFFFFF) + 1  # one sequence for both report routes
         rc = lib.nvrx_score(table_ptr, ws.R, ws.K, ws.S, int(do_indiv), int(do_rel), self._thr,
                             ws.d_scores, ws.d_flags, ws.d_meta, ws.d_counter, ws.seq,
                             ws.d_stats, ws.h_stats_dst, nrows, self._stream_handle)
         if rc < 0:
             _native.check(rc)
         if wait:
-            rc = lib.nvrx_poll_u32(ws.h_seq, ws.seq, 30.0)
+            timeout = report_timeout_s()
+            rc = lib.nvrx_poll_u32(ws.h_seq, ws.seq, timeout if timeout > 0 else 1e30)
             if rc < 0:
+                self.retire_workspace(ws)
                 _native.check(rc)
+
+    def retire_workspace(self, ws: Workspace) -> None:
+        """After a timed-out wait the kernels of ``ws`` may still be queued behind a collective: the workspace
+        must neither be reused (stale sequence / ticket state) nor freed under them, so it is parked for good."""
+        for key, val in list(self._workspaces.items()):
+            if val is ws:
+                del self._workspaces[key]
+        self._retired.append(ws)
 
     def synchronize(self) -> None:
         self.stream.synchronize()
@@ -210,8 +251,10 @@ class HipBackend:
     def row_stats(self, samples: torch.Tensor, counts: torch.Tensor, kinds: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Stateless statistics operator on caller tensors ([rows, stride] f32, [rows] u32/i32)."""
         rows, stride = samples.shape
-        stats = torch.empty((rows, _native.STATS_STRIDE), dtype=torch.float32, device=samples.device)
+        # the inputs were produced on the caller's current stream; the output is allocated under ours
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
+            stats = torch.empty((rows, _native.STATS_STRIDE), dtype=torch.float32, device=samples.device)
             _native.check(
                 self.lib.nvrx_row_stats(samples.data_ptr(), counts.data_ptr(), kinds.data_ptr() if kinds is not None else None,
                                         rows, stride, stats.data_ptr(), self.stream_handle)
@@ -355,14 +398,44 @@ class HipRings:
         if rc < 0:
             _native.check(rc)
 
+    def report_fused(self, ws: Workspace, rows_active: int, stats_rows: int, do_indiv: bool, do_rel: bool,
+                     thresholds: Sequence[float], direct=None) -> None:
+        """The whole report in one C call (``nvrx_report``): flush -> statistics kernel -> [``ncclAllGather`` of the
+        exchange rows through ``direct``] -> score kernel -> wait for the completion word.  On return
+        ``ws.scores / flags / meta / stats`` hold this report's values."""
+        d = ws.desc
+        key = (rows_active, stats_rows, do_indiv, do_rel, thresholds, direct)
+        if ws.desc_key != key:  # cold: the switches of this shape changed
+            d.rows_active, d.stats_rows = rows_active, min(stats_rows, ws.stats_rows)
+            d.do_indiv, d.do_rel = int(do_indiv), int(do_rel)
+            for i in range(4):
+                d.thresholds[i] = float(thresholds[i])
+            if direct is not None:
+                d.allgather_fn, d.comm = direct.fn_address, direct.comm_address
+            else:
+                d.allgather_fn, d.comm = None, None
+            d.timeout_s = report_timeout_s()
+            ws.desc_key = key
+        if not ws.send_initialised:
+            self.backend.send_init(ws)
+        d.seq = max(d.seq, ws.seq)
+        rc = self.lib.nvrx_report(self.ctx, ws.desc_ref, self.backend._stream_handle)
+        ws.seq = d.seq
+        if rc < 0:
+            if rc == _native.ERR_TIMEOUT:
+                self.backend.retire_workspace(ws)
+            _native.check(rc)
+
     def peek_stats(self) -> np.ndarray:
         """Statistics of every used row right now ([rows_used, 8] on the host); exchanges nothing and
         leaves the history minima alone."""
         total = self.local_ranks * self.rows_per_rank
-        stats = torch.empty((total, _native.STATS_STRIDE), dtype=torch.float32, device=self.backend.device)
-        _native.check(self.lib.nvrx_report_local(self.ctx, stats.data_ptr(), None, 0, 0, 1, self.rows_used,
-                                                 self.backend.stream_handle))
+        # allocated, written and read under the backend's stream: the caching allocator then never hands out a block
+        # that kernels on the user's current stream may still be using
         with torch.cuda.stream(self.backend.stream):
+            stats = torch.empty((total, _native.STATS_STRIDE), dtype=torch.float32, device=self.backend.device)
+            _native.check(self.lib.nvrx_report_local(self.ctx, stats.data_ptr(), None, 0, 0, 1, self.rows_used,
+                                                     self.backend.stream_handle))
             host = stats.cpu()
         self.backend.stream.synchronize()
         return host.numpy()

@@ -57,7 +57,7 @@ def _load_rccl() -> Optional[ctypes.CDLL]:
 
 
 def _all_ok(ok: bool, group) -> bool:
-    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device="cuda")
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return bool(t.item() > 0)
 
@@ -70,6 +70,9 @@ class DirectAllGather:
         self._comm = comm
         self.world = world
         self.rank = rank
+        # raw addresses for nvrx_report, which enqueues the all-gather itself between its two kernels
+        self.fn_address = ctypes.cast(lib.ncclAllGather, ctypes.c_void_p).value
+        self.comm_address = comm.value
 
     def all_gather(self, send_ptr: int, recv_ptr: int, count: int, stream_handle: int) -> None:
         """Enqueue: every rank's ``count`` floats at ``send_ptr`` -> ``recv_ptr`` ([world, count])."""
@@ -85,8 +88,13 @@ class DirectAllGather:
                 self._comm = None
 
 
-def create(group=None) -> Optional[DirectAllGather]:
-    """Collective over ``group``: a :class:`DirectAllGather`, or ``None`` on every rank."""
+def create(group=None, device_index: Optional[int] = None) -> Optional[DirectAllGather]:
+    """Collective over ``group``: a :class:`DirectAllGather`, or ``None`` on every rank.
+
+    Ordering against the job's own collectives: the all-gather runs on a second communicator on the detector's
+    stream.  Every rank calls ``generate_report`` at the same point of its program, so the report's all-gather is
+    enqueued after the same set of c10d collectives on every rank (no cross-communicator launch-order inversion), and
+    ``nvrx_report`` orders the detector's stream after the caller's current stream before it enqueues anything."""
     if os.environ.get("NVRX_DIRECT_RCCL", "1") == "0":
         return None
     if not (dist.is_available() and dist.is_initialized()):
@@ -113,6 +121,9 @@ def create(group=None) -> Optional[DirectAllGather]:
     ctypes.memmove(ctypes.byref(uid), box[0], _NCCL_UNIQUE_ID_BYTES)
     comm = ctypes.c_void_p()
     try:
+        # the communicator binds to the device that is current during init: make it the backend's
+        if device_index is not None:
+            torch.cuda.set_device(device_index)
         rc = lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
         ok = rc == 0 and bool(comm.value)
     except Exception:  # pragma: no cover

@@ -326,7 +326,8 @@ class ReportGenerator:
         self._direct_tried = True
         from . import rccl_direct
 
-        self._direct = rccl_direct.create(self.group)
+        be = _backend_mod.get_backend()
+        self._direct = rccl_direct.create(self.group, getattr(be.device, "index", None))
 
     def _exchange(self, be, ws):
         """The report's one collective: this rank's rows -> the [R, L] table, on the backend's stream."""
@@ -423,7 +424,7 @@ class ReportGenerator:
         """Everything about a ring report that only changes when names, ids or topology change."""
 
         __slots__ = ("key", "ws", "mapper", "snames", "knames", "names", "cols", "ranks", "row_lo", "row_hi",
-                     "rows_used", "stats_needed", "section_rows", "kernel_rows")
+                     "rows_used", "stats_needed", "section_rows", "kernel_rows", "fused")
 
     def _build_ring_plan(self, key, rings, section_rows, kernel_rows, local_ranks):
         be = _backend_mod.get_backend()
@@ -448,6 +449,7 @@ class ReportGenerator:
         plan.rows_used = rings.rows_used
         plan.stats_needed = rings.rows_used if rings.local_ranks == 1 else total_rows
         plan.section_rows, plan.kernel_rows = section_rows, kernel_rows
+        plan.fused = hasattr(rings, "report_fused")  # the HIP engine; the CPU test backend takes the stepwise route
         if self.gather_on_rank0:
             plan.ranks = range(plan.ws.R)
             plan.names = [mapper.get_section_name(i) for i in range(S)]
@@ -469,11 +471,19 @@ class ReportGenerator:
         self._ring_gid_state = None  # the general path must re-derive its own view if it runs next
         return plan
 
-    def _report_from_plan(self, plan, rings, t0):
-        """The steady-state report: three C calls (+ one collective), one host copy, lazy views."""
+    def _report_from_plan(self, plan, rings, t0, order_after=None):
+        """The steady-state report: ONE C call (statistics kernel, the collective, score kernel, wait), one host
+        copy of the result block, mappings built on first read."""
         be = _backend_mod.get_backend()
         ws = plan.ws
-        if self.world_size > 1 and self._exchanged():
+        multi = self.world_size > 1 and self._exchanged()
+        if plan.fused and (not multi or self._direct is not None):
+            # ONE C call: flush -> statistics kernel -> [ncclAllGather] -> score kernel -> completion word
+            if multi and order_after is not None:
+                ws.desc.order_after_stream, ws.desc.order_after_enabled = order_after, 1
+            rings.report_fused(ws, plan.rows_used, plan.stats_needed, self.is_computing_indiv_scores,
+                               self.is_computing_rel_scores, self.thresholds, self._direct if multi else None)
+        elif multi:
             rings.report_local(ws, True, rows_active=plan.rows_used)
             table = self._exchange(be, ws)
             be.score(ws, table, self.is_computing_indiv_scores, self.is_computing_rel_scores, self.thresholds,
@@ -548,12 +558,14 @@ class ReportGenerator:
 
     # ---- internal: summaries never leave the device (Detector path) -----------------------------------
     def generate_report_from_rings(self, rings, section_rows: Mapping[str, int], kernel_rows: Mapping[str, int],
-                                   local_ranks: int = 1):
+                                   local_ranks: int = 1, order_after: Optional[int] = None):
         """Report straight from the device rings: statistics kernel -> exchange -> score kernel.
 
         ``section_rows`` / ``kernel_rows`` map the names that hold samples this window to their ring
         rows.  Replaces ``_get_section_summaries`` + ``_get_kernel_summaries`` + ``generate_report``
         of the reference (straggler.py:236-239) without materialising per-section Python objects.
+        ``order_after``: raw ``hipStream_t`` of the caller's current stream; a multi-rank report is ordered after the
+        work already enqueued there (the collectives of the training step) on the device, without a host wait.
         """
         t0 = time.perf_counter_ns()
         self.world_size = dist_utils.get_world_size(self.group)
@@ -566,7 +578,7 @@ class ReportGenerator:
         plan = self._ring_plan
         resync_first = False
         if plan is not None and plan.key == key:
-            out = self._report_from_plan(plan, rings, t0)
+            out = self._report_from_plan(plan, rings, t0, order_after)
             if out is not False:
                 return out
             self._ring_plan = None

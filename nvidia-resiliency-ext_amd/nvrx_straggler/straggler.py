@@ -266,7 +266,10 @@ class Detector:
             cls._active_sections = {n: sec.row for n, sec in cls.custom_sections.items() if counts[sec.row] > 0}
             cls._active_kernels = {k: row for k, row in rings.kernel_row_names.items() if counts[row] > 0}
             cls._occupied_key = occupied
-        report = cls.reporter.generate_report_from_rings(rings, cls._active_sections, cls._active_kernels)
+        reporter = cls.reporter
+        order_after = _backend_mod.get_backend().current_stream_handle() if reporter.world_size > 1 else None
+        report = reporter.generate_report_from_rings(rings, cls._active_sections, cls._active_kernels,
+                                                     order_after=order_after)
         rings.reset()  # both the section rows and the GPU-time rows, like :241-242 of the reference
         return report
 

@@ -13,6 +13,8 @@ no-op'd because there is no GPU here) and runs
 * ``ReportGenerator.generate_report`` on N gloo ranks -> scoring.json
 * the full ``Detector.generate_report`` on 8 gloo ranks x 64 sections x 10 000 samples (BASELINE
   configs #3/#5) -> stress.json   (inputs are re-derived from the recipe in ``synth.py``)
+* ten consecutive ``Detector.generate_report`` calls on 8 gloo ranks x 4 sections x 100 samples per report
+  (BASELINE config #2: history minima across reports, rank 3 slow from report 5 on) -> loop.json
 * the reference's native ``computeStats``/``CircularBuffer``/``CuptiProfiler`` through
   ``oracle/_ref/libnvrx_ref.so`` -> native.json
 
@@ -348,9 +350,81 @@ def make_stress():
     print("stress.json:", [v["name"] for v in variants])
 
 
+# ------------------------------------------------------------------------------------------------
+# 5. BASELINE config #2: 8 ranks, 4 sections, 1000-step loop, a report every 100 steps (10 consecutive
+#    reports through ONE Detector: history minima persist, rings are cleared by every report;
+#    reference behaviour pinned by tests/straggler/unit/test_individual_gpu_scores.py:46-121 and
+#    reporting.py:298-314).  Rank 3 runs 1.2x slower from report 5 on.
+# ------------------------------------------------------------------------------------------------
+LOOP = {"world": 8, "S": 4, "n": 100, "reports": 10, "slow_rank": 3, "slow_factor": 1.2, "slow_from": 5}
+
+
+def _loop_worker(rank, world_size, store_file, ret_queue):
+    import torch
+
+    _install_reference()
+    from nvidia_resiliency_ext.attribution.straggler.straggler import CustomSection, Detector
+
+    torch.set_num_threads(1)
+    torch.distributed.init_process_group("gloo", init_method=f"file://{store_file}", world_size=world_size, rank=rank)
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name=f"node{rank}")
+    reports = []
+    for t in range(LOOP["reports"]):
+        slow = LOOP["slow_rank"] if t >= LOOP["slow_from"] else -1
+        x = synth.loop_samples(rank, t, LOOP["S"], LOOP["n"], slow_rank=slow, slow_factor=LOOP["slow_factor"])
+        for s in range(LOOP["S"]):
+            name = synth.section_name(s)
+            if name not in Detector.custom_sections:
+                Detector.custom_sections[name] = CustomSection(name=name, location="golden")
+            # one append per training step, as detection_section does (straggler.py:343)
+            for v in x[s].astype(np.float64).tolist():
+                Detector.custom_sections[name].cpu_elapsed_times.append(v)
+        rep = Detector.generate_report()
+        d = _report_to_json(rep)
+        if rep is not None:
+            d["stragglers"] = _stragglers_to_json(rep, [0.75, 0.9])
+            d["local_section_summaries"] = _summ_to_json(rep.local_section_summaries)
+        reports.append(d)
+    ret_queue.put((rank, reports))
+    torch.distributed.barrier()
+    Detector.shutdown()
+    torch.distributed.destroy_process_group()
+
+
+def make_loop():
+    import torch.multiprocessing as mp
+
+    W = LOOP["world"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.NamedTemporaryFile(delete=True) as tmpf:
+        store = tmpf.name
+    procs = [ctx.Process(target=_loop_worker, args=(r, W, store, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(W):
+        r, res = q.get(timeout=900)
+        got[r] = res
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(rep is None for r in range(1, W) for rep in got[r])  # gather_on_rank0: only rank 0 reports
+    h = hashlib.sha256()
+    for t in range(LOOP["reports"]):
+        for r in range(W):
+            slow = LOOP["slow_rank"] if t >= LOOP["slow_from"] else -1
+            h.update(synth.loop_samples(r, t, LOOP["S"], LOOP["n"], slow_rank=slow, slow_factor=LOOP["slow_factor"]).tobytes())
+    with open(os.path.join(HERE, "loop.json"), "w") as f:
+        json.dump({"generator": "reference Detector.generate_report x10 on 8 gloo ranks (straggler.py:228-244), "
+                                "inputs synth.loop_samples (BASELINE config #2)",
+                   "config": LOOP, "input_sha256": h.hexdigest(), "rank0_reports": _jsonable(got[0])}, f)
+    print("loop.json:", len(got[0]), "reports")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF_SRC), "reference tree not found; golden vectors can only be regenerated in the build container"
-    which = sys.argv[1:] or ["section", "native", "scoring", "stress"]
+    which = sys.argv[1:] or ["section", "native", "scoring", "stress", "loop"]
     if "native" in which:
         make_native()
     if "section" in which:
@@ -359,3 +433,5 @@ if __name__ == "__main__":
         make_scoring()
     if "stress" in which:
         make_stress()
+    if "loop" in which:
+        make_loop()

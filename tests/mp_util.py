@@ -7,7 +7,7 @@ import traceback
 import torch.multiprocessing as mp
 
 
-def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend):
+def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend, device=None):
     try:
         here = os.path.dirname(os.path.abspath(__file__))
         repo = os.path.dirname(here)
@@ -17,6 +17,9 @@ def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend):
         import torch
 
         torch.set_num_threads(1)
+        if device is not None:  # GPU tests: several ranks share one device, product backend
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(device)
         os.environ["RANK"] = str(rank)
         os.environ["WORLD_SIZE"] = str(world)
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -36,13 +39,14 @@ def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend):
         q.put((rank, "error", traceback.format_exc()))
 
 
-def run_ranks(fn, world, timeout=180, use_oracle_backend=True, **kwargs):
-    """Returns [result of rank 0, rank 1, ...]; raises if any rank failed."""
+def run_ranks(fn, world, timeout=180, use_oracle_backend=True, device=None, **kwargs):
+    """Returns [result of rank 0, rank 1, ...]; raises if any rank failed.  ``use_oracle_backend=False`` +
+    ``device=0``: every rank runs the PRODUCT backend on that GPU (multi-process GPU tests, gloo group)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     with tempfile.NamedTemporaryFile(delete=True) as f:
         store = f.name
-    procs = [ctx.Process(target=_entry, args=(r, world, store, fn, kwargs, q, use_oracle_backend)) for r in range(world)]
+    procs = [ctx.Process(target=_entry, args=(r, world, store, fn, kwargs, q, use_oracle_backend, device)) for r in range(world)]
     for p in procs:
         p.start()
     out = {}

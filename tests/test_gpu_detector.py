@@ -184,3 +184,29 @@ def test_gpu_telemetry_reads_rocm_smi():
         assert 10.0 < s["power_w"] < 2000.0, s
     line = Detector.gpu_telemetry_line()
     assert line.startswith("gpu telemetry: sclk_mhz="), line
+
+
+def test_config2_loop_folded_on_one_gpu_matches_reference():
+    """BASELINE config #2 folded onto one process (8 logical ranks x 4 sections x 100 samples per report, ten reports
+    through one FoldedJob): device history minima across reports, ring reset by every report, cached plan from the
+    second report on -- every report vs the real reference's (loop.json)."""
+    import workers
+    from nvrx_straggler.folded import FoldedJob
+    from util import compare_reports
+
+    g = load_golden("loop.json")
+    cfg = g["config"]
+    names = [synth.section_name(s) for s in range(cfg["S"])]
+    job = FoldedJob(total_ranks=8, section_names=names, ring_cap=8192, node_name="node0")
+    try:
+        for t, exp in enumerate(g["rank0_reports"]):
+            slow = cfg["slow_rank"] if t >= cfg["slow_from"] else -1
+            for r in range(8):
+                job.load(r, synth.loop_samples(r, t, cfg["S"], cfg["n"], slow_rank=slow, slow_factor=cfg["slow_factor"]))
+            rep = job.report()
+            assert job.rings.count(0) == 0
+            got = workers.report_to_plain(rep, (0.75, 0.9))
+            got["rank_to_node"] = exp["rank_to_node"]  # one process holds all 8 logical ranks here
+            compare_reports(got, exp, ("loop-folded", t), rel=1e-4)
+    finally:
+        job.close()

@@ -1,0 +1,81 @@
+"""Several PROCESSES against the real HIP backend on one MI355X (gloo group, ranks share cuda:0).
+
+The multi-rank protocol (name sync mid-run, gather_on_rank0 both ways, None on rank != 0, the exchange rows of every
+rank meeting in one table) runs here against the real statistics / score kernels -- the CPU twins of these tests swap
+in the oracle-backed checker backend.  The exchange itself goes through gloo (a host round trip of the 0.5 KB rows):
+RCCL refuses two ranks on one device, so the RCCL route is covered by the 1-rank ABI test and by bench.py --gpus N.
+"""
+import numpy as np
+import pytest
+
+import workers
+from mp_util import run_ranks
+from util import compare_reports, load_golden
+
+pytestmark = pytest.mark.gpu
+
+_SCENARIOS = load_golden("scoring.json")["scenarios"]
+# one scenario of every world size / option class (the full list runs on the CPU backend in test_host_logic.py)
+_PICK = ["rel_gpu_4ranks_gather1", "rel_gpu_4ranks_gather0", "sections_2ranks_gather1", "sections_2ranks_gather0",
+         "rank_without_kernels", "mixed_8ranks_all_gather", "mixed_8ranks_all_nogather"]
+
+
+@pytest.mark.parametrize("name", _PICK)
+def test_report_generator_on_hip_backend_matches_reference(name):
+    g = next(s for s in _SCENARIOS if s["scenario"]["name"] == name)
+    sc = g["scenario"]
+    res = run_ranks(workers.scoring_scenario, sc["world_size"], timeout=300, use_oracle_backend=False, device=0, scenario=sc)
+    for r in range(sc["world_size"]):
+        for t in range(len(sc["steps"])):
+            compare_reports(res[r]["reports"][t], g["per_rank"][r]["reports"][t], (name, r, t))
+        assert res[r]["ids"] == g["per_rank"][r]["ids"], (name, r)
+
+
+def test_detector_name_change_midway_on_hip_backend():
+    """Cached-plan reports, then ONE rank meets a new section: every rank must leave the planned path together."""
+    res = run_ranks(workers.detector_name_change_midway, 4, timeout=300, use_oracle_backend=False, device=0)
+    ref = run_ranks(workers.detector_name_change_midway, 4, timeout=300)  # CPU checker backend, same protocol
+    for r in range(4):
+        assert res[r]["ids"] == ref[r]["ids"] and res[r]["planned"] == ref[r]["planned"]
+        for t, (a, b) in enumerate(zip(res[r]["reports"], ref[r]["reports"])):
+            assert (a is None) == (b is None), (r, t)
+            if a is not None:
+                assert a["stragglers"] == b["stragglers"] and a["rank_to_node"] == b["rank_to_node"]
+                for key in ("section_relative_perf_scores", "section_individual_perf_scores"):
+                    assert a[key].keys() == b[key].keys()
+                    for n in a[key]:
+                        np.testing.assert_allclose(list(a[key][n].values()), list(b[key][n].values()), rtol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_folded_stress_over_processes_matches_reference(world):
+    """8 logical ranks x 64 sections x 10 000 samples folded onto `world` processes: same scores and flagged sets as the
+    reference's 8-rank run (stress.json, x1.5 variant), first report and cached-plan report alike."""
+    g = load_golden("stress.json")
+    var = next(v for v in g["variants"] if v["name"] == "slow_1.5")
+    res = run_ranks(workers.folded_job_device, world, timeout=400, use_oracle_backend=False, device=0, total_ranks=8, variant=var)
+    exp = g["rank0"]["slow_1.5"]
+    names = list(exp["section_relative_perf_scores"])
+    for rep in res[0]:
+        assert set(rep["section_relative_perf_scores"]) == set(names)
+        for n in names:
+            for r in range(8):
+                e = exp["section_relative_perf_scores"][n][str(r)]
+                assert abs(rep["section_relative_perf_scores"][n][r] - e) <= 1e-4 * abs(e), (n, r)
+        for thr in ("0.75", "0.9"):
+            assert rep["stragglers"][thr]["straggler_sections_relative"] == exp["stragglers"][thr]["straggler_sections_relative"]
+    assert all(rep is None for r in range(1, world) for rep in res[r])
+
+
+def test_config2_loop_ten_reports_on_hip_backend():
+    """BASELINE config #2 on the GPU: 8 processes, the real Detector, one ring push per training step (pinned staging +
+    scatter kernel), a collective report every 100 steps; ten consecutive reports vs the real reference's (1e-4),
+    history-driven individual scores and flagged sets at 0.75 / 0.9 included."""
+    g = load_golden("loop.json")
+    res = run_ranks(workers.detector_loop_config2, 8, timeout=400, use_oracle_backend=False, device=0)
+    assert all(rep is None for r in range(1, 8) for rep in res[r])
+    for t, exp in enumerate(g["rank0_reports"]):
+        compare_reports(res[0][t], exp, ("loop-gpu", t), rel=1e-4)
+        for n, e in exp["local_section_summaries"].items():
+            got = res[0][t]["local_section_summaries"][n]
+            assert got["NUM"] == 100 and got["MED"] == np.float32(e["MED"]) and got["MIN"] == np.float32(e["MIN"]), (t, n)

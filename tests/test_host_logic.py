@@ -1,6 +1,7 @@
 """CPU-only tests of the host side: C-ABI surface, loud failure without a GPU, name mapping, report
 views, and the multi-rank protocol on gloo (world_size 2/4/8) with the oracle-backed checker backend
 injected.  Expected values come from the REAL reference (tests/golden/scoring.json)."""
+import ctypes
 import math
 import os
 import pickle
@@ -13,7 +14,7 @@ import torch
 
 import workers
 from mp_util import run_ranks
-from util import close, load_golden
+from util import close, compare_reports, load_golden
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -32,7 +33,8 @@ def test_library_exports_every_symbol_in_the_header():
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nvrx_abi_version() == 1
+    assert lib.nvrx_abi_version() == _native.NVRX_ABI_VERSION == 2
+    assert lib.nvrx_report_desc_size() == ctypes.sizeof(_native.ReportDesc)
     assert lib.nvrx_last_error() is not None
 
 
@@ -486,27 +488,6 @@ def test_ptl_callback_with_duck_typed_trainer(caplog):
 # --------------------------------------------------------------------------------------------------
 # multi-rank protocol on gloo, against the reference's golden outputs
 # --------------------------------------------------------------------------------------------------
-def _compare_reports(got, exp, tag, rel=1e-6):
-    if exp is None:
-        assert got is None, tag
-        return
-    assert got is not None, tag
-    for key in ("gpu_relative_perf_scores", "gpu_individual_perf_scores"):
-        assert set(map(str, got[key].keys())) == set(exp[key].keys()), (tag, key)
-        for r, v in got[key].items():
-            assert close(v, exp[key][str(r)], rel=rel), (tag, key, r, v, exp[key][str(r)])
-    for key in ("section_relative_perf_scores", "section_individual_perf_scores"):
-        assert set(got[key].keys()) == set(exp[key].keys()), (tag, key, got[key].keys(), exp[key].keys())
-        for n, per_rank in got[key].items():
-            assert set(map(str, per_rank.keys())) == set(exp[key][n].keys()), (tag, key, n)
-            for r, v in per_rank.items():
-                assert close(v, exp[key][n][str(r)], rel=rel), (tag, key, n, r, v, exp[key][n][str(r)])
-    assert {str(k): v for k, v in got["rank_to_node"].items()} == exp["rank_to_node"], tag
-    assert got["gather_on_rank0"] == exp["gather_on_rank0"] and got["rank"] == exp["rank"]
-    for thr, e in exp.get("stragglers", {}).items():
-        assert got["stragglers"][thr] == e, (tag, thr)
-
-
 _SCENARIOS = load_golden("scoring.json")["scenarios"]
 
 
@@ -520,7 +501,7 @@ def test_report_generator_matches_reference_on_gloo_ranks(idx):
     res = run_ranks(workers.scoring_scenario, sc["world_size"], scenario=sc)
     for r in range(sc["world_size"]):
         for t in range(len(sc["steps"])):
-            _compare_reports(res[r]["reports"][t], g["per_rank"][r]["reports"][t], (sc["name"], r, t))
+            compare_reports(res[r]["reports"][t], g["per_rank"][r]["reports"][t], (sc["name"], r, t))
         assert res[r]["ids"] == g["per_rank"][r]["ids"], (sc["name"], r)
 
 
@@ -630,3 +611,20 @@ def test_steady_state_plan_and_name_change_on_one_rank():
     # individual scores remember the best median: b doubled on rank 0 (4 -> 8) and x4 on rank 1
     assert reps[5]["section_individual_perf_scores"]["b"] == {0: 0.5, 1: 0.25}
     assert reps[5]["stragglers"]["0.75"]["straggler_sections_individual"] == {"b": [0, 1]}
+
+
+def test_config2_loop_ten_reports_match_reference():
+    """BASELINE config #2 (8 ranks, 4 sections, a report every 100 steps, 10 reports through one Detector) against
+    the real reference's reports: every score within 1e-4 (history-driven individual scores included), identical
+    flagged sets at 0.75 / 0.9, rings emptied by every report.  Host logic on the CPU checker backend; the GPU twin
+    is tests/test_gpu_multiproc.py."""
+    g = load_golden("loop.json")
+    res = run_ranks(workers.detector_loop_config2, g["config"]["world"], timeout=300)
+    assert all(rep is None for r in range(1, 8) for rep in res[r])
+    for t, exp in enumerate(g["rank0_reports"]):
+        compare_reports(res[0][t], exp, ("loop", t), rel=1e-4)
+        for n, e in exp["local_section_summaries"].items():
+            got = res[0][t]["local_section_summaries"][n]
+            assert got["NUM"] == e["NUM"] == 100 and got["MED"] == np.float32(e["MED"]), (t, n)
+    flagged = [res[0][t]["stragglers"]["0.9"]["straggler_sections_relative"] for t in range(10)]
+    assert all(not f for f in flagged[:5]) and all(set(f) == {f"section_{s:03d}" for s in range(4)} for f in flagged[5:])

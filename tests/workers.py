@@ -258,3 +258,55 @@ def detector_reports_pickle(rank, world):
     finally:
         Detector.shutdown()
     return out
+
+
+def detector_loop_config2(rank, world, device=None):
+    """BASELINE config #2 through the real ``Detector``: 4 sections, one sample appended per training step (the way
+    ``detection_section`` does), a collective ``generate_report()`` every 100 steps, ten reports; rank 3 runs 1.2x
+    slower from report 5 on.  History minima live across reports, every report empties the rings."""
+    import synth
+    from nvrx_straggler import Detector, Statistic
+
+    cfg = {"S": 4, "n": 100, "reports": 10, "slow_rank": 3, "slow_factor": 1.2, "slow_from": 5}
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name=f"node{rank}")
+    out = []
+    try:
+        names = [synth.section_name(s) for s in range(cfg["S"])]
+        for name in names:  # create the sections (one untimed entry each), then start from empty rings
+            with Detector.detection_section(name, profile_cuda=False):
+                pass
+        Detector._reset_sections_elapseds()
+        for t in range(cfg["reports"]):
+            slow = cfg["slow_rank"] if t >= cfg["slow_from"] else -1
+            x = synth.loop_samples(rank, t, cfg["S"], cfg["n"], slow_rank=slow, slow_factor=cfg["slow_factor"])
+            for i in range(cfg["n"]):
+                for s, name in enumerate(names):
+                    Detector.custom_sections[name].cpu_elapsed_times.append(float(x[s, i]))
+            rep = Detector.generate_report()
+            assert all(len(Detector.custom_sections[n].cpu_elapsed_times) == 0 for n in names)
+            d = report_to_plain(rep, (0.75, 0.9))
+            if d is not None:
+                d["local_section_summaries"] = {n: {str(k): v for k, v in rep.local_section_summaries[n].items()} for n in names}
+            out.append(d)
+        return out
+    finally:
+        Detector.shutdown()
+
+
+def folded_job_device(rank, world, total_ranks, variant):
+    """FoldedJob over gloo ranks that SHARE one GPU, real HIP backend: device rings, statistics kernel, host
+    round trip of the exchange rows (gloo), score kernel."""
+    import synth
+    from nvrx_straggler.folded import FoldedJob
+
+    names = [synth.section_name(s) for s in range(variant["S"])]
+    job = FoldedJob(total_ranks=total_ranks, section_names=names, ring_cap=8192, node_name=f"node{rank}")
+    try:
+        out = []
+        for rep_no in range(2):  # the second report runs the cached steady-state plan
+            for lr, r in enumerate(job.logical_ranks()):
+                job.load(lr, synth.stress_samples(r, variant["S"], variant["n"], variant["slow_rank"], variant["slow_factor"]))
+            out.append(report_to_plain(job.report(), (0.75, 0.9)))
+        return out
+    finally:
+        job.close()
