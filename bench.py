@@ -124,7 +124,7 @@ def _cpu_baseline(reps: int):
     }
 
 
-def _per_step_overhead(world: int, rank: int, steps: int, blocks: int):
+def _per_step_overhead(world: int, rank: int, steps: int, blocks: int, asynchronous: bool = False):
     """BASELINE.json config #4: the real ``Detector`` around a fixed GPU workload (10 x 4096^3 bf16
     matmul), ``profile_cuda=True`` (hipEvent pair per entry), individual scores, a collective
     ``generate_report()`` EVERY step.  A/B blocks of ``steps`` steps alternate in the same process;
@@ -145,12 +145,20 @@ def _per_step_overhead(world: int, rank: int, steps: int, blocks: int):
             dist.barrier()
         torch.cuda.synchronize()
 
-    Detector.initialize(scores_to_compute=["individual_perf_scores"], gather_on_rank0=True, node_name=f"node{rank}")
+    Detector.initialize(scores_to_compute=["individual_perf_scores"], gather_on_rank0=True, node_name=f"node{rank}",
+                        asynchronous=asynchronous)
+    held = [None]
     try:
         def step_with():
             with Detector.detection_section("train_step", profile_cuda=True):
                 work()
-            return Detector.generate_report()
+            rep = Detector.generate_report()
+            if asynchronous:
+                # the report of step t is consumed during step t+1 (one-step-late detection); it is read for real
+                prev, held[0] = held[0], rep
+                if prev is not None:
+                    prev.identify_stragglers()
+            return rep
 
         for _ in range(10):
             work()
@@ -183,7 +191,9 @@ def _per_step_overhead(world: int, rank: int, steps: int, blocks: int):
         "steps_per_block": steps,
         "blocks": blocks,
         "workload": "Detector.detection_section(profile_cuda=True) around 10 x matmul(4096^2, bf16) + generate_report() "
-                    "every step, individual_perf_scores, gather_on_rank0",
+                    "every step, individual_perf_scores, gather_on_rank0"
+                    + (", asynchronous=True: report t is enqueued at step t and read (identify_stragglers) during step t+1"
+                       if asynchronous else ""),
     }
 
 
@@ -435,10 +445,12 @@ def main():
         host_inputs = {"us_per_report": round(us, 1), "host_bytes": nbytes, "gb_per_s": round(nbytes / us / 1e3, 2),
                        "note": "samples start in pageable host memory; H2D + ring appends + report; not the headline value"}
 
-    overhead = None
+    overhead = overhead_async = None
     if not args.no_overhead:
         job.backend.synchronize()
         overhead = _per_step_overhead(world, rank, args.overhead_steps, args.overhead_blocks)
+        if world == 1:
+            overhead_async = _per_step_overhead(world, rank, args.overhead_steps, args.overhead_blocks, asynchronous=True)
 
     ex_us = exchange.get("us_median", 0.0) if exchange else 0.0
     times = torch.tensor([elapsed, elapsed_instr, ex_us], dtype=torch.float64, device="cuda")
@@ -495,6 +507,8 @@ def main():
             out["detector_report"] = detector_leg
         if overhead is not None:
             out["per_step_overhead"] = overhead
+        if overhead_async is not None:
+            out["per_step_overhead_async"] = overhead_async
         if host_inputs is not None:
             out["host_inputs"] = host_inputs
         if exchange is not None:

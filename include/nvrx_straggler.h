@@ -221,7 +221,9 @@ typedef struct nvrx_report_desc {
                                  the host does not block), or NULL; takes the place of torch.cuda.synchronize()
                                  in straggler.py:234 for the collectives the caller has enqueued there */
     int32_t order_after_enabled; /* 0: order_after_stream is ignored */
-    int32_t reserved;
+    int32_t guard_rings;      /* asynchronous reports (h_seq_word == NULL, the caller polls later): nonzero makes later
+                                 device-side ring writers on other streams (nvrx_stamp_end) wait, on the device, for this
+                                 report's statistics kernel */
 } nvrx_report_desc;
 int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *desc, void *stream);
 /* sizeof(nvrx_report_desc) as this library was compiled: lets an FFI binding check its own struct layout. */

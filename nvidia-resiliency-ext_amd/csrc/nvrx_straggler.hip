@@ -1203,6 +1203,15 @@ struct nvrx_ctx {
     std::vector<hipStream_t> stamp_streams;  // user streams with stamp kernels the rings have not been ordered after
     hipEvent_t stamp_ev = nullptr;
     hipEvent_t order_ev = nullptr;  // nvrx_report: report stream ordered after the caller's stream
+    // asynchronous reports: the statistics kernel of a report the host did not wait for may still be reading the
+    // rings; device-side writers on other streams (k_stamp_end) are ordered after it with this event
+    hipEvent_t report_ev = nullptr;
+    uint64_t report_epoch = 0;  // bumped by every guarded report
+    struct StreamEpoch {
+        hipStream_t stream;
+        uint64_t epoch;
+    };
+    std::vector<StreamEpoch> stream_epochs;
 
     std::mutex mu;
 };
@@ -1458,6 +1467,7 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     CTX_TRY(hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->stamp_ev, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
+    CTX_TRY(hipEventCreateWithFlags(&ctx->report_ev, hipEventDisableTiming));
     CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
     CTX_TRY(hipMemset(ctx->d_stamps, 0, nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
     {
@@ -1498,6 +1508,7 @@ int nvrx_ctx_destroy(nvrx_ctx *ctx) {
     if (ctx->copy_done) (void)hipEventDestroy(ctx->copy_done);
     if (ctx->stamp_ev) (void)hipEventDestroy(ctx->stamp_ev);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
+    if (ctx->report_ev) (void)hipEventDestroy(ctx->report_ev);
     if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
     delete ctx;
     return NVRX_OK;
@@ -1763,6 +1774,20 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
         }
         ctx->counts_dirty = true;
         hipStream_t st = as_stream(stream);
+        if (ctx->report_epoch) {
+            // an asynchronous report may still be reading the rings: this stream's ring writes follow its statistics kernel
+            nvrx_ctx::StreamEpoch *se = nullptr;
+            for (auto &e : ctx->stream_epochs)
+                if (e.stream == st) se = &e;
+            if (!se) {
+                ctx->stream_epochs.push_back({st, 0});
+                se = &ctx->stream_epochs.back();
+            }
+            if (se->epoch < ctx->report_epoch) {
+                HIP_TRY(hipStreamWaitEvent(st, ctx->report_ev, 0));
+                se->epoch = ctx->report_epoch;
+            }
+        }
         hipLaunchKernelGGL(k_stamp_end, dim3(1), dim3(1), 0, st, ctx->d_stamps + slot, ctx->us_per_tick, dst_gpu, dst_cpu,
                            cpu_value);
         HIP_TRY(hipGetLastError());
@@ -1831,6 +1856,11 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     }
     int rc = nvrx_report_local(ctx, d->d_stats, d->d_send, d->K, d->S, d->names_ok, d->rows_active, stream);
     if (rc) return rc;
+    if (d->guard_rings) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        HIP_TRY(hipEventRecord(ctx->report_ev, as_stream(stream)));
+        ctx->report_epoch++;
+    }
     if (exchanging) {
         // ncclAllGather(sendbuff, recvbuff, sendcount, ncclFloat32 = 7, comm, stream), enqueued between the two
         // kernels on the same stream: this rank's rows -> every rank's [R, L] table (reporting.py:281,397)

@@ -237,6 +237,14 @@ class HipBackend:
                 self.retire_workspace(ws)
                 _native.check(rc)
 
+    def wait_seq(self, ws: Workspace, seq: int) -> None:
+        """Block until the report that was enqueued with sequence number ``seq`` has published its results."""
+        timeout = report_timeout_s()
+        rc = self.lib.nvrx_poll_u32(ws.h_seq, seq, timeout if timeout > 0 else 1e30)
+        if rc < 0:
+            self.retire_workspace(ws)
+            _native.check(rc)
+
     def retire_workspace(self, ws: Workspace) -> None:
         """After a timed-out wait the kernels of ``ws`` may still be queued behind a collective: the workspace
         must neither be reused (stale sequence / ticket state) nor freed under them, so it is parked for good."""
@@ -399,15 +407,19 @@ class HipRings:
             _native.check(rc)
 
     def report_fused(self, ws: Workspace, rows_active: int, stats_rows: int, do_indiv: bool, do_rel: bool,
-                     thresholds: Sequence[float], direct=None) -> None:
+                     thresholds: Sequence[float], direct=None, names_ok: bool = True, wait: bool = True,
+                     order_after: Optional[int] = None) -> int:
         """The whole report in one C call (``nvrx_report``): flush -> statistics kernel -> [``ncclAllGather`` of the
         exchange rows through ``direct``] -> score kernel -> wait for the completion word.  On return
-        ``ws.scores / flags / meta / stats`` hold this report's values."""
+        ``ws.scores / flags / meta / stats`` hold this report's values.  ``wait=False`` only enqueues (asynchronous
+        report): the caller waits for the returned sequence number with ``backend.wait_seq`` later, and ring writers on
+        other streams are ordered after the statistics kernel on the device."""
         d = ws.desc
-        key = (rows_active, stats_rows, do_indiv, do_rel, thresholds, direct)
+        key = (rows_active, stats_rows, do_indiv, do_rel, thresholds, direct, names_ok, wait)
         if ws.desc_key != key:  # cold: the switches of this shape changed
             d.rows_active, d.stats_rows = rows_active, min(stats_rows, ws.stats_rows)
             d.do_indiv, d.do_rel = int(do_indiv), int(do_rel)
+            d.names_ok = int(names_ok)
             for i in range(4):
                 d.thresholds[i] = float(thresholds[i])
             if direct is not None:
@@ -415,7 +427,13 @@ class HipRings:
             else:
                 d.allgather_fn, d.comm = None, None
             d.timeout_s = report_timeout_s()
+            d.h_seq_word = ws.h_seq if wait else None
+            d.guard_rings = 0 if wait else 1
             ws.desc_key = key
+        if order_after is not None:  # the caller's current stream: the report follows what is enqueued there
+            d.order_after_stream, d.order_after_enabled = order_after, 1
+        elif d.order_after_enabled:
+            d.order_after_enabled = 0
         if not ws.send_initialised:
             self.backend.send_init(ws)
         d.seq = max(d.seq, ws.seq)
@@ -425,6 +443,7 @@ class HipRings:
             if rc == _native.ERR_TIMEOUT:
                 self.backend.retire_workspace(ws)
             _native.check(rc)
+        return ws.seq
 
     def peek_stats(self) -> np.ndarray:
         """Statistics of every used row right now ([rows_used, 8] on the host); exchanges nothing and

@@ -16,9 +16,19 @@ pair, whose elapsed time is harvested by the host when the events complete).  St
 population stddev; CuptiProfiler.cpp:44-74) and are computed by the HIP statistics kernel.
 Granularity is therefore one timing row per profiled REGION rather than per kernel name
 (documented deviation; per-kernel names are SURVEY section 8(f) row 1).
+
+What the region granularity CANNOT do: the reference drops ``ncclDev*`` kernels from the GPU score
+(reporting.py:330-336) because a collective's duration is the time spent waiting for the slowest peer.  A region
+timed as a whole includes whatever collectives (and stream idle gaps) fall inside it, so in a synchronous
+multi-rank job the regions of all ranks equalise, ``gpu_relative_perf_scores`` sits near 1.0 for everybody and a
+slow GPU can go unflagged, while a host-bound rank looks like a slow GPU.  Keep collectives OUT of
+``profile_cuda=True`` sections in this mode, or select ``NVRX_GPU_TIMING=kernels`` (rocprofiler-sdk kernel
+records, per-kernel keys, ``ncclDev*`` excluded as in the reference).  A multi-rank job that opens a GPU-timed
+region in region mode gets this as a one-time warning.
 """
 from __future__ import annotations
 
+import logging
 import math
 import os
 import weakref
@@ -28,6 +38,28 @@ from . import _native
 from . import backend as _backend_mod
 
 DEFAULT_KEY = "gpu_region"
+_log = logging.getLogger(__name__)
+_warned_region_mode = False
+
+
+def _warn_region_mode_once() -> None:
+    """One-time notice for multi-rank jobs: see the module docstring (collectives inside a region-timed section)."""
+    global _warned_region_mode
+    if _warned_region_mode:
+        return
+    _warned_region_mode = True
+    try:
+        import torch.distributed as dist
+
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:  # noqa: BLE001
+        multi = False
+    if multi:
+        _log.warning(
+            "nvrx straggler: GPU time is measured per profiled REGION (NVRX_GPU_TIMING=%s). Collectives inside a "
+            "profile_cuda=True section add peer-wait time to it and cannot be excluded the way the reference excludes "
+            "ncclDev* kernels; relative GPU scores may flatten. Keep collectives outside GPU-timed sections or set "
+            "NVRX_GPU_TIMING=kernels.", os.environ.get("NVRX_GPU_TIMING", "stamp"))
 
 
 class KernelStats:
@@ -100,6 +132,8 @@ class CuptiProfiler:
         if self._started:
             return  # reference prints "subsequent call" and carries on (CuptiProfiler.cpp:121-123)
         row = self._rings.row_for(_native.KIND_KERNEL, key)
+        if not _warned_region_mode:
+            _warn_region_mode_once()
         if self._stamps:
             self._rings.stamp_begin(row, self._stream_handle())
         else:

@@ -80,6 +80,11 @@ class DirectAllGather:
         if rc != 0:
             raise RuntimeError(f"ncclAllGather failed: {self._lib.ncclGetErrorString(rc).decode()}")
 
+    def exchange(self, ws, backend):
+        """The report's exchange for workspace ``ws`` on the backend's stream; returns the gathered table."""
+        self.all_gather(ws.send_ptr, ws.table_ptr, ws.local_ranks * ws.L, backend.stream_handle)
+        return ws.table
+
     def close(self) -> None:
         if self._comm is not None:
             try:

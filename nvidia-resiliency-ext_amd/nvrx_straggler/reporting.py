@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import collections
 import dataclasses
+import threading
 import time
 from typing import Any, Dict, Iterator, List, Mapping, Optional, Sequence, Tuple
 
@@ -60,15 +61,57 @@ def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray) -> Dict[str
     return out
 
 
+class _PendingBlock:
+    """Result block of a report the host has not waited for (asynchronous reports): the kernels are enqueued, the
+    pinned block fills in when they run.  ``wait()`` polls the completion word and takes the private copy; the
+    generator settles the block before the workspace is used again, a ``Report`` settles it on first read."""
+
+    __slots__ = ("backend", "ws", "seq", "blob", "lock")
+
+    def __init__(self, backend, ws, seq: int):
+        self.backend, self.ws, self.seq = backend, ws, seq
+        self.blob: Optional[np.ndarray] = None
+        self.lock = threading.Lock()
+
+    def wait(self) -> np.ndarray:
+        with self.lock:
+            if self.blob is None:
+                self.backend.wait_seq(self.ws, self.seq)
+                self.blob = self.ws.host_block()
+                self.backend = self.ws = None  # nothing of the live workspace is referenced any more
+        return self.blob
+
+
 class _ScoreSource:
     """What a steady-state report keeps of the result block: a private copy of the score / statistics
     arrays plus the (shared, immutable) name tables of the plan.  The six mapping fields of ``Report`` are
     built from it as PLAIN dicts the first time each one is read; a report whose scores are only
-    thresholded (``identify_stragglers`` with the kernel's thresholds) never builds any."""
+    thresholded (``identify_stragglers`` with the kernel's thresholds) never builds any.  For an asynchronous
+    report the arrays themselves are cut out of the (then awaited) result block on first use."""
 
-    __slots__ = ("scores", "stats", "S", "ranks", "names", "cols", "has_rel", "has_indiv", "section_rows", "kernel_rows")
+    __slots__ = ("scores", "stats", "flags", "S", "ranks", "names", "cols", "has_rel", "has_indiv", "section_rows",
+                 "kernel_rows", "pending", "layout")
+
+    def __init__(self):
+        self.scores = self.stats = self.flags = None
+        self.pending: Optional[_PendingBlock] = None
+        self.layout = None
+
+    def cut(self, blob: np.ndarray) -> None:
+        """Views of this report's scores / flags / statistics inside a private copy of the result block."""
+        off_s, off_f, off_t, R, W, lo, hi, stats_rows = self.layout
+        self.scores = blob[off_s : off_s + R * W * 4].view(np.float32).reshape(R, W)[lo:hi]
+        self.flags = blob[off_f : off_f + R * W].reshape(R, W)[lo:hi]
+        self.stats = blob[off_t : off_t + stats_rows * 32].view(np.float32).reshape(stats_rows, 8)
+
+    def ensure(self) -> "_ScoreSource":
+        if self.scores is None and self.pending is not None:
+            self.cut(self.pending.wait())
+            self.pending = None
+        return self
 
     def build(self, field: str):
+        self.ensure()
         S = self.S
         if field == "gpu_relative_perf_scores":
             return dict(zip(self.ranks, self.scores[:, 1].tolist())) if self.has_rel else {}
@@ -212,13 +255,14 @@ class Report:
 
 class _DeviceFlags:
     """Below-threshold bytes written by the score kernel, with the thresholds they were computed for.
-    Holds a private ndarray (never a view of the live result block, never a callable): picklable."""
+    Holds a private ndarray (never a view of the live result block, never a callable): picklable.  ``flags`` may
+    be given as a ``_ScoreSource`` whose block is still in flight; it is resolved on first use."""
 
     __slots__ = ("thresholds", "flags", "ranks", "names", "cols", "S", "has_rel", "has_indiv")
 
-    def __init__(self, thresholds, flags: np.ndarray, ranks, names, cols, S, has_rel, has_indiv):
+    def __init__(self, thresholds, flags, ranks, names, cols, S, has_rel, has_indiv):
         self.thresholds = tuple(float(t) for t in thresholds)  # (gpu_rel, sec_rel, gpu_indiv, sec_indiv)
-        self.flags = flags  # ndarray [ranks, 2+2S] u8
+        self.flags = flags  # ndarray [ranks, 2+2S] u8, or the _ScoreSource that will hold it
         self.ranks = ranks
         self.names = names
         self.cols = cols if isinstance(cols, dict) else dict(zip(names, cols))
@@ -226,7 +270,14 @@ class _DeviceFlags:
         self.has_rel = has_rel
         self.has_indiv = has_indiv
 
+    def _array(self) -> np.ndarray:
+        f = self.flags
+        if isinstance(f, _ScoreSource):
+            f = self.flags = f.ensure().flags
+        return f
+
     def __getstate__(self):
+        self._array()
         return {k: getattr(self, k) for k in self.__slots__}
 
     def __setstate__(self, state) -> None:
@@ -240,7 +291,7 @@ class _DeviceFlags:
         return [self.ranks[int(i)] for i in np.nonzero(column)[0]]
 
     def decode(self):
-        f, S = self.flags, self.S
+        f, S = self._array(), self.S
         gi = self._ranks_of(f[:, 0]) if self.has_indiv else []
         gr = self._ranks_of(f[:, 1]) if self.has_rel else []
         if not f[:, 2:].any():  # the common case: no section of any rank is flagged
@@ -262,10 +313,16 @@ class ReportGenerator:
         node_name: name of this node in ``rank_to_node``.
         thresholds: (gpu_rel, section_rel, gpu_indiv, section_indiv) the score kernel pre-computes
             straggler flags for (default 0.75 each, the ``identify_stragglers`` defaults).
+        asynchronous: steady-state ring reports are only ENQUEUED (statistics kernel, collective, score kernel on
+            the detector's stream) and the returned ``Report`` waits for them when it is first read, so the training
+            loop never stalls on a report.  Not in the reference, whose ``generate_report`` is synchronous; two
+            visible differences: ``generate_report_elapsed_time`` is the enqueue time, and a name that first appears
+            on some rank enters the reports one report later (the name exchange is a host collective and runs at the
+            start of the next ``generate_report``, when every rank is there).
     """
 
     def __init__(self, scores_to_compute, gather_on_rank0=True, pg=None, node_name="<notset>",
-                 thresholds: Sequence[float] = _backend_mod.DEFAULT_THRESHOLDS) -> None:
+                 thresholds: Sequence[float] = _backend_mod.DEFAULT_THRESHOLDS, asynchronous: bool = False) -> None:
         self.is_computing_rel_scores = "relative_perf_scores" in scores_to_compute
         self.is_computing_indiv_scores = "individual_perf_scores" in scores_to_compute
         self.gather_on_rank0 = gather_on_rank0
@@ -291,6 +348,10 @@ class ReportGenerator:
         # collectively on the first multi-rank report, None = stay on torch.distributed
         self._direct = None
         self._direct_tried = False
+        # asynchronous reports (ring path only): generate_report_from_rings enqueues the report and returns a Report
+        # that waits for the device on first read; the block in flight is settled before the next report starts
+        self.asynchronous = bool(asynchronous)
+        self._inflight: Optional[_PendingBlock] = None
 
     # ---- pieces kept from the reference's host logic ----------------------------------------------
     @staticmethod
@@ -327,18 +388,23 @@ class ReportGenerator:
         from . import rccl_direct
 
         be = _backend_mod.get_backend()
-        self._direct = rccl_direct.create(self.group, getattr(be.device, "index", None))
+        maker = getattr(be, "create_direct_exchange", None)  # a test backend may bring its own in-call exchange
+        self._direct = maker(self.group) if maker is not None else rccl_direct.create(self.group, getattr(be.device, "index", None))
 
     def _exchange(self, be, ws):
         """The report's one collective: this rank's rows -> the [R, L] table, on the backend's stream."""
         if self._direct is not None:
-            self._direct.all_gather(ws.send_ptr, ws.table_ptr, ws.local_ranks * ws.L, be.stream_handle)
-            return ws.table
+            return self._direct.exchange(ws, be)
         with be.stream_context():  # the collective must queue behind the statistics kernel
             return dist_utils.all_gather_rows(ws.send, ws.table, self.group)
 
     def close(self) -> None:
         """Release the direct-exchange communicator (collective-free; safe to call more than once)."""
+        if self._inflight is not None:
+            try:
+                self._settle_inflight()
+            except Exception:  # noqa: BLE001  (shutdown path: a report that never completed must not mask it)
+                self._inflight = None
         if self._direct is not None:
             self._direct.close()
             self._direct = None
@@ -471,18 +537,48 @@ class ReportGenerator:
         self._ring_gid_state = None  # the general path must re-derive its own view if it runs next
         return plan
 
-    def _report_from_plan(self, plan, rings, t0, order_after=None):
+    def _settle_inflight(self) -> bool:
+        """Wait for the asynchronous report still in flight (if any) before its workspace is touched again.
+        Returns True when that report's exchange showed a rank with names that have no id yet: every rank sees the
+        same table, so every rank learns it here, at the same point of the program, and goes through the name sync."""
+        pend = self._inflight
+        if pend is None:
+            return False
+        self._inflight = None
+        blob = pend.wait()
+        return int(blob[0:4].view(np.uint32)[0]) != 1
+
+    def _source_for(self, plan, ws) -> _ScoreSource:
+        src = _ScoreSource()
+        src.layout = (ws._off_scores, ws._off_flags, ws._off_stats, ws.R, ws.W, plan.row_lo, plan.row_hi, plan.stats_needed)
+        src.S, src.ranks, src.names, src.cols = ws.S, plan.ranks, plan.names, plan.cols
+        src.has_rel, src.has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
+        src.section_rows, src.kernel_rows = plan.section_rows, plan.kernel_rows
+        return src
+
+    def _report_from_plan(self, plan, rings, t0, order_after=None, names_ok: bool = True):
         """The steady-state report: ONE C call (statistics kernel, the collective, score kernel, wait), one host
-        copy of the result block, mappings built on first read."""
+        copy of the result block, mappings built on first read.  Asynchronous generators only enqueue."""
         be = _backend_mod.get_backend()
         ws = plan.ws
         multi = self.world_size > 1 and self._exchanged()
-        if plan.fused and (not multi or self._direct is not None):
+        fused = plan.fused and (not multi or self._direct is not None)
+        if fused:
             # ONE C call: flush -> statistics kernel -> [ncclAllGather] -> score kernel -> completion word
-            if multi and order_after is not None:
-                ws.desc.order_after_stream, ws.desc.order_after_enabled = order_after, 1
-            rings.report_fused(ws, plan.rows_used, plan.stats_needed, self.is_computing_indiv_scores,
-                               self.is_computing_rel_scores, self.thresholds, self._direct if multi else None)
+            wait = not self.asynchronous
+            seq = rings.report_fused(ws, plan.rows_used, plan.stats_needed, self.is_computing_indiv_scores,
+                                     self.is_computing_rel_scores, self.thresholds, self._direct if multi else None,
+                                     names_ok=names_ok, wait=wait, order_after=order_after if multi else None)
+            if not wait:
+                pend = self._inflight = _PendingBlock(be, ws, seq)
+                if self.gather_on_rank0 and self.rank != 0:
+                    return None
+                src = self._source_for(plan, ws)
+                src.pending = pend
+                flags = _DeviceFlags(self.thresholds, src, plan.ranks, plan.names, plan.cols, ws.S, src.has_rel, src.has_indiv)
+                return Report._from_device(
+                    src, self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
+                    (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank, flags)
         elif multi:
             rings.report_local(ws, True, rows_active=plan.rows_used)
             table = self._exchange(be, ws)
@@ -496,18 +592,9 @@ class ReportGenerator:
             return False  # another rank met a new name: fall back to the general (name-syncing) path
         if self.gather_on_rank0 and self.rank != 0:
             return None
-        S, W, R = ws.S, ws.W, ws.R
-        blob = ws.host_block()  # one memcpy out of the pinned block; everything below views into the copy
-        lo, hi = plan.row_lo, plan.row_hi
-        off_s, off_f, off_t = ws._off_scores, ws._off_flags, ws._off_stats
-        src = _ScoreSource()
-        src.scores = blob[off_s : off_s + R * W * 4].view(np.float32).reshape(R, W)[lo:hi]
-        src.stats = blob[off_t : off_t + plan.stats_needed * 32].view(np.float32).reshape(plan.stats_needed, 8)
-        src.S, src.ranks, src.names, src.cols = S, plan.ranks, plan.names, plan.cols
-        src.has_rel, src.has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
-        src.section_rows, src.kernel_rows = plan.section_rows, plan.kernel_rows
-        flags = _DeviceFlags(self.thresholds, blob[off_f : off_f + R * W].reshape(R, W)[lo:hi], plan.ranks, plan.names,
-                             plan.cols, S, src.has_rel, src.has_indiv)
+        src = self._source_for(plan, ws)
+        src.cut(ws.host_block())  # one memcpy out of the pinned block; the report's arrays are views into the copy
+        flags = _DeviceFlags(self.thresholds, src.flags, plan.ranks, plan.names, plan.cols, ws.S, src.has_rel, src.has_indiv)
         return Report._from_device(
             src, self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
             (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank, flags)
@@ -524,6 +611,8 @@ class ReportGenerator:
         t0 = time.perf_counter_ns()
         self.world_size = dist_utils.get_world_size(self.group)
         self.rank = dist_utils.get_rank(self.group)
+        if self._inflight is not None:
+            self._settle_inflight()
         if not self._direct_tried:
             self._maybe_create_direct_exchange()
         kernel_summaries = self._filter_out_nccl_kernels(kernel_summaries)
@@ -577,12 +666,23 @@ class ReportGenerator:
                self._private_mapper.version, self.world_size, self.rank, rings.rows_used, local_ranks, id(rings))
         plan = self._ring_plan
         resync_first = False
+        if self._inflight is not None and self._settle_inflight():
+            # the previous (asynchronous) report's exchange carried an "ids missing" flag: every rank is here now
+            self._ring_plan = plan = None
+            resync_first = True
         if plan is not None and plan.key == key:
             out = self._report_from_plan(plan, rings, t0, order_after)
             if out is not False:
                 return out
             self._ring_plan = None
             resync_first = True  # some OTHER rank met a new name during this report's exchange
+        elif (plan is not None and self.asynchronous and plan.fused and plan.key[6:8] == key[6:8] and plan.key[9:] == key[9:]
+              and not plan.mapper.has_all_names(list(kernel_rows.keys()), list(section_rows.keys()))):
+            # asynchronous + a name this rank has no id for: the other ranks will not wait inside this report, so the
+            # name exchange cannot happen now.  Run the OLD plan (the new rows are not exchanged yet) with the
+            # "ids missing" flag in this rank's row; every rank meets it when it settles this report and they all
+            # sync names at the start of the next one.
+            return self._report_from_plan(plan, rings, t0, order_after, names_ok=False)
         kernel_rows = {k: r for k, r in kernel_rows.items() if _NCCL_MARKER not in k} if any(
             _NCCL_MARKER in k for k in kernel_rows) else kernel_rows
         self._maybe_gather_rank_to_node()

@@ -150,6 +150,7 @@ class Detector:
         report_time_interval: float = 60,
         node_name: Optional[str] = None,
         max_rows: int = 256,
+        asynchronous: Optional[bool] = None,
     ):
         """
         Args:
@@ -159,6 +160,10 @@ class Detector:
             report_time_interval: seconds between reports for ``generate_report_if_interval_elapsed``.
             node_name: name of this node in reports (default: ``socket.gethostname()``).
             max_rows: timing rows (sections + GPU-timed regions) the device rings can hold.
+            asynchronous: ``generate_report`` only enqueues the report on the detector's HIP stream and returns a
+                ``Report`` that waits for the device when it is first read, so the training loop never stalls on a
+                report (see ``ReportGenerator``).  Default: the ``NVRX_ASYNC_REPORT`` environment variable, else
+                False = the reference's synchronous behaviour.
         """
         assert not cls.initialized
 
@@ -175,10 +180,13 @@ class Detector:
         cls.rings = _backend_mod.get_backend().make_rings(1, int(max_rows), ring_cap)
         cls.cupti_manager = CuptiManager(statsMaxLenPerKernel=ring_cap, rings=cls.rings)
         cls.cupti_manager.initialize()
+        if asynchronous is None:
+            asynchronous = os.environ.get("NVRX_ASYNC_REPORT", "0") not in ("", "0")
         cls.reporter = ReportGenerator(
             scores_to_compute=cls.scores_to_compute,
             gather_on_rank0=gather_on_rank0,
             node_name=(node_name if node_name else socket.gethostname()),
+            asynchronous=asynchronous,
         )
         cls.report_interval_tracker = ReportIntervalTracker(
             time_interval=report_time_interval, profiling_interval=profiling_interval

@@ -7,7 +7,7 @@ import traceback
 import torch.multiprocessing as mp
 
 
-def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend, device=None):
+def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend, device=None, backend_kwargs=None):
     try:
         here = os.path.dirname(os.path.abspath(__file__))
         repo = os.path.dirname(here)
@@ -29,7 +29,7 @@ def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend, device=None):
             from nvrx_straggler import backend
             from oracle_backend import OracleBackend
 
-            backend.set_backend(OracleBackend())
+            backend.set_backend(OracleBackend(**(backend_kwargs or {})))
         res = fn(rank, world, **kwargs)
         q.put((rank, "ok", res))
         if world > 1:
@@ -39,14 +39,14 @@ def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend, device=None):
         q.put((rank, "error", traceback.format_exc()))
 
 
-def run_ranks(fn, world, timeout=180, use_oracle_backend=True, device=None, **kwargs):
+def run_ranks(fn, world, timeout=180, use_oracle_backend=True, device=None, backend_kwargs=None, **kwargs):
     """Returns [result of rank 0, rank 1, ...]; raises if any rank failed.  ``use_oracle_backend=False`` +
     ``device=0``: every rank runs the PRODUCT backend on that GPU (multi-process GPU tests, gloo group)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     with tempfile.NamedTemporaryFile(delete=True) as f:
         store = f.name
-    procs = [ctx.Process(target=_entry, args=(r, world, store, fn, kwargs, q, use_oracle_backend, device)) for r in range(world)]
+    procs = [ctx.Process(target=_entry, args=(r, world, store, fn, kwargs, q, use_oracle_backend, device, backend_kwargs)) for r in range(world)]
     for p in procs:
         p.start()
     out = {}

@@ -31,6 +31,7 @@ class OracleWorkspace:
         self.send = torch.zeros((local_ranks, self.L), dtype=torch.float32)
         self.table = torch.zeros((R, self.L), dtype=torch.float32) if R != local_ranks else self.send
         self.send_initialised = False
+        self.seq = 0
         # same single-block layout as the product workspace: meta | scores | flags | stats
         al = lambda n: (n + 63) // 64 * 64  # noqa: E731
         self._off_meta = 0
@@ -57,9 +58,22 @@ class OracleBackend:
     name = "oracle-test"
     device = torch.device("cpu")
 
-    def __init__(self):
+    def __init__(self, emulate_fused=False):
         self._ws = {}
         self.score_calls = 0
+        #: also offer the product's one-call report (``report_fused``, in-call exchange, deferred wait) so that the
+        #: host logic of asynchronous reports can run on CPU / gloo ranks
+        self.emulate_fused = emulate_fused
+
+    def create_direct_exchange(self, group):
+        import torch.distributed as dist
+
+        if not self.emulate_fused or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return None
+        return _OracleDirect(group)
+
+    def wait_seq(self, ws, seq):
+        assert ws.seq >= seq  # the emulation computes at enqueue time
 
     def stream_context(self):
         return contextlib.nullcontext()
@@ -78,7 +92,8 @@ class OracleBackend:
         return self._ws[key]
 
     def make_rings(self, local_ranks, rows_per_rank, ring_cap):
-        return OracleRings(self, local_ranks, rows_per_rank, ring_cap)
+        cls = OracleRingsFused if self.emulate_fused else OracleRings
+        return cls(self, local_ranks, rows_per_rank, ring_cap)
 
     def send_init(self, ws):
         KS = ws.K + ws.S
@@ -95,6 +110,21 @@ class OracleBackend:
         with np.errstate(invalid="ignore"):
             ws.flags[:] = (ws.scores.astype(np.float64) < thr[None, :]).astype(np.uint8)
         ws.meta[:4] = [int((T[:, -1] > 0).all()), ws.R, ws.K, ws.S]
+
+
+class _OracleDirect:
+    """Stand-in for rccl_direct.DirectAllGather: the in-call exchange of ``report_fused`` on a CPU group."""
+
+    def __init__(self, group):
+        self.group = group
+
+    def exchange(self, ws, backend):
+        from nvrx_straggler import dist_utils
+
+        return dist_utils.all_gather_rows(ws.send, ws.table, self.group)
+
+    def close(self):
+        pass
 
 
 class OracleRings:
@@ -223,3 +253,19 @@ class OracleRings:
 
     def timing_read(self, reset=True):
         return 0.0, 0
+
+
+class OracleRingsFused(OracleRings):
+    """Adds the product's one-call report; results are computed at enqueue time, ``wait=False`` just skips nothing."""
+
+    def report_fused(self, ws, rows_active, stats_rows, do_indiv, do_rel, thresholds, direct=None, names_ok=True, wait=True,
+                     order_after=None):
+        from nvrx_straggler import dist_utils
+
+        self.report_local(ws, names_ok, rows_active=rows_active)
+        table = ws.send
+        if direct is not None:
+            table = dist_utils.all_gather_rows(ws.send, ws.table, direct.group)
+        self.backend.score(ws, table, do_indiv, do_rel, thresholds)
+        ws.seq = getattr(ws, "seq", 0) + 1
+        return ws.seq

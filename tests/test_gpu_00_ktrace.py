@@ -23,7 +23,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRIPT = r'''
 import faulthandler, json, os, sys
 faulthandler.enable()
-faulthandler.dump_traceback_later(100, exit=True)   # a hang becomes a traceback, not a lost GPU box
+faulthandler.dump_traceback_later(140, exit=True)   # a hang becomes a traceback, not a lost GPU box
 sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
 os.environ["NVRX_GPU_TIMING"] = "kernels"
 import numpy as np
@@ -85,12 +85,19 @@ print("RESULT " + json.dumps(out))
 def test_kernels_are_traced_by_name_and_scored():
     env = dict(os.environ)
     env.pop("NVRX_GPU_TIMING", None)
+    import time as _time
+
+    t_start = _time.monotonic()
     try:
-        p = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\n" + SCRIPT], capture_output=True, text=True, timeout=110, env=env)
+        p = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\n" + SCRIPT], capture_output=True, text=True, timeout=150, env=env)
     except subprocess.TimeoutExpired:
-        pytest.skip("rocprofiler-sdk start-up stalled on this box (before any nvrx code ran)")
-    if p.returncode != 0 and "Timeout (0:01:40)" in p.stderr and ("_lazy_init" in p.stderr or "ktrace.py" in p.stderr):
-        pytest.skip("rocprofiler-sdk start-up stalled on this box (inside the first HIP call, before any nvrx code ran)")
+        # visible in the GPU test summary as XFAIL with the measured wait (a silent skip would hide that the per-kernel
+        # mode's evidence is missing on this box); the stall is inside rocprofiler-sdk's own start-up
+        pytest.xfail(f"rocprofiler-sdk start-up did not complete within {_time.monotonic() - t_start:.0f} s on this box "
+                     "(inside the first HIP call, before any nvrx code ran)")
+    if p.returncode != 0 and "Timeout (0:02:20)" in p.stderr and ("_lazy_init" in p.stderr or "ktrace.py" in p.stderr):
+        pytest.xfail(f"rocprofiler-sdk start-up stalled for {_time.monotonic() - t_start:.0f} s inside the first HIP call")
+    print(f"[ktrace] subprocess wall time {_time.monotonic() - t_start:.1f} s (SDK start-up + test body)")
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
     out = json.loads(line[len("RESULT "):])

@@ -210,3 +210,67 @@ def test_config2_loop_folded_on_one_gpu_matches_reference():
             compare_reports(got, exp, ("loop-folded", t), rel=1e-4)
     finally:
         job.close()
+
+
+def test_asynchronous_reports_do_not_race_with_device_stamps():
+    """Asynchronous report t is only enqueued when generate_report returns; the stamp kernels of window t+1 (user
+    stream) write ring slots that report t's statistics kernel (detector stream) may not have read yet.  The library
+    orders them on the device.  Provoked here by parking a long kernel in front of every report: each window's CPU
+    samples all carry the window index, so a sample of window t+1 inside report t would show up as MAX > t."""
+    from nvrx_straggler import Detector, Statistic
+    from nvrx_straggler.backend import get_backend
+
+    be = get_backend()
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n", asynchronous=True)
+    try:
+        with Detector.detection_section("s", profile_cuda=True):
+            pass
+        Detector.generate_report()
+        rings = Detector.rings
+        sec = Detector.custom_sections["s"]
+        gpu_row = rings.kernel_row_names["hipevent::s"]
+        big = torch.randn(8192, 8192, device="cuda")
+        user = torch.cuda.current_stream()
+        prev, seen = None, 0
+        for t in range(1, 40):
+            for _ in range(3):
+                rings.stamp_begin(gpu_row, be.current_stream_handle())
+                rings.stamp_end(gpu_row, be.current_stream_handle(), sec.row, float(t))
+            with torch.cuda.stream(be.stream):
+                (big @ big).sum()            # ~3 ms in front of the report on the detector's stream
+            rep = Detector.generate_report()  # returns at once
+            if prev is not None:
+                s = prev.local_section_summaries["s"]
+                assert s[Statistic.NUM] == 3 and s[Statistic.MIN] == s[Statistic.MAX] == float(t - 1), (t, s)
+                assert prev.local_kernel_summaries["hipevent::s"][Statistic.NUM] == 3
+                assert prev.section_individual_perf_scores["s"][0] == pytest.approx(1.0 / (t - 1), rel=1e-6)
+                seen += 1
+            prev = rep
+        user.synchronize()
+        assert seen == 38 and prev.local_section_summaries["s"][Statistic.MAX] == 39.0
+    finally:
+        Detector.shutdown()
+
+
+def test_asynchronous_and_synchronous_detector_reports_agree():
+    from nvrx_straggler import Detector
+
+    rng = np.random.default_rng(3)
+    data = [{f"sec{i}": rng.normal(5.0 * (i + 1), 0.2, 50).astype(np.float32) for i in range(5)} for _ in range(4)]
+    results = {}
+    for mode in (False, True):
+        Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n", asynchronous=mode)
+        try:
+            reps = []
+            for window in data:
+                for name, vals in window.items():
+                    with Detector.detection_section(name, profile_cuda=False):
+                        pass
+                    Detector.custom_sections[name].cpu_elapsed_times.clear()
+                    Detector.custom_sections[name].cpu_elapsed_times.extend(vals)
+                reps.append(Detector.generate_report())
+            results[mode] = [(dict(r.section_individual_perf_scores), dict(r.local_section_summaries), r.identify_stragglers())
+                             for r in reps]
+        finally:
+            Detector.shutdown()
+    assert results[False] == results[True]

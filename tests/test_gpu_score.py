@@ -126,3 +126,26 @@ def test_report_generator_exact_known_answers(be):
     rep = gen.generate_report({}, kernel_summaries={"kernel0": summary(1.25 * np.array([1.0, 1.0, 2.0]))})
     assert rep.gpu_relative_perf_scores[0] == pytest.approx(1.0)
     assert rep.identify_stragglers()["straggler_gpus_relative"] == set()
+
+
+@pytest.mark.parametrize("R,K,S", [(8, 0, 64), (8, 5, 64), (64, 0, 64)])
+def test_completion_word_never_precedes_the_results(be, R, K, S):
+    """k_score1 publishes the sequence word after draining its write-through stores (no system-scope fence): the host
+    must never see the new sequence number next to an older report's scores / flags.  Two tables with different
+    answers alternate through ONE result block, checked the instant the word arrives, 20 000 times."""
+    rng = np.random.default_rng(5)
+    tabs = [_random_table(rng, R, K, S, p_missing=0.0) for _ in range(2)]
+    tabs[1][:, : K + S] *= 3.0  # every median differs -> every individual score differs
+    exp = [oracle.score_table(t, K, S, True, True) for t in tabs]
+    dev = [torch.from_numpy(t).cuda() for t in tabs]
+    ws = be.workspace(R, K, S, R, 0)
+    torch.cuda.synchronize()
+    W = 2 + 2 * S
+    for i in range(20_000):
+        be.score(ws, dev[i & 1], True, True, (0.75, 0.75, 0.75, 0.75))
+        got = ws.scores
+        e = exp[i & 1]
+        # individual section scores: hmin / med, bit-exact and different between the two tables
+        assert np.array_equal(got[:, 2 : 2 + S], e[:, 2 : 2 + S]), i
+        assert np.array_equal(got[:, 2 + S : W], e[:, 2 + S : W]), i
+        assert ws.meta[4] == ws.seq and ws.meta[1] == R

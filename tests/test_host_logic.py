@@ -628,3 +628,34 @@ def test_config2_loop_ten_reports_match_reference():
             assert got["NUM"] == e["NUM"] == 100 and got["MED"] == np.float32(e["MED"]), (t, n)
     flagged = [res[0][t]["stragglers"]["0.9"]["straggler_sections_relative"] for t in range(10)]
     assert all(not f for f in flagged[:5]) and all(set(f) == {f"section_{s:03d}" for s in range(4)} for f in flagged[5:])
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_asynchronous_reports_match_synchronous_ones_and_defer_new_names(world):
+    """Asynchronous reports (enqueue now, wait on first read): same scores as the synchronous run for every report;
+    a section that ONE rank meets at report 3 enters at report 4, after the name sync every rank runs at the start of
+    that report (the synchronous run has it at report 3 already)."""
+    kw = dict(backend_kwargs={"emulate_fused": True})
+    sync = run_ranks(workers.detector_async_sequence, world, asynchronous=False, **kw)
+    asyn = run_ranks(workers.detector_async_sequence, world, asynchronous=True, **kw)
+    late = "late_rank1_only"
+    for r in range(world):
+        assert asyn[r]["ids"] == sync[r]["ids"]
+    # the cached plan serves reports 1, 2 and 5 in both modes; asynchronous also runs the OLD plan at report 3
+    assert sync[0]["planned"][1] and sync[0]["planned"][2]
+    assert asyn[0]["planned"][1] and asyn[0]["planned"][2] and asyn[0]["planned"][5]
+    for t in range(6):
+        a, s = asyn[0]["reports"][t], sync[0]["reports"][t]
+        assert a is not None and s is not None
+        for key in ("section_relative_perf_scores", "section_individual_perf_scores"):
+            exp = dict(s[key])
+            if world > 1 and t == 3:
+                assert late in exp and late not in a[key]   # one report later in asynchronous mode
+                exp.pop(late)
+            assert a[key].keys() == exp.keys(), (t, key)
+            for n in exp:
+                if n == late and key == "section_individual_perf_scores":
+                    continue  # its history (best median so far) also starts one report later
+                np.testing.assert_allclose(list(a[key][n].values()), list(exp[n].values()), rtol=1e-6, equal_nan=True)
+        if world > 1 and t >= 4:
+            assert late in a["section_relative_perf_scores"]

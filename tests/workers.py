@@ -310,3 +310,41 @@ def folded_job_device(rank, world, total_ranks, variant):
         return out
     finally:
         job.close()
+
+
+def detector_async_sequence(rank, world, asynchronous):
+    """Six reports through the Detector; at report 3 rank 1 ALONE meets a new section.  ``asynchronous=True``: reports
+    come back unread-able until waited for, the new name enters one report later (name sync at the start of report 4,
+    where every rank is).  Returns rank 0's reports (plain) and which of them took the cached plan."""
+    import numpy as np
+
+    from nvrx_straggler import Detector
+
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name=f"h{rank}", asynchronous=asynchronous)
+    out, planned = [], []
+    try:
+        def feed(name, value, n=5):
+            with Detector.detection_section(name, profile_cuda=False):
+                pass
+            sec = Detector.custom_sections[name]
+            sec.cpu_elapsed_times.clear()
+            sec.cpu_elapsed_times.extend(np.full(n, value, dtype=np.float32))
+
+        held = None
+        for t in range(6):
+            feed("a", 2.0 * (rank + 1) * (1 + 0.1 * t))
+            feed("b", 4.0 + t + rank)
+            if t >= 3 and rank == 1:
+                feed("late_rank1_only", 1.0 + t)
+            plan_before = Detector.reporter._ring_plan
+            rep = Detector.generate_report()
+            planned.append(plan_before is not None and Detector.reporter._ring_plan is plan_before)
+            if held is not None:  # consume report t-1 one step late, the way an asynchronous user would
+                out.append(report_to_plain(held))
+            held = rep
+        out.append(report_to_plain(held) if held is not None else None)
+        if rank != 0:
+            out = [None] * 6
+        return {"reports": out, "planned": planned, "ids": dict(Detector.reporter.name_mapper.section_name_to_id)}
+    finally:
+        Detector.shutdown()
