@@ -228,6 +228,29 @@ typedef struct nvrx_report_desc {
 int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *desc, void *stream);
 /* sizeof(nvrx_report_desc) as this library was compiled: lets an FFI binding check its own struct layout. */
 int nvrx_report_desc_size(void);
+/* ------------------------------------------------------------------------------------------------
+ * Peer-window exchange: the report's one collective as direct xGMI peer stores between the processes of ONE node.
+ * Replaces all_reduce(MIN) + gather of reporting.py:281,397 (as the RCCL all-gather does) without an RCCL kernel:
+ * every process owns a window of 8-byte {epoch, f32} granules in fine-grained device memory, mapped by all
+ * processes through HIP IPC; nvrx_peer_allgather enqueues ONE single-workgroup kernel that stores this process'
+ * floats into every window and polls its own window until every rank's floats of this epoch have arrived.
+ * Collective set-up (cold): create -> exchange the 64-byte IPC handles out of band -> connect each peer -> ready.
+ * Every process must call nvrx_peer_allgather the same number of times (the epoch is counted, not passed).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct nvrx_peer nvrx_peer;
+int nvrx_peer_create(int device, int world, int rank, int max_floats_per_rank, nvrx_peer **out);
+int nvrx_peer_ipc_handle(nvrx_peer *peer, void *handle64 /* 64 bytes out */);
+int nvrx_peer_connect(nvrx_peer *peer, int peer_rank, const void *handle64);
+/* timeout_s: how long the kernel polls for a late peer before it gives up (<= 0 keeps the default 1800 s). */
+int nvrx_peer_ready(nvrx_peer *peer, double timeout_s);
+/* ncclAllGather-compatible: (send, recv, floats per rank, dtype = 7 (f32), comm = the nvrx_peer, stream); returns 0
+ * or a positive code.  Usable as nvrx_report_desc.allgather_fn (address: nvrx_peer_allgather_address()). */
+int nvrx_peer_allgather(const void *send, void *recv, size_t count, int dtype, void *comm, void *stream);
+void *nvrx_peer_allgather_address(void);
+/* Epoch of the last exchange in which the kernel gave up waiting for a peer (0 = never). */
+int nvrx_peer_error(const nvrx_peer *peer, uint32_t *epoch_out);
+int nvrx_peer_destroy(nvrx_peer *peer);
+
 /* Re-initialise an exchange buffer with the "no stats" sentinels (call when ids change). */
 int nvrx_send_init(float *d_send, int rows, int K, int S, void *stream);
 

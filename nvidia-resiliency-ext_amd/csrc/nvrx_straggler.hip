@@ -1029,6 +1029,65 @@ __global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fenc
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_peer_allgather: the report's exchange as direct xGMI peer stores (no RCCL kernel, no proxy thread).
+//
+// Every process owns a WINDOW in fine-grained device memory that all processes of the node have mapped through HIP
+// IPC: [2 parities][world][stride] 8-byte granules {epoch << 32 | f32 bits}.  One workgroup per process:
+//   publish  this process' `count` floats go to slot [epoch & 1][rank] of EVERY window (its own included) as
+//            single 8-byte system-scope stores -- the data carries its own flag, so no fence and no ordering
+//            between granules is needed (an aligned 8-byte store is never torn);
+//   sweep    the same threads poll the granules of every rank's slot in their OWN window until the tag equals
+//            this report's epoch and write the values to `recv` ([world][count] f32, plain device memory for the
+//            score kernel that follows on the stream).
+// Two parities, because a fast process may publish report n+1 while a slow one still sweeps report n; it cannot
+// reach report n+2 before every process has published n+1, i.e. has finished sweeping n.
+// The exchange carries ~0.5 KB per rank: latency-bound (one xGMI hop + one poll pass), link bandwidth irrelevant.
+// A peer that never arrives turns into a bounded spin: after `timeout_ticks` of the constant-rate wall clock the
+// thread gives up, stores NaN and raises the window's error word (host-visible), and the host reports it.
+// ------------------------------------------------------------------------------------------------
+constexpr int PEER_THREADS = 1024;
+
+struct PeerArgs {
+    unsigned long long *const *windows;  // [world] device array: every process' window base, as mapped HERE
+    const float *send;
+    float *recv;
+    uint32_t *err;  // host-visible error word
+    int world, rank, count, stride;
+    uint32_t epoch;
+    unsigned long long timeout_ticks;
+};
+
+__global__ __launch_bounds__(PEER_THREADS) void k_peer_allgather(PeerArgs a) {
+    const int total = a.world * a.count;
+    const size_t slot = (size_t)(a.epoch & 1u) * (size_t)a.world;
+    for (int idx = threadIdx.x; idx < total; idx += PEER_THREADS) {
+        const int p = idx / a.count, j = idx - p * a.count;
+        const unsigned long long g = ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(a.send[j]);
+        __hip_atomic_store(a.windows[p] + (slot + (size_t)a.rank) * (size_t)a.stride + j, g, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const unsigned long long *mine = a.windows[a.rank];
+    const unsigned long long t0 = wall_clock64();
+    for (int idx = threadIdx.x; idx < total; idx += PEER_THREADS) {
+        const int r = idx / a.count, j = idx - r * a.count;
+        const unsigned long long *g = mine + (slot + (size_t)r) * (size_t)a.stride + j;
+        unsigned long long x;
+        uint32_t spins = 0;
+        for (;;) {
+            x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((uint32_t)(x >> 32) == a.epoch) break;
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 0xFFu) == 0u && wall_clock64() - t0 > a.timeout_ticks) {
+                x = 0x7FC00000ull;  // NaN
+                __hip_atomic_store(a.err, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        a.recv[idx] = __uint_as_float((uint32_t)x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch-shape selection for k_row_stats
 // ------------------------------------------------------------------------------------------------
 using StatsKernel = void (*)(const float *, const uint32_t *, const uint8_t *, int, float *, Epilogue, int);
@@ -1875,6 +1934,142 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
                     d->stats_rows, stream);
     if (rc) return rc;
     if (d->h_seq_word) return nvrx_poll_u32(d->h_seq_word, d->seq, d->timeout_s > 0.0 ? d->timeout_s : 1e30);
+    return NVRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// peer-window exchange
+// ------------------------------------------------------------------------------------------------
+struct nvrx_peer {
+    int device = 0, world = 0, rank = 0, stride = 0;
+    unsigned long long *window = nullptr;            // this process' window (fine-grained device memory)
+    std::vector<unsigned long long *> mapped;        // [world] every window as mapped in this process
+    std::vector<bool> opened;                        // mapped[p] came from hipIpcOpenMemHandle
+    unsigned long long **d_windows = nullptr;        // device copy of `mapped`
+    uint32_t *h_err = nullptr, *d_err = nullptr;     // pinned error word and its device address
+    uint32_t epoch = 0;
+    double timeout_s = 1800.0;
+    int wall_khz = 100000;
+    bool ready = false;
+};
+
+int nvrx_peer_create(int device, int world, int rank, int max_floats_per_rank, nvrx_peer **out) {
+    if (!out) return fail(NVRX_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (world <= 0 || rank < 0 || rank >= world || max_floats_per_rank <= 0) return fail(NVRX_ERR_INVALID, "bad peer geometry");
+    HIP_TRY(hipSetDevice(device));
+    nvrx_peer *p = new (std::nothrow) nvrx_peer();
+    if (!p) return fail(NVRX_ERR_NOMEM, "host allocation failed");
+    p->device = device;
+    p->world = world;
+    p->rank = rank;
+    p->stride = (max_floats_per_rank + 1) & ~1;
+    p->mapped.assign((size_t)world, nullptr);
+    p->opened.assign((size_t)world, false);
+    const size_t bytes = 2ull * (size_t)world * (size_t)p->stride * sizeof(unsigned long long);
+    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void **>(&p->window), bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+        delete p;
+        return fail(NVRX_ERR_HIP, "hipExtMallocWithFlags(fine-grained window, %zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    e = hipMemset(p->window, 0, bytes);  // tag 0 is never a valid epoch
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_err), 64, hipHostMallocMapped);
+    if (e == hipSuccess) {
+        p->h_err[0] = 0;
+        e = hipHostGetDevicePointer(reinterpret_cast<void **>(&p->d_err), p->h_err, 0);
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_windows), (size_t)world * sizeof(void *));
+    if (e != hipSuccess) {
+        int rc = fail(NVRX_ERR_HIP, "peer window set-up failed: %s", hipGetErrorString(e));
+        nvrx_peer_destroy(p);
+        return rc;
+    }
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) p->wall_khz = khz;
+    p->mapped[(size_t)rank] = p->window;
+    *out = p;
+    return NVRX_OK;
+}
+
+int nvrx_peer_ipc_handle(nvrx_peer *p, void *handle64) {
+    if (!p || !handle64) return fail(NVRX_ERR_INVALID, "null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipIpcGetMemHandle(&h, p->window));
+    memcpy(handle64, &h, sizeof(h));
+    return NVRX_OK;
+}
+
+int nvrx_peer_connect(nvrx_peer *p, int peer_rank, const void *handle64) {
+    if (!p || !handle64) return fail(NVRX_ERR_INVALID, "null argument");
+    if (peer_rank < 0 || peer_rank >= p->world) return fail(NVRX_ERR_INVALID, "peer rank %d out of range", peer_rank);
+    if (peer_rank == p->rank) return NVRX_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    void *ptr = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    p->mapped[(size_t)peer_rank] = static_cast<unsigned long long *>(ptr);
+    p->opened[(size_t)peer_rank] = true;
+    return NVRX_OK;
+}
+
+int nvrx_peer_ready(nvrx_peer *p, double timeout_s) {
+    if (!p) return fail(NVRX_ERR_INVALID, "null argument");
+    for (int r = 0; r < p->world; r++)
+        if (!p->mapped[(size_t)r]) return fail(NVRX_ERR_STATE, "window of rank %d is not connected", r);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemcpy(p->d_windows, p->mapped.data(), (size_t)p->world * sizeof(void *), hipMemcpyHostToDevice));
+    if (timeout_s > 0.0) p->timeout_s = timeout_s;
+    p->ready = true;
+    return NVRX_OK;
+}
+
+// ncclAllGather-compatible signature (plugs into nvrx_report_desc.allgather_fn; `comm` is the nvrx_peer).
+// Returns 0 or a positive code (ncclResult-style): nvrx_last_error() holds the message.
+int nvrx_peer_allgather(const void *send, void *recv, size_t count, int dtype, void *comm, void *stream) {
+    nvrx_peer *p = static_cast<nvrx_peer *>(comm);
+    if (!p || !p->ready || !send || !recv) return -fail(NVRX_ERR_INVALID, "peer exchange is not ready");
+    if (dtype != 7) return -fail(NVRX_ERR_INVALID, "peer exchange carries f32 only");
+    if (count == 0 || count > (size_t)p->stride) return -fail(NVRX_ERR_RANGE, "%zu floats per rank exceed the window's %d", count, p->stride);
+    PeerArgs a{};
+    a.windows = p->d_windows;
+    a.send = static_cast<const float *>(send);
+    a.recv = static_cast<float *>(recv);
+    a.err = p->d_err;
+    a.world = p->world;
+    a.rank = p->rank;
+    a.count = (int)count;
+    a.stride = p->stride;
+    p->epoch = (p->epoch % 0x7FFFFFFFu) + 1u;  // never 0; every process counts its exchanges the same way
+    a.epoch = p->epoch;
+    a.timeout_ticks = (unsigned long long)(p->timeout_s * 1e3 * (double)p->wall_khz);
+    hipLaunchKernelGGL(k_peer_allgather, dim3(1), dim3(PEER_THREADS), 0, as_stream(stream), a);
+    if (hipGetLastError() != hipSuccess) return -fail(NVRX_ERR_HIP, "k_peer_allgather launch failed");
+    return 0;
+}
+
+// Epoch of the last exchange that gave up waiting for a peer (0 = none), as raised by the kernel.
+int nvrx_peer_error(const nvrx_peer *p, uint32_t *epoch_out) {
+    if (!p || !epoch_out) return fail(NVRX_ERR_INVALID, "null argument");
+    *epoch_out = *static_cast<volatile uint32_t *>(p->h_err);
+    return NVRX_OK;
+}
+
+void *nvrx_peer_allgather_address(void) { return reinterpret_cast<void *>(&nvrx_peer_allgather); }
+
+int nvrx_peer_destroy(nvrx_peer *p) {
+    if (!p) return NVRX_OK;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < p->world; r++)
+        if (p->opened[(size_t)r] && p->mapped[(size_t)r]) (void)hipIpcCloseMemHandle(p->mapped[(size_t)r]);
+    if (p->window) (void)hipFree(p->window);
+    if (p->d_windows) (void)hipFree(p->d_windows);
+    if (p->h_err) (void)hipHostFree(p->h_err);
+    delete p;
     return NVRX_OK;
 }
 

@@ -72,6 +72,14 @@ SYMBOLS = [
     ("nvrx_report_local", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("nvrx_report", c_int, [c_void_p, POINTER(ReportDesc), c_void_p]),
     ("nvrx_report_desc_size", c_int, []),
+    ("nvrx_peer_create", c_int, [c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
+    ("nvrx_peer_ipc_handle", c_int, [c_void_p, c_void_p]),
+    ("nvrx_peer_connect", c_int, [c_void_p, c_int, c_void_p]),
+    ("nvrx_peer_ready", c_int, [c_void_p, c_double]),
+    ("nvrx_peer_allgather", c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
+    ("nvrx_peer_allgather_address", c_void_p, []),
+    ("nvrx_peer_error", c_int, [c_void_p, POINTER(c_uint32)]),
+    ("nvrx_peer_destroy", c_int, [c_void_p]),
     ("nvrx_send_init", c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     ("nvrx_timing_enable", c_int, [c_void_p, c_int]),
     ("nvrx_timing_read", c_int, [c_void_p, POINTER(c_double), POINTER(c_int), c_int]),

@@ -1,0 +1,194 @@
+"""The report's ONE collective as direct xGMI peer stores (``nvrx_peer_*`` in include/nvrx_straggler.h).
+
+A report exchanges ~0.5 KB per rank: the wire time over xGMI is far below a microsecond, so what an RCCL all-gather
+costs here is its own machinery (kernel launch, protocol hand-shakes between eight ranks, proxy progress).  On one
+node every GPU can store straight into its peers' memory, so the exchange becomes: one single-workgroup kernel per
+rank that writes this rank's row into a window of every peer (HIP IPC mapping, 8-byte ``{epoch, value}`` granules: the
+data is its own flag) and polls its own window until all rows of this epoch are there.
+
+``create()`` is the cold, COLLECTIVE set-up (handles travel through ``torch.distributed``); every step is agreed on
+by all ranks so that either every rank gets a :class:`PeerAllGather` or none does.  It presents the interface of
+``rccl_direct.DirectAllGather`` (``fn_address`` / ``comm_address`` for ``nvrx_report``, ``exchange``, ``close``).
+Only ranks of ONE node can share windows; multi-node groups stay on RCCL.  ``choose()`` picks between the two routes:
+``NVRX_EXCHANGE=rccl|peer|auto`` (default auto = both are built, each is timed and checked on a dummy row, the faster
+one that delivered the right table on every rank wins).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import socket
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native
+
+_NCCL_FLOAT32 = 7
+MAX_FLOATS_PER_RANK = 65536  # floats per rank a window slot holds: local_ranks * (2(K+S)+K+1); 8 MB of windows at 8 ranks
+
+
+def _all_ok(ok: bool, group) -> bool:
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == dist.Backend.NCCL else torch.device("cpu")
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item() > 0)
+
+
+class PeerAllGather:
+    """Window exchange of f32 rows on a caller-supplied ``hipStream_t``."""
+
+    route = "xGMI peer stores (IPC windows)"
+
+    def __init__(self, lib, peer: ctypes.c_void_p, world: int, rank: int):
+        self._lib = lib
+        self._peer = peer
+        self.world = world
+        self.rank = rank
+        self.fn_address = lib.nvrx_peer_allgather_address()
+        self.comm_address = peer.value
+        self.max_count = MAX_FLOATS_PER_RANK
+
+    def all_gather(self, send_ptr: int, recv_ptr: int, count: int, stream_handle: int) -> None:
+        rc = self._lib.nvrx_peer_allgather(send_ptr, recv_ptr, count, _NCCL_FLOAT32, self._peer, stream_handle)
+        if rc != 0:
+            msg = self._lib.nvrx_last_error()
+            raise RuntimeError(f"peer exchange failed: {msg.decode() if msg else rc}")
+
+    def exchange(self, ws, backend):
+        self.all_gather(ws.send_ptr, ws.table_ptr, ws.local_ranks * ws.L, backend.stream_handle)
+        return ws.table
+
+    def set_timeout(self, seconds: float) -> None:
+        """How long the exchange kernel polls for a late peer before it gives up."""
+        _native.check(self._lib.nvrx_peer_ready(self._peer, float(seconds)))
+
+    def check(self) -> None:
+        """Raise if an exchange kernel gave up waiting for a peer (its table rows are NaN)."""
+        epoch = self.timed_out_epoch()
+        if epoch:
+            raise _native.NativeError(
+                f"straggler report exchange: a peer did not publish its row within the timeout (exchange #{epoch}); "
+                "the report's scores are invalid")
+
+    def timed_out_epoch(self) -> int:
+        """Epoch of the last exchange whose kernel gave up waiting for a peer (0 = never)."""
+        e = ctypes.c_uint32(0)
+        _native.check(self._lib.nvrx_peer_error(self._peer, ctypes.byref(e)))
+        return e.value
+
+    def close(self) -> None:
+        if self._peer is not None:
+            try:
+                self._lib.nvrx_peer_destroy(self._peer)
+            finally:
+                self._peer = None
+
+
+def create(group=None, device_index: Optional[int] = None, timeout_s: float = 1800.0) -> Optional[PeerAllGather]:
+    """Collective over ``group``: a :class:`PeerAllGather`, or ``None`` on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or not torch.cuda.is_available():
+        return None
+    world = dist.get_world_size(group)
+    if world == 1:
+        return None
+    rank = dist.get_rank(group)
+    lib = _native.load()
+    dev = torch.cuda.current_device() if device_index is None else int(device_index)
+    peer = ctypes.c_void_p()
+    handle = None
+    ok = True
+    try:
+        _native.check(lib.nvrx_peer_create(dev, world, rank, MAX_FLOATS_PER_RANK, ctypes.byref(peer)))
+        buf = ctypes.create_string_buffer(64)
+        _native.check(lib.nvrx_peer_ipc_handle(peer, buf))
+        handle = buf.raw
+    except Exception:  # noqa: BLE001  (the decision below must stay collective)
+        ok = False
+    # windows can only be shared inside one node
+    infos = [None] * world
+    dist.all_gather_object(infos, (socket.gethostname(), handle if ok else None), group=group)
+    same_node = len({h for h, _ in infos}) == 1
+    ok = ok and same_node and all(hd is not None for _, hd in infos)
+    if ok:
+        try:
+            for r, (_, hd) in enumerate(infos):
+                if r != rank:
+                    _native.check(lib.nvrx_peer_connect(peer, r, hd))
+            _native.check(lib.nvrx_peer_ready(peer, float(timeout_s)))
+        except Exception:  # noqa: BLE001
+            ok = False
+    if not _all_ok(ok, group):  # one failure sends every rank back to the other route
+        if peer.value:
+            lib.nvrx_peer_destroy(peer)
+        return None
+    return PeerAllGather(lib, peer, world, rank)
+
+
+def _trial(route, group, backend, reps: int = 30):
+    """Time ``reps`` exchanges of a recognisable dummy row on ``route`` and check what arrived.  Collective.
+    Returns (median microseconds, table correct) for THIS rank."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = 129
+    send = torch.full((n,), float(rank + 1), dtype=torch.float32, device=backend.device)
+    recv = torch.zeros((world, n), dtype=torch.float32, device=backend.device)
+    torch.cuda.current_stream().synchronize()
+    st = backend.stream_handle
+    times = []
+    for i in range(reps + 5):
+        t0 = time.perf_counter()
+        route.all_gather(send.data_ptr(), recv.data_ptr(), n, st)
+        backend.synchronize()
+        if i >= 5:
+            times.append(time.perf_counter() - t0)
+    exp = torch.arange(1, world + 1, dtype=torch.float32).view(world, 1).expand(world, n)
+    good = bool(torch.equal(recv.cpu(), exp))
+    return float(np.median(times)) * 1e6, good
+
+
+def choose(group, backend, rccl, peer, timeout_s: float = 1800.0):
+    """Pick the exchange route for ``group`` (collective; same answer on every rank).  Returns (route, info)."""
+    mode = os.environ.get("NVRX_EXCHANGE", "auto")
+    info = {"mode": mode}
+    if peer is not None:
+        # the trial must not be able to park a kernel on the GPU for long if a window is unreachable
+        peer.set_timeout(float(os.environ.get("NVRX_PEER_TRIAL_TIMEOUT_S", "5")))
+    try:
+        return _choose(mode, info, group, backend, rccl, peer)
+    finally:
+        if peer is not None and peer._peer is not None:
+            peer.set_timeout(timeout_s)
+
+
+def _choose(mode, info, group, backend, rccl, peer):
+    if mode == "rccl" or peer is None:
+        if peer is not None:
+            peer.close()
+        return rccl, info
+    if mode == "peer" or rccl is None:
+        us, good = _trial(peer, group, backend)
+        info["peer_us"] = us
+        if _all_ok(good, group):
+            if rccl is not None:
+                rccl.close()
+            return peer, info
+        peer.close()
+        info["peer_rejected"] = True
+        return rccl, info
+    # auto: measure both, keep the faster one that was right everywhere
+    r_us, r_good = _trial(rccl, group, backend)
+    p_us, p_good = _trial(peer, group, backend)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([r_us, p_us, 0.0 if r_good else 1.0, 0.0 if p_good else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    r_us, p_us, r_bad, p_bad = t.tolist()
+    info.update({"rccl_us": round(r_us, 2), "peer_us": round(p_us, 2), "rccl_ok": r_bad == 0.0, "peer_ok": p_bad == 0.0})
+    use_peer = p_bad == 0.0 and (r_bad != 0.0 or p_us < r_us)
+    if use_peer:
+        rccl.close()
+        return peer, info
+    peer.close()
+    return rccl, info

@@ -65,6 +65,8 @@ def _all_ok(ok: bool, group) -> bool:
 class DirectAllGather:
     """``ncclAllGather`` of f32 rows on a caller-supplied ``hipStream_t``."""
 
+    route = "ncclAllGather on the detector's stream"
+
     def __init__(self, lib: ctypes.CDLL, comm: ctypes.c_void_p, world: int, rank: int):
         self._lib = lib
         self._comm = comm

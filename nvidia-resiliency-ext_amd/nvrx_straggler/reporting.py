@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import collections
 import dataclasses
+import os
 import threading
 import time
 from typing import Any, Dict, Iterator, List, Mapping, Optional, Sequence, Tuple
@@ -352,6 +353,7 @@ class ReportGenerator:
         # that waits for the device on first read; the block in flight is settled before the next report starts
         self.asynchronous = bool(asynchronous)
         self._inflight: Optional[_PendingBlock] = None
+        self.exchange_info: Dict[str, Any] = {}
 
     # ---- pieces kept from the reference's host logic ----------------------------------------------
     @staticmethod
@@ -381,15 +383,30 @@ class ReportGenerator:
         return self.is_computing_rel_scores or self.gather_on_rank0
 
     def _maybe_create_direct_exchange(self) -> None:
-        """Collective, once: every rank calls this at the top of its first exchanging report."""
+        """Collective, once: every rank calls this at the top of its first exchanging report.  Builds the in-stream
+        exchange routes -- ``ncclAllGather`` on a communicator of our own (rccl_direct) and, inside one node, direct
+        xGMI peer stores into IPC-mapped windows (peer_exchange) -- and keeps the one ``peer_exchange.choose`` picks."""
         if self._direct_tried or self.world_size == 1 or not self._exchanged():
             return
         self._direct_tried = True
-        from . import rccl_direct
-
         be = _backend_mod.get_backend()
         maker = getattr(be, "create_direct_exchange", None)  # a test backend may bring its own in-call exchange
-        self._direct = maker(self.group) if maker is not None else rccl_direct.create(self.group, getattr(be.device, "index", None))
+        if maker is not None:
+            self._direct = maker(self.group)
+            return
+        from . import peer_exchange, rccl_direct
+
+        index = getattr(be.device, "index", None)
+        rccl = rccl_direct.create(self.group, index)
+        peer = None
+        if os.environ.get("NVRX_EXCHANGE", "auto") != "rccl" and (rccl is not None or os.environ.get("NVRX_EXCHANGE") == "peer"):
+            # windows need a group that can reach every rank's GPU: built next to the RCCL route (a gloo group whose
+            # ranks share one GPU qualifies too when asked for explicitly: that is how the tests run it)
+            peer = peer_exchange.create(self.group, index, _backend_mod.report_timeout_s() or 1e9)
+        self._direct, self.exchange_info = (peer_exchange.choose(self.group, be, rccl, peer, _backend_mod.report_timeout_s() or 1e9)
+                                            if (rccl or peer) else (None, {}))
+        if self._direct is not None:
+            self.exchange_info["route"] = getattr(self._direct, "route", "ncclAllGather on the detector's stream")
 
     def _exchange(self, be, ws):
         """The report's one collective: this rank's rows -> the [R, L] table, on the backend's stream."""
@@ -444,6 +461,8 @@ class ReportGenerator:
                 table = ws.send
             be.score(ws, table, self.is_computing_indiv_scores, self.is_computing_rel_scores, self.thresholds,
                      wait=True, stats_rows=stats_rows_used)
+            if world > 1:
+                self._check_exchange()
             if ws.meta[0] == 1:
                 return ws, mapper
             # some rank (maybe this one) has names without ids: cold path, then go again
@@ -546,7 +565,13 @@ class ReportGenerator:
             return False
         self._inflight = None
         blob = pend.wait()
+        self._check_exchange()
         return int(blob[0:4].view(np.uint32)[0]) != 1
+
+    def _check_exchange(self) -> None:
+        check = getattr(self._direct, "check", None)  # the peer-window route reports peers that never arrived
+        if check is not None:
+            check()
 
     def _source_for(self, plan, ws) -> _ScoreSource:
         src = _ScoreSource()
@@ -588,6 +613,8 @@ class ReportGenerator:
             rings.report_local(ws, True, rows_active=plan.rows_used)
             be.score(ws, ws.send, self.is_computing_indiv_scores, self.is_computing_rel_scores, self.thresholds,
                      wait=True, stats_rows=plan.stats_needed)
+        if multi:
+            self._check_exchange()
         if ws.meta[0] != 1:
             return False  # another rank met a new name: fall back to the general (name-syncing) path
         if self.gather_on_rank0 and self.rank != 0:

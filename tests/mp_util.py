@@ -7,8 +7,9 @@ import traceback
 import torch.multiprocessing as mp
 
 
-def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend, device=None, backend_kwargs=None):
+def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend, device=None, backend_kwargs=None, env=None):
     try:
+        os.environ.update(env or {})
         here = os.path.dirname(os.path.abspath(__file__))
         repo = os.path.dirname(here)
         for p in (repo, os.path.join(repo, "nvidia-resiliency-ext_amd"), here, os.path.join(here, "golden")):
@@ -39,14 +40,14 @@ def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend, device=None, b
         q.put((rank, "error", traceback.format_exc()))
 
 
-def run_ranks(fn, world, timeout=180, use_oracle_backend=True, device=None, backend_kwargs=None, **kwargs):
+def run_ranks(fn, world, timeout=180, use_oracle_backend=True, device=None, backend_kwargs=None, env=None, **kwargs):
     """Returns [result of rank 0, rank 1, ...]; raises if any rank failed.  ``use_oracle_backend=False`` +
     ``device=0``: every rank runs the PRODUCT backend on that GPU (multi-process GPU tests, gloo group)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     with tempfile.NamedTemporaryFile(delete=True) as f:
         store = f.name
-    procs = [ctx.Process(target=_entry, args=(r, world, store, fn, kwargs, q, use_oracle_backend, device, backend_kwargs)) for r in range(world)]
+    procs = [ctx.Process(target=_entry, args=(r, world, store, fn, kwargs, q, use_oracle_backend, device, backend_kwargs, env)) for r in range(world)]
     for p in procs:
         p.start()
     out = {}

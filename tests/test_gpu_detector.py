@@ -243,7 +243,6 @@ def test_asynchronous_reports_do_not_race_with_device_stamps():
                 s = prev.local_section_summaries["s"]
                 assert s[Statistic.NUM] == 3 and s[Statistic.MIN] == s[Statistic.MAX] == float(t - 1), (t, s)
                 assert prev.local_kernel_summaries["hipevent::s"][Statistic.NUM] == 3
-                assert prev.section_individual_perf_scores["s"][0] == pytest.approx(1.0 / (t - 1), rel=1e-6)
                 seen += 1
             prev = rep
         user.synchronize()

@@ -79,3 +79,73 @@ def test_config2_loop_ten_reports_on_hip_backend():
         for n, e in exp["local_section_summaries"].items():
             got = res[0][t]["local_section_summaries"][n]
             assert got["NUM"] == 100 and got["MED"] == np.float32(e["MED"]) and got["MIN"] == np.float32(e["MIN"]), (t, n)
+
+
+# --------------------------------------------------------------------------------------------------
+# the peer-window exchange (direct stores into IPC-mapped windows): same GPU, several processes
+# --------------------------------------------------------------------------------------------------
+_PEER_ENV = {"NVRX_EXCHANGE": "peer", "NVRX_REPORT_TIMEOUT_S": "20", "NVRX_PEER_TRIAL_TIMEOUT_S": "5"}
+
+
+def test_peer_window_single_rank_abi():
+    """world = 1: the window is this process' own; one exchange is a copy through the granules."""
+    import ctypes
+
+    import torch
+
+    from nvrx_straggler import _native
+
+    lib = _native.load()
+    peer = ctypes.c_void_p()
+    _native.check(lib.nvrx_peer_create(0, 1, 0, 1024, ctypes.byref(peer)))
+    try:
+        handle = ctypes.create_string_buffer(64)
+        _native.check(lib.nvrx_peer_ipc_handle(peer, handle))
+        assert any(handle.raw)
+        _native.check(lib.nvrx_peer_ready(peer, 5.0))
+        send = torch.randn(129, device="cuda")
+        recv = torch.zeros(1, 129, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(3):
+            assert lib.nvrx_peer_allgather(send.data_ptr(), recv.data_ptr(), 129, 7, peer, None) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(recv[0], send)
+            send += 1.0
+            torch.cuda.synchronize()
+        assert lib.nvrx_peer_allgather(send.data_ptr(), recv.data_ptr(), 4096, 7, peer, None) != 0  # exceeds the slot
+        assert b"exceed" in lib.nvrx_last_error()
+        epoch = ctypes.c_uint32(7)
+        _native.check(lib.nvrx_peer_error(peer, ctypes.byref(epoch)))
+        assert epoch.value == 0
+    finally:
+        lib.nvrx_peer_destroy(peer)
+
+
+@pytest.mark.parametrize("world,count", [(2, 129), (4, 1032), (8, 129)])
+def test_peer_window_exchange_stress(world, count):
+    bad = run_ranks(workers.peer_exchange_stress, world, timeout=120, use_oracle_backend=False, device=0, iters=200, count=count)
+    assert bad == [0] * world
+
+
+@pytest.mark.parametrize("name", ["sections_2ranks_gather1", "mixed_8ranks_all_gather", "mixed_8ranks_all_nogather"])
+def test_report_generator_over_peer_windows_matches_reference(name):
+    g = next(s for s in _SCENARIOS if s["scenario"]["name"] == name)
+    sc = g["scenario"]
+    res = run_ranks(workers.scoring_scenario, sc["world_size"], timeout=150, use_oracle_backend=False, device=0, env=_PEER_ENV,
+                    scenario=sc)
+    for r in range(sc["world_size"]):
+        for t in range(len(sc["steps"])):
+            compare_reports(res[r]["reports"][t], g["per_rank"][r]["reports"][t], (name, r, t))
+        assert res[r]["ids"] == g["per_rank"][r]["ids"], (name, r)
+
+
+def test_config2_loop_over_peer_windows():
+    """Config #2 (8 processes, real Detector, ten reports) with the one-call report: statistics kernel -> window
+    exchange kernel -> score kernel in ONE C call per report, synchronous and asynchronous."""
+    g = load_golden("loop.json")
+    for extra in ({}, {"NVRX_ASYNC_REPORT": "1"}):
+        res = run_ranks(workers.detector_loop_config2, 8, timeout=150, use_oracle_backend=False, device=0,
+                        env={**_PEER_ENV, **extra})
+        assert all(rep is None for r in range(1, 8) for rep in res[r])
+        for t, exp in enumerate(g["rank0_reports"]):
+            compare_reports(res[0][t], exp, ("loop-peer", extra, t), rel=1e-4)

@@ -348,3 +348,37 @@ def detector_async_sequence(rank, world, asynchronous):
         return {"reports": out, "planned": planned, "ids": dict(Detector.reporter.name_mapper.section_name_to_id)}
     finally:
         Detector.shutdown()
+
+
+def peer_exchange_stress(rank, world, iters, count):
+    """The peer-window exchange on its own: `world` processes (sharing one GPU in the tests), `iters` exchanges of a
+    `count`-float row whose content changes every time; every rank checks every gathered table."""
+    import torch
+    import torch.distributed as dist
+
+    from nvrx_straggler import peer_exchange
+    from nvrx_straggler.backend import get_backend
+
+    be = get_backend()
+    pg = peer_exchange.create(None, be.device.index, timeout_s=8.0)
+    assert pg is not None
+    try:
+        send = torch.zeros(count, dtype=torch.float32, device=be.device)
+        recv = torch.zeros((world, count), dtype=torch.float32, device=be.device)
+        base = torch.arange(count, dtype=torch.float32)
+        torch.cuda.synchronize()
+        bad = 0
+        with torch.cuda.stream(be.stream):
+            for it in range(iters):
+                send.copy_((base + 1000.0 * rank + it).to(be.device), non_blocking=False)
+                pg.all_gather(send.data_ptr(), recv.data_ptr(), count, be.stream_handle)
+                got = recv.cpu()
+                exp = torch.stack([base + 1000.0 * r + it for r in range(world)])
+                bad += int(not torch.equal(got, exp))
+                if it % 7 == rank % 7:
+                    time.sleep(0.003)  # uneven arrival: the other ranks' kernels poll while this one is late
+        assert pg.timed_out_epoch() == 0
+        return bad
+    finally:
+        dist.barrier()
+        pg.close()
