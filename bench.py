@@ -31,6 +31,7 @@ Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
                   dicts is timed next to it; the single-rank, no-collective figure is kept as a sub-object.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -255,6 +256,7 @@ def _n8_shape_leg(steps, warmup):
         for _ in range(warmup):
             job.rearm(SAMPLES)
             job.report()
+        gc.collect()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -376,10 +378,16 @@ def main():
         flagged = rep.identify_stragglers()["straggler_sections_relative"]
         assert len(flagged) == SECTIONS and all({s.rank for s in v} == {3} for v in flagged.values()), "wrong flagged set"
 
+    # one full collection now, so that the cyclic collector's generation-2 pass (tens of ms with torch imported) does
+    # not land inside the 200 timed steps by accident of allocation counts; the collector stays enabled
+    gc.collect()
     sync_all()
+    per_step = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter_ns()
         step()
+        per_step.append(time.perf_counter_ns() - ts)
     sync_all()
     elapsed = time.perf_counter() - t0
 
@@ -409,7 +417,8 @@ def main():
                 job.backend.synchronize()
                 t_ex.append(time.perf_counter() - t0)
             exchange = {"us_median": float(np.median(t_ex)) * 1e6,
-                        "route": "ncclAllGather on the detector's stream" if job.reporter._direct is not None else "torch.distributed",
+                        "route": getattr(job.reporter._direct, "route", "torch.distributed"),
+                        "selection": dict(job.reporter.exchange_info),
                         "bytes_per_rank": int(ws.local_ranks * ws.L * 4)}
         except Exception as e:  # noqa: BLE001  (deterministic on every rank: same state everywhere)
             exchange = {"error": str(e)[-200:]}
@@ -481,10 +490,12 @@ def main():
                             "relative+individual scores, gather_on_rank0",
                 "logical_ranks_per_gpu": job.local_ranks,
                 "rows_per_gpu": job.local_ranks * SECTIONS,
-                "exchange": "none (single process)" if world == 1 else f"1 all-gather of {job.local_ranks}x{2 * SECTIONS + 1} f32 per rank ({'RCCL' if args.backend == 'nccl' else args.backend})",
+                "exchange": "none (single process)" if world == 1 else f"1 all-gather of {job.local_ranks}x{2 * SECTIONS + 1} f32 per rank ({getattr(job.reporter._direct, 'route', 'torch.distributed ' + args.backend)})",
                 "target_us": 50,
             },
             "reports_per_s": round(1e6 / us_per_report, 1),
+            "us_per_report_median": round(float(np.median(per_step)) / 1e3, 2),
+            "us_per_report_p95": round(float(np.percentile(per_step, 95)) / 1e3, 2),
             "instrumented_ms_per_step": round(elapsed_instr / args.steps * 1e3, 5),
             "roofline": {
                 "bound": "hbm",

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Full GPU validation of HEAD on one MI355X box: tools/run_gpu_round.sh <tag>   (run through gpurun)
+# Everything lands in gpurun_out/<tag>/; tools/summarize_profiles.py turns it into profiles/<tag>_* afterwards.
+set -x
+TAG=${1:-round}
+O=gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+B="--steps 200 --warmup 20"
+timeout -s KILL 900 python -m pytest tests -m gpu -x -q --durations=10 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -15 $O/pytest.log
+timeout 600 python bench.py $B > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench.json; cat $O/bench.json
+timeout 120 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+# the multi-rank flow with ranks SHARING this GPU (gloo group; the report's exchange through IPC peer windows)
+for n in 2 8; do
+  NVRX_EXCHANGE=peer NVRX_REPORT_TIMEOUT_S=30 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n \
+      --master-addr 127.0.0.1 --master-port $((29500 + n)) bench.py --gpus $n $B --backend gloo --no-cpu-baseline --no-overhead \
+      > $O/bench_gloo_peer_n$n.log 2>&1
+  grep '^{"metric' $O/bench_gloo_peer_n$n.log | tail -1 > $O/bench_gloo_peer_n$n.json; cat $O/bench_gloo_peer_n$n.json
+done
+P="python bench.py $B --no-cpu-baseline --no-overhead --no-host-inputs"
+echo "$P" > $O/command.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $P > $O/prof_stats.log 2>&1
+cp $O/command.txt $O/stats/command.txt
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $P > $O/prof_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $P > $O/prof_write.log 2>&1
+find $O -name "*kernel_trace.csv" -size +2M -delete
+find $O -name "*counter_collection.csv" -size +8M -delete
+du -sh $O

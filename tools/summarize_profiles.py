@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 output under gpurun_out/ into the committed summaries under profiles/.
 
-usage: tools/summarize_profiles.py <tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir>] [--local-ranks N]
+usage: tools/summarize_profiles.py <tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir>]
   <stats_dir>      output of `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...`
   <pmc_*_dir>      outputs of separate `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace ...` passes
 Writes profiles/<tag>_kernel_stats.csv (verbatim), profiles/<tag>_summary.md and updates
@@ -23,40 +23,48 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    m = re.search(r"k_row_stats<(\d+), (\d+)>", name)
+    m = re.search(r"k_row_stats<(\d+), (\d+)", name)
     if m and m.group(2) != "5":  # <512,5> is the bench shape; other tiles come from the overhead leg
         return f"k_row_stats<{m.group(1)},{m.group(2)}>"
-    for k in ("k_row_stats", "k_score", "k_scatter", "k_colmin", "k_send_init", "k_fill_f32", "k_stamp_begin", "k_stamp_end"):
+    for k in ("k_row_stats", "k_score1", "k_score", "k_peer_allgather", "k_scatter", "k_colmin", "k_send_init", "k_fill_f32",
+              "k_stamp_begin", "k_stamp_end"):
         if k in name:
             return k
     return name[:40]
 
 
+def kernel_source_sha():
+    import hashlib
+
+    with open(os.path.join(REPO, "nvidia-resiliency-ext_amd", "csrc", "nvrx_straggler.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def pmc(dirname, counter):
+    """{(kernel, rows): (dispatches, mean counter value)}; rows = workgroups of the dispatch (one per timing row for
+    k_row_stats), so the bench shape (512 rows) and the N=8 per-GPU shape (64 rows) stay apart."""
     vals = collections.defaultdict(list)
     for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
             if row["Counter_Name"] == counter:
-                vals[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+                wgs = int(row["Grid_Size"]) // max(int(row["Workgroup_Size"]), 1)
+                vals[(short(row["Kernel_Name"]), wgs)].append(float(row["Counter_Value"]))
     return {k: (len(v), sum(v) / len(v)) for k, v in vals.items()}
 
 
 def main():
     argv = sys.argv[1:]
-    local_ranks = 8
-    if "--local-ranks" in argv:
-        i = argv.index("--local-ranks")
-        local_ranks = int(argv[i + 1])
-        del argv[i : i + 2]
     tag, stats_dir = argv[0], argv[1]
     out = os.path.join(REPO, "profiles")
     os.makedirs(out, exist_ok=True)
     stats_csv = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)[0]
     shutil.copy(stats_csv, os.path.join(out, f"{tag}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats_csv)))
+    cmd = open(os.path.join(stats_dir, "command.txt")).read().strip() if os.path.exists(os.path.join(stats_dir, "command.txt")) else \
+        "python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-overhead"
     lines = [f"# rocprofv3 summary `{tag}`", "",
-             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20 "
-             f"--no-cpu-baseline --no-overhead` (N=1: {local_ranks} logical ranks x 64 sections x 10000 samples on one MI355X)", "",
+             f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}` (N=1: 8 logical ranks x 64 sections x "
+             "10000 samples on one MI355X; kernel source sha " + kernel_source_sha() + ")", "",
              "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
     for r in rows:
         lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | "
@@ -64,25 +72,28 @@ def main():
     if len(argv) >= 4:
         f = pmc(argv[2], "FETCH_SIZE")
         w = pmc(argv[3], "WRITE_SIZE")
-        lines += ["", "PMC passes (separate runs, `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` with `--kernel-trace` only):", "",
-                  "| kernel | dispatches | FETCH_SIZE avg (KiB) | read bytes (x2 gfx950 correction) | WRITE_SIZE avg (KiB) |",
-                  "|---|---|---|---|---|"]
+        lines += ["", "PMC passes (separate runs, `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` with `--kernel-trace` only; one line per "
+                      "kernel and launch size):", "",
+                  "| kernel | workgroups | dispatches | FETCH_SIZE avg (KiB) | read bytes (x2 gfx950 correction) | WRITE_SIZE avg (KiB) |",
+                  "|---|---|---|---|---|---|"]
         for k in sorted(set(f) | set(w)):
-            if not k.startswith("k_"):
+            if not k[0].startswith("k_"):
                 continue
             fn, fv = f.get(k, (0, 0.0))
             _, wv = w.get(k, (0, 0.0))
-            lines.append(f"| {k} | {fn} | {fv:.1f} | {2 * fv * 1024:.0f} | {wv:.1f} |")
-        if "k_row_stats" in f:
-            hbm = 2 * f["k_row_stats"][1] * 1024 + w.get("k_row_stats", (0, 0.0))[1] * 1024
-            path = os.path.join(out, "pmc_row_stats.json")
-            d = json.load(open(path)) if os.path.exists(path) else {}
-            d[str(local_ranks)] = {"hbm_bytes_per_launch": int(hbm), "fetch_size_kib_avg": f["k_row_stats"][1],
-                                   "write_size_kib_avg": w.get("k_row_stats", (0, 0.0))[1], "source": tag,
-                                   "note": "read side = 2 x FETCH_SIZE x 1024 (gfx950 correction, MI355X_MICROARCH.md HBM)"}
-            json.dump(d, open(path, "w"), indent=1)
-            lines += ["", f"k_row_stats HBM traffic per launch: {hbm/1e6:.2f} MB "
-                          f"(algorithmic {local_ranks * 64 * 10000 * 4 / 1e6:.2f} MB)"]
+            lines.append(f"| {k[0]} | {k[1]} | {fn} | {fv:.1f} | {2 * fv * 1024:.0f} | {wv:.1f} |")
+        d = {"kernel_source_sha16": kernel_source_sha(), "source": tag, "rows": {},
+             "note": "read side = 2 x FETCH_SIZE x 1024 (gfx950 correction, MI355X_MICROARCH.md HBM); write side = WRITE_SIZE x 1024"}
+        for (k, wgs), (n, fv) in sorted(f.items()):
+            if k != "k_row_stats" or n < 5:
+                continue
+            wv = w.get((k, wgs), (0, 0.0))[1]
+            hbm = 2 * fv * 1024 + wv * 1024
+            d["rows"][str(wgs)] = {"hbm_bytes_per_launch": int(hbm), "fetch_size_kib_avg": fv, "write_size_kib_avg": wv, "dispatches": n}
+            lines += ["", f"k_row_stats, {wgs} rows: HBM traffic per launch {hbm/1e6:.2f} MB (algorithmic {wgs * 10000 * 4 / 1e6:.2f} MB, "
+                          f"ratio {hbm / (wgs * 10000 * 4):.3f})"]
+        if d["rows"]:
+            json.dump(d, open(os.path.join(out, "pmc_row_stats.json"), "w"), indent=1)
     open(os.path.join(out, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
