@@ -382,3 +382,30 @@ def peer_exchange_stress(rank, world, iters, count):
     finally:
         dist.barrier()
         pg.close()
+
+
+def folded_loop_config2(rank, world, asynchronous):
+    """Config #2 through FoldedJob on `world` processes (8 / world logical ranks each): ten reports, history minima
+    across reports.  Returns the plain reports plus which exchange route / report path served them."""
+    import synth
+    from nvrx_straggler.folded import FoldedJob
+
+    cfg = {"S": 4, "n": 100, "reports": 10, "slow_rank": 3, "slow_factor": 1.2, "slow_from": 5}
+    names = [synth.section_name(s) for s in range(cfg["S"])]
+    job = FoldedJob(total_ranks=8, section_names=names, ring_cap=8192, node_name=f"node{rank}")
+    job.reporter.asynchronous = asynchronous
+    try:
+        held, out = [], []
+        for t in range(cfg["reports"]):
+            slow = cfg["slow_rank"] if t >= cfg["slow_from"] else -1
+            for lr, r in enumerate(job.logical_ranks()):
+                job.load(lr, synth.loop_samples(r, t, cfg["S"], cfg["n"], slow_rank=slow, slow_factor=cfg["slow_factor"]))
+            held.append(job.report())
+            if len(held) > 1:  # read one report late, as an asynchronous consumer would
+                out.append(report_to_plain(held[-2], (0.75, 0.9)))
+        out.append(report_to_plain(held[-1], (0.75, 0.9)))
+        plan = job.reporter._ring_plan
+        return {"reports": out, "route": getattr(job.reporter._direct, "route", "none"),
+                "fused": bool(plan is not None and plan.fused)}
+    finally:
+        job.close()

@@ -12,7 +12,7 @@ tail -15 $O/pytest.log
 timeout 600 python bench.py $B > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench.json; cat $O/bench.json
 timeout 120 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 # the multi-rank flow with ranks SHARING this GPU (gloo group; the report's exchange through IPC peer windows)
-for n in 2 8; do
+for n in 2 4; do
   NVRX_EXCHANGE=peer NVRX_REPORT_TIMEOUT_S=30 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n \
       --master-addr 127.0.0.1 --master-port $((29500 + n)) bench.py --gpus $n $B --backend gloo --no-cpu-baseline --no-overhead \
       > $O/bench_gloo_peer_n$n.log 2>&1

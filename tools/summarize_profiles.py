@@ -69,6 +69,22 @@ def main():
     for r in rows:
         lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | "
                      f"{float(r['MaxNs'])/1e3:.2f} | {float(r['Percentage']):.1f} |")
+    # the same trace split by launch size: k_row_stats runs at the bench shape (512 rows), at the N=8 per-GPU shape (64
+    # rows) and, in the Detector legs, on a handful of rows; the stats table above averages over all of them
+    by_size = collections.defaultdict(list)
+    for path in glob.glob(os.path.join(stats_dir, "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            k = short(row["Kernel_Name"])
+            if k.startswith("k_row_stats") or k.startswith("k_score") or k.startswith("k_peer"):
+                wgs = int(row["Grid_Size_X"]) // max(int(row["Workgroup_Size_X"]), 1)
+                by_size[(k, wgs)].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    if by_size:
+        lines += ["", "Same trace, by launch size (workgroups = timing rows for k_row_stats):", "",
+                  "| kernel | workgroups | calls | avg us | median us | min us |", "|---|---|---|---|---|---|"]
+        for (k, wgs), v in sorted(by_size.items()):
+            if len(v) >= 20:
+                v = sorted(v)
+                lines.append(f"| {k} | {wgs} | {len(v)} | {sum(v)/len(v)/1e3:.2f} | {v[len(v)//2]/1e3:.2f} | {v[0]/1e3:.2f} |")
     if len(argv) >= 4:
         f = pmc(argv[2], "FETCH_SIZE")
         w = pmc(argv[3], "WRITE_SIZE")
