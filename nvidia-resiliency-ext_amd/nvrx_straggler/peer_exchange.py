@@ -130,23 +130,31 @@ def create(group=None, device_index: Optional[int] = None, timeout_s: float = 18
 
 def _trial(route, group, backend, reps: int = 30):
     """Time ``reps`` exchanges of a recognisable dummy row on ``route`` and check what arrived.  Collective.
-    Returns (median microseconds, table correct) for THIS rank."""
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    n = 129
-    send = torch.full((n,), float(rank + 1), dtype=torch.float32, device=backend.device)
-    recv = torch.zeros((world, n), dtype=torch.float32, device=backend.device)
-    torch.cuda.current_stream().synchronize()
-    st = backend.stream_handle
-    times = []
-    for i in range(reps + 5):
-        t0 = time.perf_counter()
-        route.all_gather(send.data_ptr(), recv.data_ptr(), n, st)
-        backend.synchronize()
-        if i >= 5:
-            times.append(time.perf_counter() - t0)
-    exp = torch.arange(1, world + 1, dtype=torch.float32).view(world, 1).expand(world, n)
-    good = bool(torch.equal(recv.cpu(), exp))
-    return float(np.median(times)) * 1e6, good
+    Returns (median microseconds, table correct) for THIS rank.  Never raises: a rank that fails reports "not
+    correct", which the callers turn into the same decision on every rank (its peers' exchanges run into the
+    route's own bounded wait)."""
+    try:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        n = 129
+        send = torch.full((n,), float(rank + 1), dtype=torch.float32, device=backend.device)
+        recv = torch.zeros((world, n), dtype=torch.float32, device=backend.device)
+        torch.cuda.current_stream().synchronize()
+        st = backend.stream_handle
+        times = []
+        for i in range(reps + 5):
+            t0 = time.perf_counter()
+            route.all_gather(send.data_ptr(), recv.data_ptr(), n, st)
+            backend.synchronize()
+            if i >= 5:
+                times.append(time.perf_counter() - t0)
+        exp = torch.arange(1, world + 1, dtype=torch.float32).view(world, 1).expand(world, n)
+        good = bool(torch.equal(recv.cpu(), exp))
+        check = getattr(route, "timed_out_epoch", None)
+        if check is not None and check():
+            good = False
+        return float(np.median(times)) * 1e6, good
+    except Exception:  # noqa: BLE001
+        return float("inf"), False
 
 
 def choose(group, backend, rccl, peer, timeout_s: float = 1800.0):

@@ -698,7 +698,11 @@ class ReportGenerator:
             self._ring_plan = plan = None
             resync_first = True
         if plan is not None and plan.key == key:
-            out = self._report_from_plan(plan, rings, t0, order_after)
+            try:
+                out = self._report_from_plan(plan, rings, t0, order_after)
+            except Exception:
+                self._ring_plan = None  # e.g. a timed-out wait retired the plan's workspace: never run it again
+                raise
             if out is not False:
                 return out
             self._ring_plan = None

@@ -273,3 +273,38 @@ def test_asynchronous_and_synchronous_detector_reports_agree():
         finally:
             Detector.shutdown()
     assert results[False] == results[True]
+
+
+def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
+    """The wait for the completion word is bounded by NVRX_REPORT_TIMEOUT_S (default: 30 minutes, c10d's): when it
+    expires the report raises, the workspace whose kernels may still be queued is parked (never reused, never freed
+    under them), and the next report runs on a fresh one."""
+    from nvrx_straggler import _native
+    from nvrx_straggler.backend import get_backend
+    from nvrx_straggler.folded import FoldedJob
+
+    be = get_backend()
+    names = [synth.section_name(s) for s in range(4)]
+    job = FoldedJob(total_ranks=2, section_names=names, ring_cap=256, node_name="n")
+    try:
+        for r in range(2):
+            job.load(r, synth.loop_samples(r, 0, 4, 100))
+        first = job.report(reset=False)
+        ws_before = job.reporter._ring_plan.ws
+        big = torch.randn(8192, 8192, device="cuda")
+        monkeypatch.setenv("NVRX_REPORT_TIMEOUT_S", "0.02")
+        ws_before.desc_key = None  # the descriptor caches the timeout: make it pick the new one up
+        with torch.cuda.stream(be.stream):
+            for _ in range(40):          # > 100 ms of work queued in front of the report
+                big = (big @ big) * 1e-4
+        with pytest.raises(_native.NativeError, match="not seen after"):
+            job.report(reset=False)
+        assert ws_before in be._retired and ws_before not in be._workspaces.values()
+        monkeypatch.setenv("NVRX_REPORT_TIMEOUT_S", "60")
+        be.synchronize()
+        assert job.reporter._ring_plan is None  # the generator dropped the plan that pointed at the parked workspace
+        again = job.report(reset=False)
+        assert job.reporter._ring_plan.ws is not ws_before
+        assert again.section_relative_perf_scores == first.section_relative_perf_scores
+    finally:
+        job.close()
