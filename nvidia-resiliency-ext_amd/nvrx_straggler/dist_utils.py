@@ -17,8 +17,11 @@ import torch
 import torch.distributed as dist
 
 
+_DIST_AVAILABLE = dist.is_available()
+
+
 def _dist_ready() -> bool:
-    return dist.is_available() and dist.is_initialized()
+    return _DIST_AVAILABLE and dist.is_initialized()
 
 
 def get_world_size(group=None) -> int:
@@ -27,6 +30,13 @@ def get_world_size(group=None) -> int:
 
 def get_rank(group=None) -> int:
     return dist.get_rank(group) if _dist_ready() else 0
+
+
+def world_and_rank(group=None):
+    """(world size, rank) of ``group`` with one initialisation check: the per-report lookup."""
+    if _DIST_AVAILABLE and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
 
 
 def get_device_for_backend(group=None) -> torch.device:

@@ -106,9 +106,12 @@ class _ScoreSource:
         self.stats = blob[off_t : off_t + stats_rows * 32].view(np.float32).reshape(stats_rows, 8)
 
     def ensure(self) -> "_ScoreSource":
-        if self.scores is None and self.pending is not None:
-            self.cut(self.pending.wait())
-            self.pending = None
+        if self.scores is None:
+            pend = self.pending
+            if pend is not None:
+                # a private copy of the block (ndarray), or the block still in flight (_PendingBlock)
+                self.cut(pend if type(pend) is np.ndarray else pend.wait())
+                self.pending = None
         return self
 
     def build(self, field: str):
@@ -262,7 +265,7 @@ class _DeviceFlags:
     __slots__ = ("thresholds", "flags", "ranks", "names", "cols", "S", "has_rel", "has_indiv")
 
     def __init__(self, thresholds, flags, ranks, names, cols, S, has_rel, has_indiv):
-        self.thresholds = tuple(float(t) for t in thresholds)  # (gpu_rel, sec_rel, gpu_indiv, sec_indiv)
+        self.thresholds = thresholds  # (gpu_rel, sec_rel, gpu_indiv, sec_indiv), a tuple of floats
         self.flags = flags  # ndarray [ranks, 2+2S] u8, or the _ScoreSource that will hold it
         self.ranks = ranks
         self.names = names
@@ -620,8 +623,8 @@ class ReportGenerator:
         if self.gather_on_rank0 and self.rank != 0:
             return None
         src = self._source_for(plan, ws)
-        src.cut(ws.host_block())  # one memcpy out of the pinned block; the report's arrays are views into the copy
-        flags = _DeviceFlags(self.thresholds, src.flags, plan.ranks, plan.names, plan.cols, ws.S, src.has_rel, src.has_indiv)
+        src.pending = ws.host_block()  # one memcpy out of the pinned block; cut into views when the report is first read
+        flags = _DeviceFlags(self.thresholds, src, plan.ranks, plan.names, plan.cols, ws.S, src.has_rel, src.has_indiv)
         return Report._from_device(
             src, self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
             (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank, flags)
@@ -684,8 +687,7 @@ class ReportGenerator:
         work already enqueued there (the collectives of the training step) on the device, without a host wait.
         """
         t0 = time.perf_counter_ns()
-        self.world_size = dist_utils.get_world_size(self.group)
-        self.rank = dist_utils.get_rank(self.group)
+        self.world_size, self.rank = dist_utils.world_and_rank(self.group)
         if not self._direct_tried:
             self._maybe_create_direct_exchange()
         # steady state: same name tables as last time -> run the cached plan
