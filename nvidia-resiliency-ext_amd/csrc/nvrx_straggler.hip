@@ -917,6 +917,71 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_peer_allgather: the report's exchange as direct xGMI peer stores (no RCCL kernel, no proxy thread).
+//
+// Every process owns a WINDOW in fine-grained device memory that all processes of the node have mapped through HIP
+// IPC: [2 parities][world][stride] 8-byte granules {epoch << 32 | f32 bits}.  One workgroup per process:
+//   publish  this process' `count` floats go to slot [epoch & 1][rank] of EVERY window (its own included) as
+//            single 8-byte system-scope stores -- the data carries its own flag, so no fence and no ordering
+//            between granules is needed (an aligned 8-byte store is never torn);
+//   sweep    the same threads poll the granules of every rank's slot in their OWN window until the tag equals
+//            this report's epoch and write the values to `recv` ([world][count] f32, plain device memory for the
+//            score kernel that follows on the stream).
+// Two parities, because a fast process may publish report n+1 while a slow one still sweeps report n; it cannot
+// reach report n+2 before every process has published n+1, i.e. has finished sweeping n.
+// The exchange carries ~0.5 KB per rank: latency-bound (one xGMI hop + one poll pass), link bandwidth irrelevant.
+// A peer that never arrives turns into a bounded spin: after `timeout_ticks` of the constant-rate wall clock the
+// thread gives up, stores NaN and raises the window's error word (host-visible), and the host reports it.
+// The same code runs as the prologue of k_score1 (nvrx_report with the peer route and a table that fits the
+// single-workgroup score kernel): the exchange then costs no kernel of its own.
+// ------------------------------------------------------------------------------------------------
+constexpr int PEER_THREADS = 1024;
+
+struct PeerArgs {
+    unsigned long long *const *windows;  // [world] device array: every process' window base, as mapped HERE
+    const float *send;
+    float *recv;
+    uint32_t *err;  // host-visible error word
+    int world, rank, count, stride;
+    uint32_t epoch;
+    unsigned long long timeout_ticks;
+};
+
+// The exchange, by every thread of the calling workgroup (no barrier inside; the caller synchronises before reading recv).
+__device__ __forceinline__ void peer_exchange_block(const PeerArgs &a) {
+    const int nthr = (int)blockDim.x;
+    const int total = a.world * a.count;
+    const size_t slot = (size_t)(a.epoch & 1u) * (size_t)a.world;
+    for (int idx = threadIdx.x; idx < total; idx += nthr) {
+        const int p = idx / a.count, j = idx - p * a.count;
+        const unsigned long long g = ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(a.send[j]);
+        __hip_atomic_store(a.windows[p] + (slot + (size_t)a.rank) * (size_t)a.stride + j, g, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const unsigned long long *mine = a.windows[a.rank];
+    const unsigned long long t0 = wall_clock64();
+    for (int idx = threadIdx.x; idx < total; idx += nthr) {
+        const int r = idx / a.count, j = idx - r * a.count;
+        const unsigned long long *g = mine + (slot + (size_t)r) * (size_t)a.stride + j;
+        unsigned long long x;
+        uint32_t spins = 0;
+        for (;;) {
+            x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((uint32_t)(x >> 32) == a.epoch) break;
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 0xFFu) == 0u && wall_clock64() - t0 > a.timeout_ticks) {
+                x = 0x7FC00000ull;  // NaN
+                __hip_atomic_store(a.err, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        a.recv[idx] = __uint_as_float((uint32_t)x);
+    }
+}
+
+__global__ __launch_bounds__(PEER_THREADS) void k_peer_allgather(PeerArgs a) { peer_exchange_block(a); }
+
+// ------------------------------------------------------------------------------------------------
 // k_score1: the whole table scored by ONE workgroup (R <= 64 ranks, results staged in LDS).
 //
 // The report's second kernel is pure latency (a few KB in, a few KB out over PCIe), so what counts is the
@@ -948,7 +1013,7 @@ __host__ __device__ inline size_t score1_lds_bytes(int R, int K, int S) {
     return ks4 * 4 + ((nout + 3) & ~(size_t)3) * 4 + ((nout + 15) & ~(size_t)15);
 }
 
-__global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fence) {
+__global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fence, PeerArgs pa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ double s_red[8][SCORE1_THREADS / 64];   // two alternating sets of 4 (see the rank loop)
     __shared__ uint32_t s_cnt[4][SCORE1_THREADS / 64];
@@ -964,6 +1029,12 @@ __global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fenc
     const int tid = threadIdx.x;
     const float NaN = __builtin_nanf("");
 
+    if (pa.windows) {
+        // the report's exchange as this kernel's prologue: publish this process' rows into every window, sweep ours
+        // into a.table (plain device memory, written and read by this one workgroup)
+        peer_exchange_block(pa);
+        __syncthreads();
+    }
     // local statistics rows -> result block; issued first so the loads overlap everything below
     for (int i = tid; i < a.stats_n4; i += SCORE1_THREADS) {
         const float4 v = a.stats_src[i];
@@ -1025,65 +1096,6 @@ __global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fenc
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_peer_allgather: the report's exchange as direct xGMI peer stores (no RCCL kernel, no proxy thread).
-//
-// Every process owns a WINDOW in fine-grained device memory that all processes of the node have mapped through HIP
-// IPC: [2 parities][world][stride] 8-byte granules {epoch << 32 | f32 bits}.  One workgroup per process:
-//   publish  this process' `count` floats go to slot [epoch & 1][rank] of EVERY window (its own included) as
-//            single 8-byte system-scope stores -- the data carries its own flag, so no fence and no ordering
-//            between granules is needed (an aligned 8-byte store is never torn);
-//   sweep    the same threads poll the granules of every rank's slot in their OWN window until the tag equals
-//            this report's epoch and write the values to `recv` ([world][count] f32, plain device memory for the
-//            score kernel that follows on the stream).
-// Two parities, because a fast process may publish report n+1 while a slow one still sweeps report n; it cannot
-// reach report n+2 before every process has published n+1, i.e. has finished sweeping n.
-// The exchange carries ~0.5 KB per rank: latency-bound (one xGMI hop + one poll pass), link bandwidth irrelevant.
-// A peer that never arrives turns into a bounded spin: after `timeout_ticks` of the constant-rate wall clock the
-// thread gives up, stores NaN and raises the window's error word (host-visible), and the host reports it.
-// ------------------------------------------------------------------------------------------------
-constexpr int PEER_THREADS = 1024;
-
-struct PeerArgs {
-    unsigned long long *const *windows;  // [world] device array: every process' window base, as mapped HERE
-    const float *send;
-    float *recv;
-    uint32_t *err;  // host-visible error word
-    int world, rank, count, stride;
-    uint32_t epoch;
-    unsigned long long timeout_ticks;
-};
-
-__global__ __launch_bounds__(PEER_THREADS) void k_peer_allgather(PeerArgs a) {
-    const int total = a.world * a.count;
-    const size_t slot = (size_t)(a.epoch & 1u) * (size_t)a.world;
-    for (int idx = threadIdx.x; idx < total; idx += PEER_THREADS) {
-        const int p = idx / a.count, j = idx - p * a.count;
-        const unsigned long long g = ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(a.send[j]);
-        __hip_atomic_store(a.windows[p] + (slot + (size_t)a.rank) * (size_t)a.stride + j, g, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    const unsigned long long *mine = a.windows[a.rank];
-    const unsigned long long t0 = wall_clock64();
-    for (int idx = threadIdx.x; idx < total; idx += PEER_THREADS) {
-        const int r = idx / a.count, j = idx - r * a.count;
-        const unsigned long long *g = mine + (slot + (size_t)r) * (size_t)a.stride + j;
-        unsigned long long x;
-        uint32_t spins = 0;
-        for (;;) {
-            x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((uint32_t)(x >> 32) == a.epoch) break;
-            __builtin_amdgcn_s_sleep(4);
-            if ((++spins & 0xFFu) == 0u && wall_clock64() - t0 > a.timeout_ticks) {
-                x = 0x7FC00000ull;  // NaN
-                __hip_atomic_store(a.err, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-        }
-        a.recv[idx] = __uint_as_float((uint32_t)x);
     }
 }
 
@@ -1174,6 +1186,16 @@ int score_fence_enabled() {
     if (v < 0) {
         const char *e = getenv("NVRX_SCORE_FENCE");
         v = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return v;
+}
+
+// NVRX_PEER_PROLOGUE=0 keeps the peer-window exchange in its own kernel (A/B measurements).
+int peer_prologue_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NVRX_PEER_PROLOGUE");
+        v = (e && atoi(e) == 0) ? 0 : 1;
     }
     return v;
 }
@@ -1400,9 +1422,17 @@ int nvrx_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8
     return launch_row_stats(d_samples, d_counts, d_kinds, rows, row_stride, d_stats, ep, as_stream(stream));
 }
 
-int nvrx_score(const float *d_table, int R, int K, int S, int do_indiv, int do_rel, const double *thresholds,
-               float *d_scores, uint8_t *d_flags, uint32_t *d_meta, uint32_t *d_done_counter, uint32_t seq,
-               const float *d_stats_src, float *d_stats_dst, int stats_rows, void *stream) {
+// `pa` (optional): the peer-window exchange to run as the score kernel's prologue.  Only honoured by the
+// single-workgroup kernel; *pa_used tells the caller whether it was (else the caller enqueues the exchange itself).
+static bool score_fits_single_wg(int R, int K, int S, const float *d_scores, const uint8_t *d_flags) {
+    return R <= SCORE1_MAX_RANKS && score1_lds_bytes(R, K, S) <= SCORE1_MAX_LDS &&
+           (reinterpret_cast<uintptr_t>(d_scores) & 15u) == 0 && (reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0 &&
+           score_single_wg_enabled();
+}
+
+static int score_launch(const float *d_table, int R, int K, int S, int do_indiv, int do_rel, const double *thresholds,
+                        float *d_scores, uint8_t *d_flags, uint32_t *d_meta, uint32_t *d_done_counter, uint32_t seq,
+                        const float *d_stats_src, float *d_stats_dst, int stats_rows, void *stream, const PeerArgs *pa) {
     if (R <= 0 || K < 0 || S < 0) return fail(NVRX_ERR_INVALID, "bad table shape R=%d K=%d S=%d", R, K, S);
     if (!d_table || !d_scores) return fail(NVRX_ERR_INVALID, "null device pointer");
     hipStream_t st = as_stream(stream);
@@ -1427,13 +1457,14 @@ int nvrx_score(const float *d_table, int R, int K, int S, int do_indiv, int do_r
     const int KS = K + S;
     // One workgroup does it all when the staged results fit in LDS.  The result arrays are then written in 16-byte
     // units: the caller's buffers must be 16-byte aligned and padded to a multiple of 16 bytes (the workspace is).
-    if (R <= SCORE1_MAX_RANKS && score1_lds_bytes(R, K, S) <= SCORE1_MAX_LDS &&
-        (reinterpret_cast<uintptr_t>(d_scores) & 15u) == 0 && (reinterpret_cast<uintptr_t>(d_flags) & 15u) == 0 &&
-        score_single_wg_enabled()) {
-        hipLaunchKernelGGL(k_score1, dim3(1), dim3(SCORE1_THREADS), score1_lds_bytes(R, K, S), st, a, score_fence_enabled());
+    if (score_fits_single_wg(R, K, S, d_scores, d_flags)) {
+        PeerArgs none{};
+        hipLaunchKernelGGL(k_score1, dim3(1), dim3(SCORE1_THREADS), score1_lds_bytes(R, K, S), st, a, score_fence_enabled(),
+                           pa ? *pa : none);
         HIP_TRY(hipGetLastError());
         return NVRX_OK;
     }
+    if (pa) return fail(NVRX_ERR_STATE, "the exchange prologue needs the single-workgroup score kernel");
     size_t lds = (size_t)KS * sizeof(float);
     if (R > 64 || lds > 48 * 1024) {
         // large jobs: column minima in their own pass over a coalesced grid
@@ -1456,6 +1487,13 @@ int nvrx_score(const float *d_table, int R, int K, int S, int do_indiv, int do_r
     hipLaunchKernelGGL(k_score, dim3(R), dim3(SCORE_THREADS), lds, st, a);
     HIP_TRY(hipGetLastError());
     return NVRX_OK;
+}
+
+int nvrx_score(const float *d_table, int R, int K, int S, int do_indiv, int do_rel, const double *thresholds,
+               float *d_scores, uint8_t *d_flags, uint32_t *d_meta, uint32_t *d_done_counter, uint32_t seq,
+               const float *d_stats_src, float *d_stats_dst, int stats_rows, void *stream) {
+    return score_launch(d_table, R, K, S, do_indiv, do_rel, thresholds, d_scores, d_flags, d_meta, d_done_counter, seq,
+                        d_stats_src, d_stats_dst, stats_rows, stream, nullptr);
 }
 
 int nvrx_send_init(float *d_send, int rows, int K, int S, void *stream) {
@@ -1900,6 +1938,41 @@ int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S
 }
 
 // ------------------------------------------------------------------------------------------------
+// peer-window exchange: state (the entry points follow the report)
+// ------------------------------------------------------------------------------------------------
+struct nvrx_peer {
+    int device = 0, world = 0, rank = 0, stride = 0;
+    unsigned long long *window = nullptr;            // this process' window (fine-grained device memory)
+    std::vector<unsigned long long *> mapped;        // [world] every window as mapped in this process
+    std::vector<bool> opened;                        // mapped[p] came from hipIpcOpenMemHandle
+    unsigned long long **d_windows = nullptr;        // device copy of `mapped`
+    uint32_t *h_err = nullptr, *d_err = nullptr;     // pinned error word and its device address
+    uint32_t epoch = 0;
+    double timeout_s = 1800.0;
+    int wall_khz = 100000;
+    bool ready = false;
+};
+
+// Arguments of one exchange on `p` (advances the epoch: every process counts its exchanges the same way).
+static int peer_fill_args(nvrx_peer *p, const void *send, void *recv, size_t count, PeerArgs *a) {
+    if (!p || !p->ready || !send || !recv) return fail(NVRX_ERR_INVALID, "peer exchange is not ready");
+    if (count == 0 || count > (size_t)p->stride) return fail(NVRX_ERR_RANGE, "%zu floats per rank exceed the window's %d", count, p->stride);
+    *a = PeerArgs{};
+    a->windows = p->d_windows;
+    a->send = static_cast<const float *>(send);
+    a->recv = static_cast<float *>(recv);
+    a->err = p->d_err;
+    a->world = p->world;
+    a->rank = p->rank;
+    a->count = (int)count;
+    a->stride = p->stride;
+    p->epoch = (p->epoch % 0x7FFFFFFFu) + 1u;  // never 0
+    a->epoch = p->epoch;
+    a->timeout_ticks = (unsigned long long)(p->timeout_s * 1e3 * (double)p->wall_khz);
+    return NVRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // report (everything, one call)
 // ------------------------------------------------------------------------------------------------
 int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
@@ -1920,7 +1993,15 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         HIP_TRY(hipEventRecord(ctx->report_ev, as_stream(stream)));
         ctx->report_epoch++;
     }
-    if (exchanging) {
+    PeerArgs pa{};
+    bool prologue = false;
+    if (exchanging && d->allgather_fn == reinterpret_cast<void *>(&nvrx_peer_allgather) &&
+        score_fits_single_wg(d->R, d->K, d->S, d->d_scores, d->d_flags) && peer_prologue_enabled()) {
+        // peer windows + a table the single-workgroup score kernel takes: the exchange runs as that kernel's prologue
+        rc = peer_fill_args(static_cast<nvrx_peer *>(d->comm), d->d_send, d->d_table, (size_t)d->send_count, &pa);
+        if (rc) return rc;
+        prologue = true;
+    } else if (exchanging) {
         // ncclAllGather(sendbuff, recvbuff, sendcount, ncclFloat32 = 7, comm, stream), enqueued between the two
         // kernels on the same stream: this rank's rows -> every rank's [R, L] table (reporting.py:281,397)
         using AllGatherFn = int (*)(const void *, void *, size_t, int, void *, void *);
@@ -1929,9 +2010,9 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         if (nrc != 0) return fail(NVRX_ERR_HIP, "all-gather of the exchange rows failed (ncclResult %d)", nrc);
     }
     d->seq = (d->seq % 0x7FFFFFFFu) + 1u;
-    rc = nvrx_score(exchanging ? d->d_table : d->d_send, d->R, d->K, d->S, d->do_indiv, d->do_rel, d->thresholds,
-                    d->d_scores, d->d_flags, d->d_meta, d->d_done_counter, d->seq, d->d_stats, d->d_stats_dst,
-                    d->stats_rows, stream);
+    rc = score_launch(exchanging ? d->d_table : d->d_send, d->R, d->K, d->S, d->do_indiv, d->do_rel, d->thresholds,
+                      d->d_scores, d->d_flags, d->d_meta, d->d_done_counter, d->seq, d->d_stats, d->d_stats_dst,
+                      d->stats_rows, stream, prologue ? &pa : nullptr);
     if (rc) return rc;
     if (d->h_seq_word) return nvrx_poll_u32(d->h_seq_word, d->seq, d->timeout_s > 0.0 ? d->timeout_s : 1e30);
     return NVRX_OK;
@@ -1940,19 +2021,6 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
 // ------------------------------------------------------------------------------------------------
 // peer-window exchange
 // ------------------------------------------------------------------------------------------------
-struct nvrx_peer {
-    int device = 0, world = 0, rank = 0, stride = 0;
-    unsigned long long *window = nullptr;            // this process' window (fine-grained device memory)
-    std::vector<unsigned long long *> mapped;        // [world] every window as mapped in this process
-    std::vector<bool> opened;                        // mapped[p] came from hipIpcOpenMemHandle
-    unsigned long long **d_windows = nullptr;        // device copy of `mapped`
-    uint32_t *h_err = nullptr, *d_err = nullptr;     // pinned error word and its device address
-    uint32_t epoch = 0;
-    double timeout_s = 1800.0;
-    int wall_khz = 100000;
-    bool ready = false;
-};
-
 int nvrx_peer_create(int device, int world, int rank, int max_floats_per_rank, nvrx_peer **out) {
     if (!out) return fail(NVRX_ERR_INVALID, "out is null");
     *out = nullptr;
@@ -2031,21 +2099,10 @@ int nvrx_peer_ready(nvrx_peer *p, double timeout_s) {
 // Returns 0 or a positive code (ncclResult-style): nvrx_last_error() holds the message.
 int nvrx_peer_allgather(const void *send, void *recv, size_t count, int dtype, void *comm, void *stream) {
     nvrx_peer *p = static_cast<nvrx_peer *>(comm);
-    if (!p || !p->ready || !send || !recv) return -fail(NVRX_ERR_INVALID, "peer exchange is not ready");
     if (dtype != 7) return -fail(NVRX_ERR_INVALID, "peer exchange carries f32 only");
-    if (count == 0 || count > (size_t)p->stride) return -fail(NVRX_ERR_RANGE, "%zu floats per rank exceed the window's %d", count, p->stride);
     PeerArgs a{};
-    a.windows = p->d_windows;
-    a.send = static_cast<const float *>(send);
-    a.recv = static_cast<float *>(recv);
-    a.err = p->d_err;
-    a.world = p->world;
-    a.rank = p->rank;
-    a.count = (int)count;
-    a.stride = p->stride;
-    p->epoch = (p->epoch % 0x7FFFFFFFu) + 1u;  // never 0; every process counts its exchanges the same way
-    a.epoch = p->epoch;
-    a.timeout_ticks = (unsigned long long)(p->timeout_s * 1e3 * (double)p->wall_khz);
+    const int frc = peer_fill_args(p, send, recv, count, &a);
+    if (frc) return -frc;
     hipLaunchKernelGGL(k_peer_allgather, dim3(1), dim3(PEER_THREADS), 0, as_stream(stream), a);
     if (hipGetLastError() != hipSuccess) return -fail(NVRX_ERR_HIP, "k_peer_allgather launch failed");
     return 0;
