@@ -158,3 +158,19 @@ def test_config2_loop_over_peer_windows(asynchronous):
         got = res[0]["reports"][t]
         got["rank_to_node"] = exp["rank_to_node"]  # a process holds two logical ranks here
         compare_reports(got, exp, ("loop-peer", asynchronous, t), rel=1e-4)
+
+
+def test_ptl_callback_on_hip_backend_flags_the_slow_gpu():
+    """StragglerDetectionCallback (duck-typed trainer; Lightning is not in the image) on the HIP backend, two ranks
+    sharing the GPU: training_step is wrapped into a GPU-timed section, reports come on the time-derived interval, the
+    rank doing 4x the GPU work gets a low relative GPU score and the job is told to stop
+    (P/straggler_det_callback.py:106-117,239-254)."""
+    res = run_ranks(workers.ptl_callback_run, 2, timeout=200, use_oracle_backend=False, device=0, slow_rank=1)
+    r0 = res[0]
+    assert r0["interval"] is not None and res[1]["interval"] == r0["interval"]   # MAX-reduced: same on every rank
+    assert r0["sections"] == ["Strategy.training_step"]
+    assert r0["logged"] is not None and "gpu_relative_perf/min" in r0["logged"]
+    assert r0["logged"]["gpu_relative_perf/min"] < 0.7 <= r0["logged"]["gpu_relative_perf/max"]
+    assert any("GPU relative performance" in m for m in r0["messages"])
+    assert any("STRAGGLER DETECTION WARNING" in m and "rank=1" in m for m in r0["messages"]), r0["messages"][-6:]
+    assert r0["should_stop"] and res[1]["should_stop"]

@@ -659,3 +659,13 @@ def test_asynchronous_reports_match_synchronous_ones_and_defer_new_names(world):
                 np.testing.assert_allclose(list(a[key][n].values()), list(exp[n].values()), rtol=1e-6, equal_nan=True)
         if world > 1 and t >= 4:
             assert late in a["section_relative_perf_scores"]
+
+
+def test_ptl_callback_two_ranks_flags_the_slow_one():
+    """The PTL callback end to end on two gloo ranks (CPU checker backend; GPU twin in tests/test_gpu_multiproc.py)."""
+    res = run_ranks(workers.ptl_callback_run, 2, timeout=200, slow_rank=1)
+    r0 = res[0]
+    assert r0["interval"] is not None and res[1]["interval"] == r0["interval"]
+    assert r0["logged"]["gpu_relative_perf/min"] < 0.7 <= r0["logged"]["gpu_relative_perf/max"]
+    assert any("STRAGGLER DETECTION WARNING" in m and "rank=1" in m for m in r0["messages"])
+    assert r0["should_stop"] and res[1]["should_stop"]

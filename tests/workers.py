@@ -409,3 +409,70 @@ def folded_loop_config2(rank, world, asynchronous):
                 "fused": bool(plan is not None and plan.fused)}
     finally:
         job.close()
+
+
+def ptl_callback_run(rank, world, slow_rank):
+    """StragglerDetectionCallback driven by a duck-typed trainer (Lightning is not in the image): training_step does
+    real GPU work when a GPU backend is active, the slow rank does 4x of it; returns what the callback logged/decided."""
+    import logging
+
+    import torch
+
+    from nvidia_resiliency_ext.ptl_resiliency import StragglerDetectionCallback
+    from nvrx_straggler import Detector
+    from nvrx_straggler.backend import get_backend
+
+    on_gpu = get_backend().name == "hip"
+    x = torch.randn(1024, 1024, device="cuda") if on_gpu else None
+
+    class Strategy:
+        def training_step(self, batch):
+            reps = 4 if rank == slow_rank else 1
+            if on_gpu:
+                y = x
+                for _ in range(4 * reps):
+                    y = y @ x
+                torch.cuda.current_stream().synchronize()
+            else:
+                time.sleep(0.002 * reps)
+            return batch
+
+    class Trainer:
+        def __init__(self):
+            self.strategy = Strategy()
+            self.global_rank = rank
+            self.should_stop = False
+            self.checkpoint_callback = None
+
+    class Module:
+        def __init__(self):
+            self.logged = []
+
+        def log_dict(self, d, **kw):
+            self.logged.append(dict(d))
+
+    records = []
+
+    class Grab(logging.Handler):
+        def emit(self, record):
+            records.append(record.getMessage())
+
+    log = logging.getLogger("test.straggler.ptl")
+    log.setLevel(logging.INFO)
+    log.addHandler(Grab())
+    cb = StragglerDetectionCallback(report_time_interval=0.05, calc_relative_gpu_perf=True, calc_individual_gpu_perf=True,
+                                    num_gpu_perf_scores_to_print=2, gpu_relative_perf_threshold=0.7,
+                                    gpu_individual_perf_threshold=0.7, stop_if_detected=True, enable_ptl_logging=True,
+                                    logger_name="test.straggler.ptl")
+    trainer, module = Trainer(), Module()
+    cb.setup(trainer, module, "fit")
+    try:
+        for i in range(80):
+            trainer.strategy.training_step(i)
+            cb.on_train_batch_end(trainer, module, None, None, i)
+        return {"interval": Detector.report_interval_tracker.iter_interval, "should_stop": trainer.should_stop,
+                "logged": ({k: v for d in module.logged[-2:] for k, v in d.items()} if module.logged else None),
+                "messages": records,
+                "sections": sorted(Detector.custom_sections)}
+    finally:
+        cb.teardown(trainer, module, "fit")
