@@ -467,9 +467,17 @@ def ptl_callback_run(rank, world, slow_rank):
     trainer, module = Trainer(), Module()
     cb.setup(trainer, module, "fit")
     try:
-        for i in range(80):
+        # the report interval comes from the measured step time (0.05 s / median step): run until two reports have
+        # been produced on rank 0's clock; the iteration count is agreed through the report collectives themselves
+        n_iters = 80
+        tr = Detector.report_interval_tracker
+        i = 0
+        while i < n_iters:
             trainer.strategy.training_step(i)
             cb.on_train_batch_end(trainer, module, None, None, i)
+            i += 1
+            if i == 20 and tr.iter_interval is not None:
+                n_iters = max(n_iters, 2 * tr.iter_interval + 1)  # iter_interval is MAX-reduced: same on every rank
         return {"interval": Detector.report_interval_tracker.iter_interval, "should_stop": trainer.should_stop,
                 "logged": ({k: v for d in module.logged[-2:] for k, v in d.items()} if module.logged else None),
                 "messages": records,
