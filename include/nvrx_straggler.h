@@ -99,7 +99,7 @@ int nvrx_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8
  *      workgroup scores the whole table and writes d_scores / d_flags in 16-byte units when both are 16-byte
  *      aligned: pad each array to a multiple of 16 bytes;
  *   d_flags  [R][NVRX_SCORE_LEN(S)] u8 out, 1 where score < threshold (strict; NaN never flagged);
- *   d_meta   [NVRX_META_WORDS] u32 out: {all ranks' name flags set, R, K, S, seq, 0, 0, 0};
+ *   d_meta   [NVRX_META_WORDS] u32 out: {all ranks' name flags set, R, K, S, seq, seq of the statistics rows, 0, 0};
  *   d_done_counter  device word (zero before the first launch) or NULL.  When given, d_scores /
  *      d_flags / d_meta may point into pinned host memory (nvrx_host_alloc): after every block's
  *      results are visible system-wide the kernel stores `seq` into d_meta[4] with release
@@ -221,6 +221,11 @@ typedef struct nvrx_report_desc {
                                  the host does not block), or NULL; takes the place of torch.cuda.synchronize()
                                  in straggler.py:234 for the collectives the caller has enqueued there */
     int32_t order_after_enabled; /* 0: order_after_stream is ignored */
+    int32_t resident;         /* nonzero: the library may run the score kernel RESIDENT on a stream of its own next to the
+                                 statistics kernel (rows handed over as 8-byte tagged granules instead of through the
+                                 stream order); used for synchronous reports without an exchange or with the peer-window
+                                 exchange.  The statistics rows then land under their own completion word d_meta[5]. */
+    int32_t reserved;
     int32_t guard_rings;      /* asynchronous reports (h_seq_word == NULL, the caller polls later): nonzero makes later
                                  device-side ring writers on other streams (nvrx_stamp_end) wait, on the device, for this
                                  report's statistics kernel */

@@ -146,7 +146,13 @@ struct Epilogue {
     int KS;
     int L;
     float names_ok;
+    // resident-scorer reports: instead of the plain exchange-row stores, thread 0 publishes the row's results as
+    // ROW_GRANULES 8-byte {epoch, f32} granules (agent-scope atomic stores: the data is its own flag) that the score
+    // kernel, already resident on another stream, polls for; null = plain stores, ordered by the stream
+    unsigned long long *rowg;
+    uint32_t epoch;
 };
+constexpr int ROW_GRANULES = 11;  // med, history minimum, weight | the 8 words of the statistics row
 
 // Ablation switch for tools/kbench.cpp only (always 0 in the shipped library):
 // 1 = load + min/max/mean/std only (no selection), 0 = everything.
@@ -778,7 +784,16 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                 ep.hist_min[row] = h;
             }
         }
-        if (ep.send) {
+        if (ep.rowg) {
+            unsigned long long *g8 = ep.rowg + (size_t)blockIdx.x * ROW_GRANULES;
+            const unsigned long long tag = (unsigned long long)ep.epoch << 32;
+            const float vals[ROW_GRANULES] = {n ? r_med : -1.0f, n ? h : __builtin_nanf(""), weight,
+                                              r_min, r_max, r_med, r_avg, r_std, (float)n, weight, (float)path};
+#pragma unroll
+            for (int q = 0; q < ROW_GRANULES; q++)
+                __hip_atomic_store(g8 + q, tag | (unsigned long long)__float_as_uint(vals[q]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        } else if (ep.send) {
             const int lr = row / ep.rows_per_rank;
             float *s = ep.send + (size_t)lr * ep.L;
             const int g = row_gid;
@@ -904,11 +919,13 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
         __syncthreads();
         if (tid == 0 && a.R == 1) {
             // one workgroup: nobody to wait for
+            a.meta[5] = a.seq;
             __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         } else if (tid == 0) {
             const uint32_t ticket = atomicAdd(a.done_counter, 1u);
             if (ticket == (uint32_t)a.R - 1u) {
                 *a.done_counter = 0u;  // ready for the next launch (launches on one stream are ordered)
+                a.meta[5] = a.seq;     // statistics were forwarded by every block before its ticket
                 __threadfence_system();
                 __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -996,6 +1013,7 @@ __global__ __launch_bounds__(PEER_THREADS) void k_peer_allgather(PeerArgs a) { p
 //     NVRX_SCORE_FENCE=1 (read by the host library) adds the release fence back in front of that store.
 // ------------------------------------------------------------------------------------------------
 constexpr int SCORE1_THREADS = 1024;
+constexpr int SCORE1_RESIDENT_THREADS = 256;
 constexpr int SCORE1_MAX_RANKS = 64;
 constexpr size_t SCORE1_MAX_LDS = 60 * 1024;
 
@@ -1013,10 +1031,43 @@ __host__ __device__ inline size_t score1_lds_bytes(int R, int K, int S) {
     return ks4 * 4 + ((nout + 3) & ~(size_t)3) * 4 + ((nout + 15) & ~(size_t)15);
 }
 
-__global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fence, PeerArgs pa) {
+// Resident-scorer reports: where the score kernel finds the rows' results while k_row_stats is still running.
+struct GatherArgs {
+    const unsigned long long *g;  // this report's granules [n_blocks][ROW_GRANULES]; null = rows arrived by stream order
+    const int32_t *gid;           // [rows] ring row -> slot in the exchange row (-1 = not exchanged)
+    float *send;                  // [local_ranks][L] exchange rows, assembled here
+    nvrx_f4 *stats_out;           // [rows][2] statistics rows in the result block (forwarded after the scores), or null
+    uint32_t *err;                // host-visible word: epoch of a wait that gave up
+    int n_blocks, rows_active, rows_per_rank, local_ranks;
+    float names_ok;
+    uint32_t epoch;
+    unsigned long long timeout_ticks;
+};
+
+// One granule of this epoch (bounded wait; NaN + error word when the row never shows up).
+__device__ __forceinline__ float wait_granule(const unsigned long long *p, const GatherArgs &g, unsigned long long t0) {
+    uint32_t spins = 0;
+    for (;;) {
+        const unsigned long long x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(x >> 32) == g.epoch) return __uint_as_float((uint32_t)x);
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 0xFFu) == 0u && wall_clock64() - t0 > g.timeout_ticks) {
+            __hip_atomic_store(g.err, g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return __builtin_nanf("");
+        }
+    }
+}
+
+// NTHR = 1024: launched behind k_row_stats (or behind the exchange) on the report's stream.
+// NTHR = 256 : the RESIDENT scorer -- launched on a second stream next to k_row_stats, small enough (one wave per SIMD)
+//              to sit on a CU beside two row workgroups; it polls the rows' granules, so k_row_stats has no successor in
+//              its own queue (a queued successor adds ~1.9 us to a kernel's measured duration and the dependent launch
+//              ~1.5-2 us more to the report) and this kernel's dispatch is off the critical path.
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArgs pa, GatherArgs ga) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    __shared__ double s_red[8][SCORE1_THREADS / 64];   // two alternating sets of 4 (see the rank loop)
-    __shared__ uint32_t s_cnt[4][SCORE1_THREADS / 64];
+    __shared__ double s_red[8][NTHR / 64];   // two alternating sets of 4 (see the rank loop)
+    __shared__ uint32_t s_cnt[4][NTHR / 64];
 
     const int K = a.K, S = a.S, KS = K + S, R = a.R;
     const int L = NVRX_TABLE_LEN(K, S);
@@ -1028,7 +1079,21 @@ __global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fenc
     uint8_t *s_fl = reinterpret_cast<uint8_t *>(s_out + nout4);
     const int tid = threadIdx.x;
     const float NaN = __builtin_nanf("");
+    const unsigned long long t_begin = wall_clock64();
 
+    if (ga.g) {
+        // the rows' exchange values, as they are published: med / history minimum / weight of every launched row go
+        // to the slots k_row_stats itself would have written (packing loops of reporting.py:273-279)
+        for (int idx = tid; idx < ga.n_blocks * 3; idx += NTHR) {
+            const int b = idx / 3, q = idx - 3 * b;
+            const float v = wait_granule(ga.g + (size_t)b * ROW_GRANULES + q, ga, t_begin);
+            const int lr = b / ga.rows_active;
+            const int gidv = ga.gid[lr * ga.rows_per_rank + (b - lr * ga.rows_active)];
+            if (gidv >= 0 && gidv < KS && (q < 2 || gidv < K)) ga.send[(size_t)lr * L + q * KS + gidv] = v;
+        }
+        for (int lr = tid; lr < ga.local_ranks; lr += NTHR) ga.send[(size_t)lr * L + (L - 1)] = ga.names_ok;
+        __syncthreads();
+    }
     if (pa.windows) {
         // the report's exchange as this kernel's prologue: publish this process' rows into every window, sweep ours
         // into a.table (plain device memory, written and read by this one workgroup)
@@ -1036,12 +1101,12 @@ __global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fenc
         __syncthreads();
     }
     // local statistics rows -> result block; issued first so the loads overlap everything below
-    for (int i = tid; i < a.stats_n4; i += SCORE1_THREADS) {
+    for (int i = tid; i < a.stats_n4; i += NTHR) {
         const float4 v = a.stats_src[i];
         store16_sys(a.stats_dst + i, nvrx_f4{v.x, v.y, v.z, v.w});
     }
-    score_colmin(a, tid, SCORE1_THREADS, s_min);
-    if (a.meta && (tid >> 6) == SCORE1_THREADS / 64 - 1) score_meta(a, tid & 63);
+    score_colmin(a, tid, NTHR, s_min);
+    if (a.meta && (tid >> 6) == NTHR / 64 - 1) score_meta(a, tid & 63);
     // zero the padding of the staged arrays (it is stored too)
     if (tid < nout4 - nout) s_out[nout + tid] = 0.f;
     if (tid < ((nout + 15) & ~15) - nout) s_fl[nout + tid] = 0;
@@ -1049,7 +1114,7 @@ __global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fenc
 
     if (K == 0) {
         // no GPU-timed rows anywhere: every (rank, section) pair is independent -> one flat pass, no barriers
-        for (int idx = tid; idx < R * S; idx += SCORE1_THREADS) {
+        for (int idx = tid; idx < R * S; idx += NTHR) {
             const int r = idx / S, sct = idx - r * S;
             const float *__restrict__ row = a.table + (size_t)r * L;
             const float med = row[sct];
@@ -1063,7 +1128,7 @@ __global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fenc
             s_fl[r * W + 2 + sct] = ((double)si < a.thr[3]) ? 1 : 0;
             s_fl[r * W + 2 + S + sct] = ((double)sr < a.thr[1]) ? 1 : 0;
         }
-        for (int r = tid; r < R; r += SCORE1_THREADS) {  // reporting.py:226-228: no kernels -> NaN, never flagged
+        for (int r = tid; r < R; r += NTHR) {  // reporting.py:226-228: no kernels -> NaN, never flagged
             s_out[r * W] = NaN;
             s_out[r * W + 1] = NaN;
             s_fl[r * W] = 0;
@@ -1073,7 +1138,7 @@ __global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fenc
         // rank r's reduction scratch alternates between two sets: thread 0 may still be summing set r&1 while the
         // other waves already fill set (r+1)&1; set r&1 is rewritten only after the barrier of rank r+1.
         for (int r = 0; r < R; r++)
-            score_rank<SCORE1_THREADS>(a, r, tid, s_min, s_red + 4 * (r & 1), s_cnt + 2 * (r & 1), s_out + r * W, s_fl + r * W);
+            score_rank<NTHR>(a, r, tid, s_min, s_red + 4 * (r & 1), s_cnt + 2 * (r & 1), s_out + r * W, s_fl + r * W);
     }
     __syncthreads();
 
@@ -1081,21 +1146,43 @@ __global__ __launch_bounds__(SCORE1_THREADS) void k_score1(ScoreArgs a, int fenc
     {
         const nvrx_f4 *src = reinterpret_cast<const nvrx_f4 *>(s_out);
         nvrx_f4 *dst = reinterpret_cast<nvrx_f4 *>(a.scores);
-        for (int i = tid; i < nout4 / 4; i += SCORE1_THREADS) store16_sys(dst + i, src[i]);
+        for (int i = tid; i < nout4 / 4; i += NTHR) store16_sys(dst + i, src[i]);
         if (a.flags) {
             const nvrx_f4 *fsrc = reinterpret_cast<const nvrx_f4 *>(s_fl);
             nvrx_f4 *fdst = reinterpret_cast<nvrx_f4 *>(a.flags);
-            for (int i = tid; i < (nout + 15) / 16; i += SCORE1_THREADS) store16_sys(fdst + i, fsrc[i]);
+            for (int i = tid; i < (nout + 15) / 16; i += NTHR) store16_sys(fdst + i, fsrc[i]);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores (asm and plain) have been accepted
     __syncthreads();
-    if (tid == 0 && a.meta && a.done_counter) {
+    const bool publish = a.meta && a.done_counter;
+    if (tid == 0 && publish) {
         if (fence) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if (!(ga.g && ga.stats_out))  // statistics already forwarded above: both words at once
+            __hip_atomic_store(&a.meta[5], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (ga.g && ga.stats_out) {
+        // the statistics rows travel as granules too and are forwarded AFTER the scores were published: meta[5] is
+        // their own completion word (the host reads statistics lazily)
+        for (int idx = tid; idx < ga.n_blocks * 2; idx += NTHR) {
+            const int b = idx >> 1, half = idx & 1;
+            const unsigned long long *p = ga.g + (size_t)b * ROW_GRANULES + 3 + 4 * half;
+            nvrx_f4 v;
+            v.x = wait_granule(p + 0, ga, t_begin);
+            v.y = wait_granule(p + 1, ga, t_begin);
+            v.z = wait_granule(p + 2, ga, t_begin);
+            v.w = wait_granule(p + 3, ga, t_begin);
+            const int lr = b / ga.rows_active;
+            const int row = lr * ga.rows_per_rank + (b - lr * ga.rows_active);
+            store16_sys(ga.stats_out + (size_t)row * 2 + half, v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && publish) __hip_atomic_store(&a.meta[5], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1186,6 +1273,16 @@ int score_fence_enabled() {
     if (v < 0) {
         const char *e = getenv("NVRX_SCORE_FENCE");
         v = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    return v;
+}
+
+// NVRX_RESIDENT_SCORER=0 keeps the score kernel behind the statistics kernel on the report's stream (A/B measurements).
+int resident_scorer_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("NVRX_RESIDENT_SCORER");
+        v = (e && atoi(e) == 0) ? 0 : 1;
     }
     return v;
 }
@@ -1286,6 +1383,12 @@ struct nvrx_ctx {
     hipEvent_t order_ev = nullptr;  // nvrx_report: report stream ordered after the caller's stream
     // asynchronous reports: the statistics kernel of a report the host did not wait for may still be reading the
     // rings; device-side writers on other streams (k_stamp_end) are ordered after it with this event
+    // resident-scorer reports: the score kernel's own stream, the rows' granules (two parities) and their epoch
+    hipStream_t score_stream = nullptr;
+    unsigned long long *d_rowg = nullptr;
+    uint32_t *h_gather_err = nullptr, *d_gather_err = nullptr;  // pinned: epoch of a granule wait that gave up
+    uint32_t gran_epoch = 0;
+    int wall_khz = 100000;
     hipEvent_t report_ev = nullptr;
     uint64_t report_epoch = 0;  // bumped by every guarded report
     struct StreamEpoch {
@@ -1432,7 +1535,8 @@ static bool score_fits_single_wg(int R, int K, int S, const float *d_scores, con
 
 static int score_launch(const float *d_table, int R, int K, int S, int do_indiv, int do_rel, const double *thresholds,
                         float *d_scores, uint8_t *d_flags, uint32_t *d_meta, uint32_t *d_done_counter, uint32_t seq,
-                        const float *d_stats_src, float *d_stats_dst, int stats_rows, void *stream, const PeerArgs *pa) {
+                        const float *d_stats_src, float *d_stats_dst, int stats_rows, void *stream, const PeerArgs *pa,
+                        const GatherArgs *ga = nullptr) {
     if (R <= 0 || K < 0 || S < 0) return fail(NVRX_ERR_INVALID, "bad table shape R=%d K=%d S=%d", R, K, S);
     if (!d_table || !d_scores) return fail(NVRX_ERR_INVALID, "null device pointer");
     hipStream_t st = as_stream(stream);
@@ -1459,11 +1563,19 @@ static int score_launch(const float *d_table, int R, int K, int S, int do_indiv,
     // units: the caller's buffers must be 16-byte aligned and padded to a multiple of 16 bytes (the workspace is).
     if (score_fits_single_wg(R, K, S, d_scores, d_flags)) {
         PeerArgs none{};
-        hipLaunchKernelGGL(k_score1, dim3(1), dim3(SCORE1_THREADS), score1_lds_bytes(R, K, S), st, a, score_fence_enabled(),
-                           pa ? *pa : none);
+        GatherArgs nog{};
+        if (ga) {
+            a.stats_n4 = 0;  // statistics come through the granules
+            hipLaunchKernelGGL(k_score1<SCORE1_RESIDENT_THREADS>, dim3(1), dim3(SCORE1_RESIDENT_THREADS), score1_lds_bytes(R, K, S), st, a,
+                               score_fence_enabled(), pa ? *pa : none, *ga);
+        } else {
+            hipLaunchKernelGGL(k_score1<SCORE1_THREADS>, dim3(1), dim3(SCORE1_THREADS), score1_lds_bytes(R, K, S), st, a,
+                               score_fence_enabled(), pa ? *pa : none, nog);
+        }
         HIP_TRY(hipGetLastError());
         return NVRX_OK;
     }
+    if (ga) return fail(NVRX_ERR_STATE, "the resident scorer needs the single-workgroup score kernel");
     if (pa) return fail(NVRX_ERR_STATE, "the exchange prologue needs the single-workgroup score kernel");
     size_t lds = (size_t)KS * sizeof(float);
     if (R > 64 || lds > 48 * 1024) {
@@ -1565,12 +1677,23 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     CTX_TRY(hipEventCreateWithFlags(&ctx->stamp_ev, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->report_ev, hipEventDisableTiming));
+    CTX_TRY(hipStreamCreateWithFlags(&ctx->score_stream, hipStreamNonBlocking));
+    {
+        const size_t gbytes = 2ull * (size_t)ctx->rows * ROW_GRANULES * sizeof(unsigned long long);
+        CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_rowg), gbytes));
+        CTX_TRY(hipMemset(ctx->d_rowg, 0, gbytes));  // tag 0 is never a valid epoch
+        CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_gather_err), 64, hipHostMallocMapped));
+        ctx->h_gather_err[0] = 0;
+        CTX_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->d_gather_err), ctx->h_gather_err, 0));
+    }
     CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
     CTX_TRY(hipMemset(ctx->d_stamps, 0, nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
     {
         int khz = 0;
-        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) {
             ctx->us_per_tick = 1000.0f / (float)khz;
+            ctx->wall_khz = khz;
+        }
     }
     CTX_TRY(hipDeviceSynchronize());
 #undef CTX_TRY
@@ -1606,6 +1729,9 @@ int nvrx_ctx_destroy(nvrx_ctx *ctx) {
     if (ctx->stamp_ev) (void)hipEventDestroy(ctx->stamp_ev);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     if (ctx->report_ev) (void)hipEventDestroy(ctx->report_ev);
+    if (ctx->score_stream) (void)hipStreamDestroy(ctx->score_stream);
+    if (ctx->d_rowg) (void)hipFree(ctx->d_rowg);
+    if (ctx->h_gather_err) (void)hipHostFree(ctx->h_gather_err);
     if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
     delete ctx;
     return NVRX_OK;
@@ -1898,8 +2024,16 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
 // ------------------------------------------------------------------------------------------------
 // report (local half)
 // ------------------------------------------------------------------------------------------------
+static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
+                             void *stream, unsigned long long *rowg, uint32_t epoch);
+
 int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
                       void *stream) {
+    return report_local_impl(ctx, d_stats, d_send, K, S, names_ok, rows_active, stream, nullptr, 0);
+}
+
+static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
+                             void *stream, unsigned long long *rowg, uint32_t epoch) {
     hipStream_t st = as_stream(stream);
     if (!ctx || !d_stats) return fail(NVRX_ERR_INVALID, "null argument");
     if (K < 0 || S < 0) return fail(NVRX_ERR_INVALID, "bad K/S");
@@ -1922,6 +2056,8 @@ int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S
     ep.KS = K + S;
     ep.L = NVRX_TABLE_LEN(K, S);
     ep.names_ok = names_ok ? 1.0f : 0.0f;
+    ep.rowg = rowg;
+    ep.epoch = epoch;
     int pair = -1;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     if (ctx->timing) {
@@ -1985,6 +2121,48 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         HIP_TRY(hipEventRecord(ctx->order_ev, as_stream(d->order_after_stream)));
         HIP_TRY(hipStreamWaitEvent(as_stream(stream), ctx->order_ev, 0));
+    }
+    // Resident scorer: the score kernel goes to its own stream NEXT TO the statistics kernel and picks the rows' results
+    // up as they are published (8-byte tagged granules), so neither kernel has a queued successor / predecessor.
+    // Synchronous reports only, no exchange or the peer-window exchange (an RCCL all-gather needs the stream order).
+    const int rows_launch = (d->rows_active > 0 ? d->rows_active : ctx->rows_per_rank) * ctx->local_ranks;
+    const bool peer_route = exchanging && d->allgather_fn == reinterpret_cast<void *>(&nvrx_peer_allgather) && peer_prologue_enabled();
+    const bool resident = d->resident && d->h_seq_word && !d->guard_rings && (!exchanging || peer_route) && rows_launch > 0 &&
+                          score_fits_single_wg(d->R, d->K, d->S, d->d_scores, d->d_flags) && resident_scorer_enabled();
+    if (resident) {
+        ctx->gran_epoch = (ctx->gran_epoch % 0x7FFFFFFFu) + 1u;
+        unsigned long long *slice = ctx->d_rowg + (size_t)(ctx->gran_epoch & 1u) * (size_t)ctx->rows * ROW_GRANULES;
+        int rc2 = report_local_impl(ctx, d->d_stats, d->d_send, d->K, d->S, d->names_ok, d->rows_active, stream, slice,
+                                    ctx->gran_epoch);
+        if (rc2) return rc2;
+        GatherArgs ga{};
+        ga.g = slice;
+        ga.gid = ctx->d_gid;
+        ga.send = d->d_send;
+        ga.stats_out = (d->d_stats_dst && d->stats_rows > 0) ? reinterpret_cast<nvrx_f4 *>(d->d_stats_dst) : nullptr;
+        ga.err = ctx->d_gather_err;
+        ga.n_blocks = rows_launch;
+        ga.rows_active = d->rows_active > 0 ? d->rows_active : ctx->rows_per_rank;
+        ga.rows_per_rank = ctx->rows_per_rank;
+        ga.local_ranks = ctx->local_ranks;
+        ga.names_ok = d->names_ok ? 1.0f : 0.0f;
+        ga.epoch = ctx->gran_epoch;
+        ga.timeout_ticks = (unsigned long long)((d->timeout_s > 0.0 ? d->timeout_s : 1e9) * 1e3 * (double)ctx->wall_khz);
+        PeerArgs pa{};
+        if (peer_route) {
+            rc2 = peer_fill_args(static_cast<nvrx_peer *>(d->comm), d->d_send, d->d_table, (size_t)d->send_count, &pa);
+            if (rc2) return rc2;
+        }
+        d->seq = (d->seq % 0x7FFFFFFFu) + 1u;
+        rc2 = score_launch(exchanging ? d->d_table : d->d_send, d->R, d->K, d->S, d->do_indiv, d->do_rel, d->thresholds,
+                           d->d_scores, d->d_flags, d->d_meta, d->d_done_counter, d->seq, nullptr, nullptr, 0,
+                           ctx->score_stream, peer_route ? &pa : nullptr, &ga);
+        if (rc2) return rc2;
+        rc2 = nvrx_poll_u32(d->h_seq_word, d->seq, d->timeout_s > 0.0 ? d->timeout_s : 1e30);
+        if (rc2) return rc2;
+        if (*static_cast<volatile uint32_t *>(ctx->h_gather_err) == ctx->gran_epoch)
+            return fail(NVRX_ERR_TIMEOUT, "the score kernel gave up waiting for the statistics kernel's rows (epoch %u)", ctx->gran_epoch);
+        return NVRX_OK;
     }
     int rc = nvrx_report_local(ctx, d->d_stats, d->d_send, d->K, d->S, d->names_ok, d->rows_active, stream);
     if (rc) return rc;

@@ -118,7 +118,8 @@ class Workspace:
         self.d_meta = self.d_ptr + self._off_meta
         self.d_scores = self.d_ptr + self._off_scores
         self.d_flags = self.d_ptr + self._off_flags
-        self.h_seq = self.h_ptr + self._off_meta + 16  # meta[4]
+        self.h_seq = self.h_ptr + self._off_meta + 16  # meta[4]: scores / flags / meta have landed
+        self.h_seq2 = self.h_ptr + self._off_meta + 20  # meta[5]: the statistics rows have landed
         self.done_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.d_counter = self.done_counter.data_ptr()
         self.seq = 0
@@ -151,6 +152,14 @@ class Workspace:
     def host_block(self) -> np.ndarray:
         """A private copy of the pinned result block (the block itself is overwritten by the next report)."""
         return self._host.copy()
+
+    def host_head(self) -> np.ndarray:
+        """A private copy of meta | scores | flags (valid once meta[4] shows the report's sequence number)."""
+        return self._host[: self._off_stats].copy()
+
+    def host_stats(self, rows: int) -> np.ndarray:
+        """A private copy of the first ``rows`` statistics rows (valid once meta[5] shows the sequence number)."""
+        return self.stats[:rows].copy()
 
     def set_send_row(self, lr: int, row: np.ndarray) -> None:
         """Host-packed exchange row (dict-input path)."""
@@ -237,10 +246,11 @@ class HipBackend:
                 self.retire_workspace(ws)
                 _native.check(rc)
 
-    def wait_seq(self, ws: Workspace, seq: int) -> None:
-        """Block until the report that was enqueued with sequence number ``seq`` has published its results."""
+    def wait_seq(self, ws: Workspace, seq: int, stats: bool = False) -> None:
+        """Block until the report that was enqueued with sequence number ``seq`` has published its results
+        (``stats=True``: its statistics rows, which a resident score kernel forwards after the scores)."""
         timeout = report_timeout_s()
-        rc = self.lib.nvrx_poll_u32(ws.h_seq, seq, timeout if timeout > 0 else 1e30)
+        rc = self.lib.nvrx_poll_u32(ws.h_seq2 if stats else ws.h_seq, seq, timeout if timeout > 0 else 1e30)
         if rc < 0:
             self.retire_workspace(ws)
             _native.check(rc)
@@ -429,6 +439,7 @@ class HipRings:
             d.timeout_s = report_timeout_s()
             d.h_seq_word = ws.h_seq if wait else None
             d.guard_rings = 0 if wait else 1
+            d.resident = 1 if wait else 0  # the library decides (no exchange / peer windows, table fits one workgroup)
             ws.desc_key = key
         if order_after is not None:  # the caller's current stream: the report follows what is enqueued there
             d.order_after_stream, d.order_after_enabled = order_after, 1
@@ -436,6 +447,7 @@ class HipRings:
             d.order_after_enabled = 0
         if not ws.send_initialised:
             self.backend.send_init(ws)
+            self.backend.synchronize()  # cold: a resident score kernel touches the exchange rows from its own stream
         d.seq = max(d.seq, ws.seq)
         rc = self.lib.nvrx_report(self.ctx, ws.desc_ref, self.backend._stream_handle)
         ws.seq = d.seq

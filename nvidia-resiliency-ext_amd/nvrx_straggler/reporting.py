@@ -25,6 +25,7 @@ import dataclasses
 import os
 import threading
 import time
+import weakref
 from typing import Any, Dict, Iterator, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -83,6 +84,25 @@ class _PendingBlock:
         return self.blob
 
 
+class _StatsLater:
+    """The statistics rows of a report whose scores have already arrived: a resident score kernel forwards them
+    after it published the scores, under a completion word of their own.  ``get()`` waits for that word and takes a
+    private copy; the generator calls it before the next report overwrites the block if anybody still holds this."""
+
+    __slots__ = ("backend", "ws", "seq", "rows", "array", "__weakref__")
+
+    def __init__(self, backend, ws, seq: int, rows: int):
+        self.backend, self.ws, self.seq, self.rows = backend, ws, seq, rows
+        self.array: Optional[np.ndarray] = None
+
+    def get(self) -> np.ndarray:
+        if self.array is None:
+            self.backend.wait_seq(self.ws, self.seq, stats=True)
+            self.array = self.ws.host_stats(self.rows)
+            self.backend = self.ws = None
+        return self.array
+
+
 class _ScoreSource:
     """What a steady-state report keeps of the result block: a private copy of the score / statistics
     arrays plus the (shared, immutable) name tables of the plan.  The six mapping fields of ``Report`` are
@@ -103,7 +123,15 @@ class _ScoreSource:
         off_s, off_f, off_t, R, W, lo, hi, stats_rows = self.layout
         self.scores = blob[off_s : off_s + R * W * 4].view(np.float32).reshape(R, W)[lo:hi]
         self.flags = blob[off_f : off_f + R * W].reshape(R, W)[lo:hi]
-        self.stats = blob[off_t : off_t + stats_rows * 32].view(np.float32).reshape(stats_rows, 8)
+        if blob.size >= off_t + stats_rows * 32:  # a copy of the whole block; else the statistics come later
+            self.stats = blob[off_t : off_t + stats_rows * 32].view(np.float32).reshape(stats_rows, 8)
+
+    def statistics(self) -> np.ndarray:
+        self.ensure()
+        st = self.stats
+        if type(st) is _StatsLater:
+            st = self.stats = st.get()
+        return st
 
     def ensure(self) -> "_ScoreSource":
         if self.scores is None:
@@ -126,9 +154,9 @@ class _ScoreSource:
         if field == "section_individual_perf_scores":
             return self._sections(2) if (self.has_indiv and self.names) else {}
         if field == "local_section_summaries":
-            return _summaries_from_rows(self.section_rows, self.stats)
+            return _summaries_from_rows(self.section_rows, self.statistics())
         if field == "local_kernel_summaries":
-            return _summaries_from_rows(self.kernel_rows, self.stats)
+            return _summaries_from_rows(self.kernel_rows, self.statistics())
         raise AttributeError(field)
 
     def _sections(self, first_col: int) -> Dict[str, Dict[int, float]]:
@@ -356,6 +384,7 @@ class ReportGenerator:
         # that waits for the device on first read; the block in flight is settled before the next report starts
         self.asynchronous = bool(asynchronous)
         self._inflight: Optional[_PendingBlock] = None
+        self._stats_later = None  # (weakref to the _StatsLater, workspace, sequence) of the last synchronous one-call report
         self.exchange_info: Dict[str, Any] = {}
 
     # ---- pieces kept from the reference's host logic ----------------------------------------------
@@ -559,6 +588,20 @@ class ReportGenerator:
         self._ring_gid_state = None  # the general path must re-derive its own view if it runs next
         return plan
 
+    def _settle_stats(self) -> None:
+        """Before a workspace is used again: the previous one-call report's statistics rows must have landed (a
+        resident score kernel forwards them after the scores, from its own stream), and if somebody still holds that
+        report they leave the result block now (they are copied lazily)."""
+        pending = self._stats_later
+        if pending is not None:
+            self._stats_later = None
+            ref, ws, seq = pending
+            later = ref()
+            if later is not None:
+                later.get()
+            else:
+                _backend_mod.get_backend().wait_seq(ws, seq, stats=True)
+
     def _settle_inflight(self) -> bool:
         """Wait for the asynchronous report still in flight (if any) before its workspace is touched again.
         Returns True when that report's exchange showed a rank with names that have no id yet: every rank sees the
@@ -623,7 +666,14 @@ class ReportGenerator:
         if self.gather_on_rank0 and self.rank != 0:
             return None
         src = self._source_for(plan, ws)
-        src.pending = ws.host_block()  # one memcpy out of the pinned block; cut into views when the report is first read
+        if fused:
+            # scores / flags now (one memcpy of the block's head, cut into views when the report is first read); the
+            # statistics rows when somebody asks for them -- a resident score kernel forwards them after the scores
+            src.pending = ws.host_head()
+            later = src.stats = _StatsLater(be, ws, ws.seq, plan.stats_needed)
+            self._stats_later = (weakref.ref(later), ws, ws.seq)
+        else:
+            src.pending = ws.host_block()
         flags = _DeviceFlags(self.thresholds, src, plan.ranks, plan.names, plan.cols, ws.S, src.has_rel, src.has_indiv)
         return Report._from_device(
             src, self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
@@ -643,6 +693,8 @@ class ReportGenerator:
         self.rank = dist_utils.get_rank(self.group)
         if self._inflight is not None:
             self._settle_inflight()
+        if self._stats_later is not None:
+            self._settle_stats()
         if not self._direct_tried:
             self._maybe_create_direct_exchange()
         kernel_summaries = self._filter_out_nccl_kernels(kernel_summaries)
@@ -688,6 +740,8 @@ class ReportGenerator:
         """
         t0 = time.perf_counter_ns()
         self.world_size, self.rank = dist_utils.world_and_rank(self.group)
+        if self._stats_later is not None:
+            self._settle_stats()
         if not self._direct_tried:
             self._maybe_create_direct_exchange()
         # steady state: same name tables as last time -> run the cached plan

@@ -49,6 +49,12 @@ class OracleWorkspace:
     def host_block(self):
         return self._host.copy()
 
+    def host_head(self):
+        return self._host[: self._off_stats].copy()
+
+    def host_stats(self, rows):
+        return self.stats[:rows].copy()
+
     def set_send_row(self, lr, row):
         self.send[lr].copy_(torch.from_numpy(row))
         self.send_initialised = True
@@ -72,7 +78,7 @@ class OracleBackend:
             return None
         return _OracleDirect(group)
 
-    def wait_seq(self, ws, seq):
+    def wait_seq(self, ws, seq, stats=False):
         assert ws.seq >= seq  # the emulation computes at enqueue time
 
     def stream_context(self):

@@ -37,6 +37,22 @@ __global__ void k_between_release(uint32_t *host_word, uint32_t v) {  // between
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(host_word, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__global__ void k_between_plain(float *dev_word, float v) {  // between=6: a different kernel, nothing special in it
+    if (threadIdx.x == 0) dev_word[0] = v;
+}
+__global__ void k_between_hoststore(uint32_t *host_word, uint32_t v) {  // between=7: stores to pinned host memory, drained, no fence
+    if (threadIdx.x < 64) __hip_atomic_store(host_word + threadIdx.x % 8, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__global__ void k_spin(unsigned long long ticks, uint32_t *sink) {  // between=11: resident poller on ANOTHER stream while the rows run
+    const unsigned long long t0 = wall_clock64();
+    uint32_t spins = 0;
+    while (wall_clock64() - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(4);
+        spins += __hip_atomic_load(sink, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (spins == 0xFFFFFFFFu) *sink = spins;
+}
 __global__ void k_between_sweep(const float4 *p, size_t n4, float *sink) {
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -123,11 +139,51 @@ int main(int argc, char **argv) {
         if (!best) continue;
         Epilogue ep{};
         (void)use_win;
+        // KB_EP=1: the report path's epilogue (gid / history loads, exchange-row stores); KB_STREAM=1|2: launch on a created
+        // stream (non-blocking / high priority) instead of the null stream
+        static float *d_send = nullptr, *d_hmin = nullptr;
+        static int32_t *d_gidv = nullptr;
+        if (getenv("KB_EP")) {
+            if (!d_send) {
+                CK(hipMalloc(&d_send, (size_t)(2 * rows + 1) * 4 * 8));
+                CK(hipMalloc(&d_hmin, rows * 4));
+                CK(hipMalloc(&d_gidv, rows * 4));
+                std::vector<int32_t> g(rows);
+                for (int r = 0; r < rows; r++) g[r] = r % 64;
+                CK(hipMemcpy(d_gidv, g.data(), rows * 4, hipMemcpyHostToDevice));
+                CK(hipMemset(d_hmin, 0x7f, rows * 4));
+            }
+            ep.gid = d_gidv;
+            ep.hist_min = d_hmin;
+            ep.send = d_send;
+            ep.rows_per_rank = 64;
+            ep.rows_active = 64;
+            ep.K = 0;
+            ep.KS = 64;
+            ep.L = 129;
+            ep.names_ok = 1.0f;
+        }
+        static hipStream_t kb_stream = nullptr;
+        if (getenv("KB_STREAM") && !kb_stream) {
+            if (atoi(getenv("KB_STREAM")) == 2) {
+                int lo, hi;
+                CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                CK(hipStreamCreateWithPriority(&kb_stream, hipStreamNonBlocking, hi));
+            } else {
+                CK(hipStreamCreateWithFlags(&kb_stream, hipStreamNonBlocking));
+            }
+        }
         CK(hipMemset(d_wlo, 0, rows * 4));
         CK(hipMemset(d_wsh, 0xFF, rows * 4));
+        static hipStream_t spin_stream = nullptr;
+        if (between == 11 && !spin_stream) CK(hipStreamCreateWithFlags(&spin_stream, hipStreamNonBlocking));
         auto launch = [&]() -> float {
-            hipExtLaunchKernelGGL(best->fn, dim3(rows), dim3(best->threads), 0, nullptr, a, b, 0, (const float *)d_s,
-                                  (const uint32_t *)d_c, (const uint8_t *)nullptr, stride, d_stats, ep, -1);
+            hipExtLaunchKernelGGL(best->fn, dim3(rows), dim3(best->threads), 0, kb_stream, a, b, 0, (const float *)d_s,
+                                  (const uint32_t *)d_c, (const uint8_t *)nullptr, stride, d_stats, ep, getenv("KB_UNIFORM") ? n : -1);
+            if (between == 11) {  // 256-thread poller for ~15 us (100 MHz wall clock), launched right behind the rows
+                hipLaunchKernelGGL(k_spin, dim3(1), dim3(256), 0, spin_stream, 1500ull, (uint32_t *)d_wlo);
+                CK(hipStreamSynchronize(spin_stream));
+            }
             CK(hipEventSynchronize(b));
             float ms;
             CK(hipEventElapsedTime(&ms, a, b));
@@ -170,6 +226,18 @@ int main(int argc, char **argv) {
             if (between == 1 || between == 3) hipLaunchKernelGGL(k_between_fence, dim3(1), dim3(256), 0, nullptr, h_word, (uint32_t)i);
             if (between == 4) hipLaunchKernelGGL(k_between_release, dim3(8), dim3(256), 0, nullptr, h_word, (uint32_t)i);
             if (between == 5) hipLaunchKernelGGL(k_between_fence, dim3(8), dim3(256), 0, nullptr, h_word, (uint32_t)i);
+            if (between == 6) hipLaunchKernelGGL(k_between_plain, dim3(1), dim3(256), 0, nullptr, d_stats + (size_t)rows * 8 - 1, (float)i);
+            if (between == 7) hipLaunchKernelGGL(k_between_hoststore, dim3(1), dim3(256), 0, nullptr, h_word, (uint32_t)i);
+            if (between == 9)  // the SAME kernel function on one row in between
+                hipLaunchKernelGGL(best->fn, dim3(1), dim3(best->threads), 0, nullptr, (const float *)d_s, (const uint32_t *)d_c,
+                                   (const uint8_t *)nullptr, stride, d_stats, ep, -1);
+            if (between == 10)  // another instantiation of the same template on one row in between
+                hipLaunchKernelGGL(kVariants[0].fn, dim3(1), dim3(kVariants[0].threads), 0, nullptr, (const float *)d_s,
+                                   (const uint32_t *)d_c, (const uint8_t *)nullptr, 1024, d_stats, ep, 777);
+            if (between == 8) {  // host-side gap only: the queue sits idle for 30 us before the launch
+                const auto t0 = std::chrono::steady_clock::now();
+                while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(30)) {}
+            }
             if (between == 2) hipLaunchKernelGGL(k_between_sweep, dim3(2048), dim3(256), 0, nullptr, (const float4 *)d_sweep, sweep_n4, d_stats);
             if (between == 3) {
                 CK(hipDeviceSynchronize());
