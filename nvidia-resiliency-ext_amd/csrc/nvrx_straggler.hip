@@ -196,6 +196,8 @@ struct ScoreArgs {
     const float4 *stats_src;  // optional: statistics rows to forward (device -> pinned host)
     float4 *stats_dst;
     int stats_n4;
+    int tab_in_lds;   // k_score1 with a prologue (row gather / peer exchange): keep the table it assembles in LDS
+    int send_floats;  // local_ranks * L
 };
 
 // all_reduce(MIN) of the f32 MED tensor with -1 sentinels (reporting.py:273-295) into s_min[KS]
@@ -965,34 +967,63 @@ struct PeerArgs {
 };
 
 // The exchange, by every thread of the calling workgroup (no barrier inside; the caller synchronises before reading recv).
-__device__ __forceinline__ void peer_exchange_block(const PeerArgs &a) {
+// `lds_send` (optional): this process' rows as the calling workgroup holds them in LDS (read instead of a.send);
+// `lds_tab` (optional): LDS copy of the gathered table, filled next to a.recv, so the caller can score without
+// reading back what it has just written to memory.
+__device__ __forceinline__ void peer_exchange_block(const PeerArgs &a, const float *lds_send = nullptr, float *lds_tab = nullptr) {
     const int nthr = (int)blockDim.x;
     const int total = a.world * a.count;
     const size_t slot = (size_t)(a.epoch & 1u) * (size_t)a.world;
+    const float *src = lds_send ? lds_send : a.send;
     for (int idx = threadIdx.x; idx < total; idx += nthr) {
         const int p = idx / a.count, j = idx - p * a.count;
-        const unsigned long long g = ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(a.send[j]);
+        const unsigned long long g = ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(src[j]);
         __hip_atomic_store(a.windows[p] + (slot + (size_t)a.rank) * (size_t)a.stride + j, g, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // Sweep: every pass issues the loads of ALL granules this thread still waits for, so that one pass (one memory
+    // round trip) after the last peer has published the thread is done -- polling them one after the other would put
+    // a round trip per granule behind the last arrival.
     const unsigned long long *mine = a.windows[a.rank];
     const unsigned long long t0 = wall_clock64();
-    for (int idx = threadIdx.x; idx < total; idx += nthr) {
-        const int r = idx / a.count, j = idx - r * a.count;
-        const unsigned long long *g = mine + (slot + (size_t)r) * (size_t)a.stride + j;
-        unsigned long long x;
+    constexpr int CH = 8;
+    for (int base = threadIdx.x; base < total; base += nthr * CH) {
+        unsigned long long x[CH];
+        uint32_t pending = 0;
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+            if (base + c * nthr < total) pending |= 1u << c;
         uint32_t spins = 0;
-        for (;;) {
-            x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((uint32_t)(x >> 32) == a.epoch) break;
-            __builtin_amdgcn_s_sleep(4);
-            if ((++spins & 0xFFu) == 0u && wall_clock64() - t0 > a.timeout_ticks) {
-                x = 0x7FC00000ull;  // NaN
-                __hip_atomic_store(a.err, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
+        while (pending) {
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+                if (pending & (1u << c)) {
+                    const int idx = base + c * nthr;
+                    const int r = idx / a.count, j = idx - r * a.count;
+                    x[c] = __hip_atomic_load(mine + (slot + (size_t)r) * (size_t)a.stride + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+                if ((pending & (1u << c)) && (uint32_t)(x[c] >> 32) == a.epoch) {
+                    const float v = __uint_as_float((uint32_t)x[c]);
+                    a.recv[base + c * nthr] = v;
+                    if (lds_tab) lds_tab[base + c * nthr] = v;
+                    pending &= ~(1u << c);
+                }
+            if (pending) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 0xFFu) == 0u && wall_clock64() - t0 > a.timeout_ticks) {
+#pragma unroll
+                    for (int c = 0; c < CH; c++)
+                        if (pending & (1u << c)) {
+                            a.recv[base + c * nthr] = __builtin_nanf("");
+                            if (lds_tab) lds_tab[base + c * nthr] = __builtin_nanf("");
+                        }
+                    __hip_atomic_store(a.err, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    pending = 0;
+                }
             }
         }
-        a.recv[idx] = __uint_as_float((uint32_t)x);
     }
 }
 
@@ -1029,6 +1060,10 @@ __host__ __device__ inline size_t score1_lds_bytes(int R, int K, int S) {
     const size_t ks4 = (size_t)((K + S + 3) & ~3);
     const size_t nout = (size_t)R * NVRX_SCORE_LEN(S);
     return ks4 * 4 + ((nout + 3) & ~(size_t)3) * 4 + ((nout + 15) & ~(size_t)15);
+}
+// extra LDS of the prologue variants: the gathered table [R][L] and this process' rows [send_floats]
+__host__ __device__ inline size_t score1_table_lds_bytes(int R, int K, int S, int send_floats) {
+    return (((size_t)R * NVRX_TABLE_LEN(K, S) + 3) & ~(size_t)3) * 4 + (((size_t)send_floats + 3) & ~(size_t)3) * 4;
 }
 
 // Resident-scorer reports: where the score kernel finds the rows' results while k_row_stats is still running.
@@ -1077,28 +1112,84 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
     float *s_min = reinterpret_cast<float *>(s_raw);
     float *s_out = s_min + ((KS + 3) & ~3);
     uint8_t *s_fl = reinterpret_cast<uint8_t *>(s_out + nout4);
+    // prologue variants keep what they assemble in LDS: scoring then never reads back what was just written to memory
+    float *s_tab = a.tab_in_lds ? reinterpret_cast<float *>(s_fl + ((nout + 15) & ~15)) : nullptr;  // [R][L]
+    float *s_send = a.tab_in_lds ? s_tab + ((R * L + 3) & ~3) : nullptr;                             // [send_floats]
     const int tid = threadIdx.x;
     const float NaN = __builtin_nanf("");
     const unsigned long long t_begin = wall_clock64();
 
+    if (ga.g && s_send) {
+        // sentinels of the exchange row (nvrx_send_init): -1 = no statistics, NaN history, zero weight
+        for (int j = tid; j < a.send_floats; j += NTHR) {
+            const int col = j % L;
+            s_send[j] = col < KS ? -1.0f : (col < 2 * KS ? NaN : 0.0f);
+        }
+        __syncthreads();
+    }
     if (ga.g) {
         // the rows' exchange values, as they are published: med / history minimum / weight of every launched row go
         // to the slots k_row_stats itself would have written (packing loops of reporting.py:273-279)
-        for (int idx = tid; idx < ga.n_blocks * 3; idx += NTHR) {
-            const int b = idx / 3, q = idx - 3 * b;
-            const float v = wait_granule(ga.g + (size_t)b * ROW_GRANULES + q, ga, t_begin);
-            const int lr = b / ga.rows_active;
-            const int gidv = ga.gid[lr * ga.rows_per_rank + (b - lr * ga.rows_active)];
-            if (gidv >= 0 && gidv < KS && (q < 2 || gidv < K)) ga.send[(size_t)lr * L + q * KS + gidv] = v;
+        // (all granules a thread still waits for are loaded in every pass: one round trip behind the last arrival)
+        constexpr int CH = 8;
+        const int total = ga.n_blocks * 3;
+        for (int base = tid; base < total; base += NTHR * CH) {
+            unsigned long long x[CH];
+            uint32_t pending = 0;
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+                if (base + c * NTHR < total) pending |= 1u << c;
+            uint32_t spins = 0;
+            while (pending) {
+#pragma unroll
+                for (int c = 0; c < CH; c++)
+                    if (pending & (1u << c)) {
+                        const int idx = base + c * NTHR;
+                        const int b = idx / 3, q = idx - 3 * b;
+                        x[c] = __hip_atomic_load(ga.g + (size_t)b * ROW_GRANULES + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                for (int c = 0; c < CH; c++) {
+                    if (!(pending & (1u << c))) continue;
+                    bool got = (uint32_t)(x[c] >> 32) == ga.epoch;
+                    float v = __uint_as_float((uint32_t)x[c]);
+                    if (!got && (spins & 0xFFu) == 0xFFu && wall_clock64() - t_begin > ga.timeout_ticks) {
+                        __hip_atomic_store(ga.err, ga.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        v = NaN;
+                        got = true;
+                    }
+                    if (got) {
+                        const int idx = base + c * NTHR;
+                        const int b = idx / 3, q = idx - 3 * b;
+                        const int lr = b / ga.rows_active;
+                        const int gidv = ga.gid[lr * ga.rows_per_rank + (b - lr * ga.rows_active)];
+                        if (gidv >= 0 && gidv < KS && (q < 2 || gidv < K)) {
+                            ga.send[(size_t)lr * L + q * KS + gidv] = v;
+                            if (s_send) s_send[lr * L + q * KS + gidv] = v;
+                        }
+                        pending &= ~(1u << c);
+                    }
+                }
+                if (pending) {
+                    __builtin_amdgcn_s_sleep(1);
+                    spins++;
+                }
+            }
         }
-        for (int lr = tid; lr < ga.local_ranks; lr += NTHR) ga.send[(size_t)lr * L + (L - 1)] = ga.names_ok;
+        for (int lr = tid; lr < ga.local_ranks; lr += NTHR) {
+            ga.send[(size_t)lr * L + (L - 1)] = ga.names_ok;
+            if (s_send) s_send[lr * L + (L - 1)] = ga.names_ok;
+        }
         __syncthreads();
     }
     if (pa.windows) {
         // the report's exchange as this kernel's prologue: publish this process' rows into every window, sweep ours
-        // into a.table (plain device memory, written and read by this one workgroup)
-        peer_exchange_block(pa);
+        // into a.table (plain device memory, written and read by this one workgroup) and into LDS
+        peer_exchange_block(pa, ga.g ? s_send : nullptr, s_tab);
         __syncthreads();
+        if (s_tab) a.table = s_tab;
+    } else if (ga.g && s_send) {
+        a.table = s_send;  // one process: its rows are the whole table
     }
     // local statistics rows -> result block; issued first so the loads overlap everything below
     for (int i = tid; i < a.stats_n4; i += NTHR) {
@@ -1564,13 +1655,23 @@ static int score_launch(const float *d_table, int R, int K, int S, int do_indiv,
     if (score_fits_single_wg(R, K, S, d_scores, d_flags)) {
         PeerArgs none{};
         GatherArgs nog{};
+        size_t lds1 = score1_lds_bytes(R, K, S);
+        if (ga || pa) {
+            const int send_floats = pa ? pa->count : R * NVRX_TABLE_LEN(K, S);
+            const size_t extra = score1_table_lds_bytes(R, K, S, send_floats);
+            if (lds1 + extra <= SCORE1_MAX_LDS) {
+                a.tab_in_lds = 1;
+                a.send_floats = send_floats;
+                lds1 += extra;
+            }
+        }
         if (ga) {
             a.stats_n4 = 0;  // statistics come through the granules
-            hipLaunchKernelGGL(k_score1<SCORE1_RESIDENT_THREADS>, dim3(1), dim3(SCORE1_RESIDENT_THREADS), score1_lds_bytes(R, K, S), st, a,
+            hipLaunchKernelGGL(k_score1<SCORE1_RESIDENT_THREADS>, dim3(1), dim3(SCORE1_RESIDENT_THREADS), lds1, st, a,
                                score_fence_enabled(), pa ? *pa : none, *ga);
         } else {
-            hipLaunchKernelGGL(k_score1<SCORE1_THREADS>, dim3(1), dim3(SCORE1_THREADS), score1_lds_bytes(R, K, S), st, a,
-                               score_fence_enabled(), pa ? *pa : none, nog);
+            hipLaunchKernelGGL(k_score1<SCORE1_THREADS>, dim3(1), dim3(SCORE1_THREADS), lds1, st, a, score_fence_enabled(),
+                               pa ? *pa : none, nog);
         }
         HIP_TRY(hipGetLastError());
         return NVRX_OK;
@@ -1677,8 +1778,8 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     CTX_TRY(hipEventCreateWithFlags(&ctx->stamp_ev, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->report_ev, hipEventDisableTiming));
-    CTX_TRY(hipStreamCreateWithFlags(&ctx->score_stream, hipStreamNonBlocking));
-    {
+    {   // (the resident scorer's own stream is created with the first resident report: a process that never runs one
+        // should not hold another hardware queue)
         const size_t gbytes = 2ull * (size_t)ctx->rows * ROW_GRANULES * sizeof(unsigned long long);
         CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_rowg), gbytes));
         CTX_TRY(hipMemset(ctx->d_rowg, 0, gbytes));  // tag 0 is never a valid epoch
@@ -2130,6 +2231,11 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     const bool resident = d->resident && d->h_seq_word && !d->guard_rings && (!exchanging || peer_route) && rows_launch > 0 &&
                           score_fits_single_wg(d->R, d->K, d->S, d->d_scores, d->d_flags) && resident_scorer_enabled();
     if (resident) {
+        if (!ctx->score_stream) {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->score_stream, hipStreamNonBlocking));
+        }
         ctx->gran_epoch = (ctx->gran_epoch % 0x7FFFFFFFu) + 1u;
         unsigned long long *slice = ctx->d_rowg + (size_t)(ctx->gran_epoch & 1u) * (size_t)ctx->rows * ROW_GRANULES;
         int rc2 = report_local_impl(ctx, d->d_stats, d->d_send, d->K, d->S, d->names_ok, d->rows_active, stream, slice,

@@ -418,14 +418,14 @@ class HipRings:
 
     def report_fused(self, ws: Workspace, rows_active: int, stats_rows: int, do_indiv: bool, do_rel: bool,
                      thresholds: Sequence[float], direct=None, names_ok: bool = True, wait: bool = True,
-                     order_after: Optional[int] = None) -> int:
+                     order_after: Optional[int] = None, resident: bool = True) -> int:
         """The whole report in one C call (``nvrx_report``): flush -> statistics kernel -> [``ncclAllGather`` of the
         exchange rows through ``direct``] -> score kernel -> wait for the completion word.  On return
         ``ws.scores / flags / meta / stats`` hold this report's values.  ``wait=False`` only enqueues (asynchronous
         report): the caller waits for the returned sequence number with ``backend.wait_seq`` later, and ring writers on
         other streams are ordered after the statistics kernel on the device."""
         d = ws.desc
-        key = (rows_active, stats_rows, do_indiv, do_rel, thresholds, direct, names_ok, wait)
+        key = (rows_active, stats_rows, do_indiv, do_rel, thresholds, direct, names_ok, wait, resident)
         if ws.desc_key != key:  # cold: the switches of this shape changed
             d.rows_active, d.stats_rows = rows_active, min(stats_rows, ws.stats_rows)
             d.do_indiv, d.do_rel = int(do_indiv), int(do_rel)
@@ -439,7 +439,9 @@ class HipRings:
             d.timeout_s = report_timeout_s()
             d.h_seq_word = ws.h_seq if wait else None
             d.guard_rings = 0 if wait else 1
-            d.resident = 1 if wait else 0  # the library decides (no exchange / peer windows, table fits one workgroup)
+            # resident score kernel on a stream of its own: the library decides among the eligible shapes (no exchange or
+            # peer windows, table fits one workgroup); off when ranks share a device
+            d.resident = 1 if (wait and resident) else 0
             ws.desc_key = key
         if order_after is not None:  # the caller's current stream: the report follows what is enqueued there
             d.order_after_stream, d.order_after_enabled = order_after, 1

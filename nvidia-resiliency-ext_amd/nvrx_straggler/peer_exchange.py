@@ -43,7 +43,10 @@ class PeerAllGather:
 
     route = "xGMI peer stores (IPC windows)"
 
-    def __init__(self, lib, peer: ctypes.c_void_p, world: int, rank: int):
+    def __init__(self, lib, peer: ctypes.c_void_p, world: int, rank: int, shared_device: bool = False):
+        #: some ranks of the group sit on ONE device (tests, folded runs): kernels that poll for each other are then
+        #: multiplexed by the hardware scheduler, so the reports keep to one stream per process (no resident scorer)
+        self.shared_device = shared_device
         self._lib = lib
         self._peer = peer
         self.world = world
@@ -110,12 +113,17 @@ def create(group=None, device_index: Optional[int] = None, timeout_s: float = 18
         ok = False
     # windows can only be shared inside one node
     infos = [None] * world
-    dist.all_gather_object(infos, (socket.gethostname(), handle if ok else None), group=group)
-    same_node = len({h for h, _ in infos}) == 1
-    ok = ok and same_node and all(hd is not None for _, hd in infos)
+    try:
+        device_id = str(torch.cuda.get_device_properties(dev).uuid)
+    except Exception:  # noqa: BLE001
+        device_id = f"index{dev}"
+    dist.all_gather_object(infos, (socket.gethostname(), handle if ok else None, device_id), group=group)
+    same_node = len({h for h, _, _ in infos}) == 1
+    shared_device = len({d for _, _, d in infos}) < world
+    ok = ok and same_node and all(hd is not None for _, hd, _ in infos)
     if ok:
         try:
-            for r, (_, hd) in enumerate(infos):
+            for r, (_, hd, _) in enumerate(infos):
                 if r != rank:
                     _native.check(lib.nvrx_peer_connect(peer, r, hd))
             _native.check(lib.nvrx_peer_ready(peer, float(timeout_s)))
@@ -125,7 +133,7 @@ def create(group=None, device_index: Optional[int] = None, timeout_s: float = 18
         if peer.value:
             lib.nvrx_peer_destroy(peer)
         return None
-    return PeerAllGather(lib, peer, world, rank)
+    return PeerAllGather(lib, peer, world, rank, shared_device)
 
 
 def _trial(route, group, backend, reps: int = 30):

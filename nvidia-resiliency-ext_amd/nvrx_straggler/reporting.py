@@ -639,7 +639,8 @@ class ReportGenerator:
             wait = not self.asynchronous
             seq = rings.report_fused(ws, plan.rows_used, plan.stats_needed, self.is_computing_indiv_scores,
                                      self.is_computing_rel_scores, self.thresholds, self._direct if multi else None,
-                                     names_ok=names_ok, wait=wait, order_after=order_after if multi else None)
+                                     names_ok=names_ok, wait=wait, order_after=order_after if multi else None,
+                                     resident=not (multi and getattr(self._direct, "shared_device", False)))
             if not wait:
                 pend = self._inflight = _PendingBlock(be, ws, seq)
                 if self.gather_on_rank0 and self.rank != 0:

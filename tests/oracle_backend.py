@@ -265,7 +265,7 @@ class OracleRingsFused(OracleRings):
     """Adds the product's one-call report; results are computed at enqueue time, ``wait=False`` just skips nothing."""
 
     def report_fused(self, ws, rows_active, stats_rows, do_indiv, do_rel, thresholds, direct=None, names_ok=True, wait=True,
-                     order_after=None):
+                     order_after=None, resident=True):
         from nvrx_straggler import dist_utils
 
         self.report_local(ws, names_ok, rows_active=rows_active)

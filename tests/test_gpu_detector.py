@@ -290,6 +290,7 @@ def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
         for r in range(2):
             job.load(r, synth.loop_samples(r, 0, 4, 100))
         first = job.report(reset=False)
+        job.report(reset=False)  # the cached plan's first run (initialises its exchange rows: a cold, synchronising step)
         ws_before = job.reporter._ring_plan.ws
         big = torch.randn(8192, 8192, device="cuda")
         monkeypatch.setenv("NVRX_REPORT_TIMEOUT_S", "0.02")
@@ -297,7 +298,7 @@ def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
         with torch.cuda.stream(be.stream):
             for _ in range(40):          # > 100 ms of work queued in front of the report
                 big = (big @ big) * 1e-4
-        with pytest.raises(_native.NativeError, match="not seen after"):
+        with pytest.raises(_native.NativeError, match="not seen after|gave up waiting"):
             job.report(reset=False)
         assert ws_before in be._retired and ws_before not in be._workspaces.values()
         monkeypatch.setenv("NVRX_REPORT_TIMEOUT_S", "60")

@@ -163,7 +163,7 @@ def test_config2_loop_over_peer_windows(asynchronous):
 def test_ptl_callback_on_hip_backend_flags_the_slow_gpu():
     """StragglerDetectionCallback (duck-typed trainer; Lightning is not in the image) on the HIP backend, two ranks
     sharing the GPU: training_step is wrapped into a GPU-timed section, reports come on the time-derived interval, the
-    rank doing 4x the GPU work gets a low relative GPU score and the job is told to stop
+    rank doing 8x the GPU work gets a low relative GPU score and the job is told to stop
     (P/straggler_det_callback.py:106-117,239-254)."""
     res = run_ranks(workers.ptl_callback_run, 2, timeout=200, use_oracle_backend=False, device=0, slow_rank=1)
     r0 = res[0]

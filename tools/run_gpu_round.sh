@@ -11,6 +11,9 @@ timeout -s KILL 900 python -m pytest tests -m gpu -x -q --durations=10 > $O/pyte
 tail -15 $O/pytest.log
 timeout 600 python bench.py $B > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench.json; cat $O/bench.json
 timeout 120 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+# A/B on the same box: the score kernel behind the statistics kernel on one stream instead of resident on its own
+NVRX_RESIDENT_SCORER=0 timeout 300 python bench.py $B --no-cpu-baseline --no-overhead --no-host-inputs --no-extra-legs > $O/bench_nonresident.log 2>&1
+tail -1 $O/bench_nonresident.log > $O/bench_nonresident.json; cat $O/bench_nonresident.json
 # the multi-rank flow with ranks SHARING this GPU (gloo group; the report's exchange through IPC peer windows)
 for n in 2 4; do
   NVRX_EXCHANGE=peer NVRX_REPORT_TIMEOUT_S=30 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n \
