@@ -1500,11 +1500,15 @@ int ctx_set_device(const nvrx_ctx *ctx) {
 
 // Samples written by stamp kernels on user streams must be in the rings before anything on `stream`
 // reads them: one event per such stream, waited for on the device (the host does not block).
-int order_after_stamps(nvrx_ctx *ctx, hipStream_t stream) {
+// `also` (optional): a second stream to order the same way -- the resident scorer's.  A score kernel that became
+// resident while the report still waits for the user's work would hold a CU for all that time (measured: a report
+// every step behind 10 x matmul(4096^2) cost +560 us per step, the matmuls' workgroups no longer fit one per CU).
+int order_after_stamps(nvrx_ctx *ctx, hipStream_t stream, hipStream_t also = nullptr) {
     for (hipStream_t s : ctx->stamp_streams) {
         if (s == stream) continue;
         HIP_TRY(hipEventRecord(ctx->stamp_ev, s));
         HIP_TRY(hipStreamWaitEvent(stream, ctx->stamp_ev, 0));
+        if (also) HIP_TRY(hipStreamWaitEvent(also, ctx->stamp_ev, 0));
     }
     ctx->stamp_streams.clear();
     return NVRX_OK;
@@ -2231,10 +2235,17 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     const bool resident = d->resident && d->h_seq_word && !d->guard_rings && (!exchanging || peer_route) && rows_launch > 0 &&
                           score_fits_single_wg(d->R, d->K, d->S, d->d_scores, d->d_flags) && resident_scorer_enabled();
     if (resident) {
-        if (!ctx->score_stream) {
+        {
             std::lock_guard<std::mutex> lk(ctx->mu);
             HIP_TRY(hipSetDevice(ctx->device));
-            HIP_TRY(hipStreamCreateWithFlags(&ctx->score_stream, hipStreamNonBlocking));
+            if (!ctx->score_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->score_stream, hipStreamNonBlocking));
+            // the score kernel becomes dispatchable when the statistics kernel does, not before
+            if (d->order_after_enabled && d->order_after_stream != stream)
+                HIP_TRY(hipStreamWaitEvent(ctx->score_stream, ctx->order_ev, 0));
+            if (!ctx->stamp_streams.empty()) {
+                int orc = order_after_stamps(ctx, as_stream(stream), ctx->score_stream);
+                if (orc) return orc;
+            }
         }
         ctx->gran_epoch = (ctx->gran_epoch % 0x7FFFFFFFu) + 1u;
         unsigned long long *slice = ctx->d_rowg + (size_t)(ctx->gran_epoch & 1u) * (size_t)ctx->rows * ROW_GRANULES;
