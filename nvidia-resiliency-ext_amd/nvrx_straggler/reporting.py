@@ -640,7 +640,8 @@ class ReportGenerator:
             seq = rings.report_fused(ws, plan.rows_used, plan.stats_needed, self.is_computing_indiv_scores,
                                      self.is_computing_rel_scores, self.thresholds, self._direct if multi else None,
                                      names_ok=names_ok, wait=wait, order_after=order_after if multi else None,
-                                     resident=not (multi and getattr(self._direct, "shared_device", False)))
+                                     resident=not (multi and getattr(self._direct, "shared_device", False)
+                                                   and os.environ.get("NVRX_RESIDENT_SHARED_OK", "0") in ("", "0")))
             if not wait:
                 pend = self._inflight = _PendingBlock(be, ws, seq)
                 if self.gather_on_rank0 and self.rank != 0:

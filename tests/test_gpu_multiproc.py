@@ -144,6 +144,20 @@ def test_report_generator_over_peer_windows_matches_reference(name):
         assert res[r]["ids"] == g["per_rank"][r]["ids"], (name, r)
 
 
+def test_config2_loop_over_peer_windows_with_the_resident_scorer():
+    """The combination that one process per GPU runs in production: resident score kernel (rows arrive as granules)
+    whose prologue is the peer-window exchange.  On a shared device it is switched off by default (an extra queue per
+    process slows processes that poll for each other); forced on here, two processes x 4 logical ranks."""
+    g = load_golden("loop.json")
+    res = run_ranks(workers.folded_loop_config2, 2, timeout=150, use_oracle_backend=False, device=0,
+                    env={**_PEER_ENV, "NVRX_RESIDENT_SHARED_OK": "1"}, asynchronous=False)
+    assert res[0]["route"].startswith("xGMI peer stores") and res[0]["fused"]
+    for t, exp in enumerate(g["rank0_reports"]):
+        got = res[0]["reports"][t]
+        got["rank_to_node"] = exp["rank_to_node"]
+        compare_reports(got, exp, ("loop-peer-resident", t), rel=1e-4)
+
+
 @pytest.mark.parametrize("asynchronous", [False, True])
 def test_config2_loop_over_peer_windows(asynchronous):
     """Config #2 (8 logical ranks, ten reports, history across reports) on FOUR processes x 2 logical ranks with the
