@@ -1182,6 +1182,7 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
         }
         __syncthreads();
     }
+    const unsigned long long t_rows = wall_clock64();  // resident scorer: every row's exchange values have arrived
     if (pa.windows) {
         // the report's exchange as this kernel's prologue: publish this process' rows into every window, sweep ours
         // into a.table (plain device memory, written and read by this one workgroup) and into LDS
@@ -1254,6 +1255,10 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
         }
         if (!(ga.g && ga.stats_out))  // statistics already forwarded above: both words at once
             __hip_atomic_store(&a.meta[5], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // diagnostics (constant-rate wall clock, 10 ns ticks): how long this kernel waited for the rows, and how long
+        // it took from the last row to this store
+        __hip_atomic_store(&a.meta[6], (uint32_t)(t_rows - t_begin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&a.meta[7], (uint32_t)(wall_clock64() - t_rows), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (ga.g && ga.stats_out) {
@@ -2471,10 +2476,15 @@ int nvrx_poll_u32(const uint32_t *h_word, uint32_t expected, double timeout_s) {
     if (*p == expected) return NVRX_OK;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; spins++) {
-        if (*p == expected) {
+        const uint32_t cur = *p;
+        if (cur == expected) {
             std::atomic_thread_fence(std::memory_order_acquire);
             return NVRX_OK;
         }
+        // sequence words only move forward: one that is already PAST the awaited value will never show it (the block
+        // was reused by a later report before this one was collected) -- an error, not a wait
+        if (cur != 0 && (uint32_t)(cur - expected) < 0x10000000u)
+            return fail(NVRX_ERR_STATE, "completion word is at %u, past the awaited %u: the result block was reused", cur, expected);
         __builtin_ia32_pause();
         if ((spins & 0x3FFu) == 0x3FFu) {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -22,6 +22,7 @@ from __future__ import annotations
 import ctypes
 import os
 import threading
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -140,6 +141,10 @@ class Workspace:
         d.timeout_s = report_timeout_s()
         self.desc_ref = ctypes.byref(d)
         self.desc_key = None
+        # the last report's result block may still be "live" (read lazily by a Report): see attach() / settle()
+        self._live = None
+        self._live_seq = 0
+        self._backend = backend
 
     def __del__(self):  # pragma: no cover
         try:
@@ -148,6 +153,24 @@ class Workspace:
                 self.h_ptr = None
         except Exception:
             pass
+
+    def attach(self, live) -> None:
+        """``live`` (reporting._LiveBlock) reads this block lazily; ``settle()`` collects it before any reuse."""
+        self._live = weakref.ref(live)
+        self._live_seq = live.seq
+
+    def settle(self) -> None:
+        """Called before anything is enqueued that writes this workspace: the previous report's statistics rows must
+        have landed (a resident score kernel forwards them after the scores), and if somebody still holds that report
+        its data is copied out now."""
+        ref = self._live
+        if ref is not None:
+            self._live = None
+            live = ref()
+            if live is not None:
+                live.detach()
+            elif self.meta[5] != self._live_seq:
+                self._backend.wait_seq(self, self._live_seq, stats=True)
 
     def host_block(self) -> np.ndarray:
         """A private copy of the pinned result block (the block itself is overwritten by the next report)."""
@@ -231,6 +254,8 @@ class HipBackend:
                 self._thr[i] = float(thresholds[i])
             self._thr_src = thresholds
         lib = self.lib
+        if ws._live is not None:
+            ws.settle()
         nrows = ws.stats_rows if stats_rows is None else min(stats_rows, ws.stats_rows)
         table_ptr = ws.table_ptr if table is ws.table else (ws.send_ptr if table is ws.send else table.data_ptr())
         ws.seq = ws.desc.seq = (max(ws.seq, ws.desc.seq) % 0x7FFFFFFF) + 1  # one sequence for both report routes
@@ -409,6 +434,8 @@ class HipRings:
     # ---- report ----------------------------------------------------------------------------------
     def report_local(self, ws: Workspace, names_ok: bool, rows_active: int = 0) -> None:
         """flush -> statistics kernel -> exchange rows, all on the backend's stream."""
+        if ws._live is not None:
+            ws.settle()
         if not ws.send_initialised:
             self.backend.send_init(ws)
         rc = self.lib.nvrx_report_local(self.ctx, ws.d_stats, ws.send_ptr, ws.K, ws.S, int(names_ok),
@@ -424,6 +451,8 @@ class HipRings:
         ``ws.scores / flags / meta / stats`` hold this report's values.  ``wait=False`` only enqueues (asynchronous
         report): the caller waits for the returned sequence number with ``backend.wait_seq`` later, and ring writers on
         other streams are ordered after the statistics kernel on the device."""
+        if ws._live is not None:
+            ws.settle()
         d = ws.desc
         key = (rows_active, stats_rows, do_indiv, do_rel, thresholds, direct, names_ok, wait, resident)
         if ws.desc_key != key:  # cold: the switches of this shape changed

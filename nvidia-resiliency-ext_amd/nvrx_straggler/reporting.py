@@ -25,7 +25,6 @@ import dataclasses
 import os
 import threading
 import time
-import weakref
 from typing import Any, Dict, Iterator, List, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
@@ -84,23 +83,39 @@ class _PendingBlock:
         return self.blob
 
 
-class _StatsLater:
-    """The statistics rows of a report whose scores have already arrived: a resident score kernel forwards them
-    after it published the scores, under a completion word of their own.  ``get()`` waits for that word and takes a
-    private copy; the generator calls it before the next report overwrites the block if anybody still holds this."""
+class _LiveBlock:
+    """The result block of the LAST synchronous one-call report on a workspace, still in place.  Nothing is copied when
+    the report returns: ``head()`` / ``stats()`` take private copies when the report is first read, and the workspace
+    calls ``detach()`` before anything reuses the block -- which copies only if somebody still holds the report.  The
+    statistics rows have a completion word of their own (a resident score kernel forwards them after the scores)."""
 
-    __slots__ = ("backend", "ws", "seq", "rows", "array", "__weakref__")
+    __slots__ = ("backend", "ws", "seq", "rows", "_head", "_stats", "__weakref__")
 
     def __init__(self, backend, ws, seq: int, rows: int):
         self.backend, self.ws, self.seq, self.rows = backend, ws, seq, rows
-        self.array: Optional[np.ndarray] = None
+        self._head: Optional[np.ndarray] = None
+        self._stats: Optional[np.ndarray] = None
 
-    def get(self) -> np.ndarray:
-        if self.array is None:
+    def head(self) -> np.ndarray:
+        if self._head is None:
+            self._head = self.ws.host_head()
+            self._release()
+        return self._head
+
+    def stats(self) -> np.ndarray:
+        if self._stats is None:
             self.backend.wait_seq(self.ws, self.seq, stats=True)
-            self.array = self.ws.host_stats(self.rows)
-            self.backend = self.ws = None
-        return self.array
+            self._stats = self.ws.host_stats(self.rows)
+            self._release()
+        return self._stats
+
+    def detach(self) -> None:
+        self.head()
+        self.stats()
+
+    def _release(self) -> None:
+        if self._head is not None and self._stats is not None:
+            self.backend = self.ws = None  # nothing of the live workspace is referenced any more
 
 
 class _ScoreSource:
@@ -129,16 +144,18 @@ class _ScoreSource:
     def statistics(self) -> np.ndarray:
         self.ensure()
         st = self.stats
-        if type(st) is _StatsLater:
-            st = self.stats = st.get()
+        if type(st) is _LiveBlock:
+            st = self.stats = st.stats()
         return st
 
     def ensure(self) -> "_ScoreSource":
         if self.scores is None:
             pend = self.pending
             if pend is not None:
-                # a private copy of the block (ndarray), or the block still in flight (_PendingBlock)
-                self.cut(pend if type(pend) is np.ndarray else pend.wait())
+                # a private copy of the block (ndarray), the live block of a synchronous report, or the block still in
+                # flight of an asynchronous one
+                t = type(pend)
+                self.cut(pend if t is np.ndarray else (pend.head() if t is _LiveBlock else pend.wait()))
                 self.pending = None
         return self
 
@@ -384,7 +401,6 @@ class ReportGenerator:
         # that waits for the device on first read; the block in flight is settled before the next report starts
         self.asynchronous = bool(asynchronous)
         self._inflight: Optional[_PendingBlock] = None
-        self._stats_later = None  # (weakref to the _StatsLater, workspace, sequence) of the last synchronous one-call report
         self.exchange_info: Dict[str, Any] = {}
 
     # ---- pieces kept from the reference's host logic ----------------------------------------------
@@ -588,20 +604,6 @@ class ReportGenerator:
         self._ring_gid_state = None  # the general path must re-derive its own view if it runs next
         return plan
 
-    def _settle_stats(self) -> None:
-        """Before a workspace is used again: the previous one-call report's statistics rows must have landed (a
-        resident score kernel forwards them after the scores, from its own stream), and if somebody still holds that
-        report they leave the result block now (they are copied lazily)."""
-        pending = self._stats_later
-        if pending is not None:
-            self._stats_later = None
-            ref, ws, seq = pending
-            later = ref()
-            if later is not None:
-                later.get()
-            else:
-                _backend_mod.get_backend().wait_seq(ws, seq, stats=True)
-
     def _settle_inflight(self) -> bool:
         """Wait for the asynchronous report still in flight (if any) before its workspace is touched again.
         Returns True when that report's exchange showed a rank with names that have no id yet: every rank sees the
@@ -669,11 +671,10 @@ class ReportGenerator:
             return None
         src = self._source_for(plan, ws)
         if fused:
-            # scores / flags now (one memcpy of the block's head, cut into views when the report is first read); the
-            # statistics rows when somebody asks for them -- a resident score kernel forwards them after the scores
-            src.pending = ws.host_head()
-            later = src.stats = _StatsLater(be, ws, ws.seq, plan.stats_needed)
-            self._stats_later = (weakref.ref(later), ws, ws.seq)
+            # nothing is copied now: scores / flags / statistics leave the block when the report is first read, or when
+            # the workspace is about to be reused and the report is still held
+            live = src.pending = src.stats = _LiveBlock(be, ws, ws.seq, plan.stats_needed)
+            ws.attach(live)  # the workspace collects it (if still held) before the block is reused by anybody
         else:
             src.pending = ws.host_block()
         flags = _DeviceFlags(self.thresholds, src, plan.ranks, plan.names, plan.cols, ws.S, src.has_rel, src.has_indiv)
@@ -695,8 +696,6 @@ class ReportGenerator:
         self.rank = dist_utils.get_rank(self.group)
         if self._inflight is not None:
             self._settle_inflight()
-        if self._stats_later is not None:
-            self._settle_stats()
         if not self._direct_tried:
             self._maybe_create_direct_exchange()
         kernel_summaries = self._filter_out_nccl_kernels(kernel_summaries)
@@ -742,8 +741,6 @@ class ReportGenerator:
         """
         t0 = time.perf_counter_ns()
         self.world_size, self.rank = dist_utils.world_and_rank(self.group)
-        if self._stats_later is not None:
-            self._settle_stats()
         if not self._direct_tried:
             self._maybe_create_direct_exchange()
         # steady state: same name tables as last time -> run the cached plan

@@ -46,6 +46,20 @@ class OracleWorkspace:
         self.scores = h[self._off_scores : self._off_scores + R * self.W * 4].view(np.float32).reshape(R, self.W)
         self.flags = h[self._off_flags : self._off_flags + R * self.W].reshape(R, self.W)
 
+    # same lazy-collection interface as the product workspace (backend.Workspace.attach / settle)
+    _live = None
+
+    def attach(self, live):
+        import weakref
+
+        self._live = weakref.ref(live)
+
+    def settle(self):
+        ref, self._live = self._live, None
+        live = ref() if ref is not None else None
+        if live is not None:
+            live.detach()
+
     def host_block(self):
         return self._host.copy()
 
@@ -109,6 +123,7 @@ class OracleBackend:
         ws.send_initialised = True
 
     def score(self, ws, table, do_indiv, do_rel, thresholds=(0.75,) * 4, wait=True, stats_rows=None):
+        ws.settle()
         self.score_calls += 1
         T = table.numpy()
         ws.scores[:] = oracle.score_table(T, ws.K, ws.S, do_indiv, do_rel)
@@ -234,6 +249,7 @@ class OracleRings:
         return self._stats()[0]
 
     def report_local(self, ws, names_ok, rows_active=0):
+        ws.settle()
         if not ws.send_initialised:
             self.backend.send_init(ws)
         st, counts = self._stats()
@@ -268,6 +284,7 @@ class OracleRingsFused(OracleRings):
                      order_after=None, resident=True):
         from nvrx_straggler import dist_utils
 
+        ws.settle()
         self.report_local(ws, names_ok, rows_active=rows_active)
         table = ws.send
         if direct is not None:

@@ -669,3 +669,18 @@ def test_ptl_callback_two_ranks_flags_the_slow_one():
     assert r0["logged"]["gpu_relative_perf/min"] < 0.7 <= r0["logged"]["gpu_relative_perf/max"]
     assert any("STRAGGLER DETECTION WARNING" in m and "rank=1" in m for m in r0["messages"])
     assert r0["should_stop"] and res[1]["should_stop"]
+
+
+def test_poll_fails_fast_when_the_word_has_moved_past():
+    """nvrx_poll_u32 waits for equality with a sequence number that only moves forward: a word already past it means
+    the result block was reused before this report was collected -- reported at once, never waited for."""
+    from nvrx_straggler import _native
+
+    lib = _native.load()
+    word = ctypes.c_uint32(7)
+    addr = ctypes.addressof(word)
+    assert lib.nvrx_poll_u32(addr, 7, 0.01) == 0
+    assert lib.nvrx_poll_u32(addr, 5, 5.0) == -1 and b"past the awaited 5" in lib.nvrx_last_error()
+    assert lib.nvrx_poll_u32(addr, 9, 0.01) == -62 and b"not seen after" in lib.nvrx_last_error()
+    word.value = 0
+    assert lib.nvrx_poll_u32(addr, 1, 0.01) == -62  # a fresh block (0) is simply not there yet
