@@ -118,24 +118,29 @@ class _LiveBlock:
             self.backend = self.ws = None  # nothing of the live workspace is referenced any more
 
 
+class _View:
+    """What all reports of one plan share (immutable once built): table shape, rank / name tables, which score families
+    exist, where this report's rows sit in the result block, the thresholds the score kernel flagged with."""
+
+    __slots__ = ("S", "ranks", "names", "cols", "has_rel", "has_indiv", "section_rows", "kernel_rows", "layout", "thresholds")
+
+
 class _ScoreSource:
-    """What a steady-state report keeps of the result block: a private copy of the score / statistics
-    arrays plus the (shared, immutable) name tables of the plan.  The six mapping fields of ``Report`` are
-    built from it as PLAIN dicts the first time each one is read; a report whose scores are only
-    thresholded (``identify_stragglers`` with the kernel's thresholds) never builds any.  For an asynchronous
-    report the arrays themselves are cut out of the (then awaited) result block on first use."""
+    """What a steady-state report keeps of the result block: the (shared, immutable) view of its plan and the block
+    itself -- live, in flight or a private copy.  The six mapping fields of ``Report`` are built from it as PLAIN
+    dicts the first time each one is read; a report whose scores are only thresholded (``identify_stragglers`` with
+    the kernel's thresholds) never builds any.  The arrays are cut out of the block on first use."""
 
-    __slots__ = ("scores", "stats", "flags", "S", "ranks", "names", "cols", "has_rel", "has_indiv", "section_rows",
-                 "kernel_rows", "pending", "layout")
+    __slots__ = ("view", "pending", "scores", "stats", "flags")
 
-    def __init__(self):
+    def __init__(self, view: _View, pending=None):
+        self.view = view
+        self.pending = pending  # ndarray (private copy), _LiveBlock (synchronous report) or _PendingBlock (asynchronous)
         self.scores = self.stats = self.flags = None
-        self.pending: Optional[_PendingBlock] = None
-        self.layout = None
 
     def cut(self, blob: np.ndarray) -> None:
         """Views of this report's scores / flags / statistics inside a private copy of the result block."""
-        off_s, off_f, off_t, R, W, lo, hi, stats_rows = self.layout
+        off_s, off_f, off_t, R, W, lo, hi, stats_rows = self.view.layout
         self.scores = blob[off_s : off_s + R * W * 4].view(np.float32).reshape(R, W)[lo:hi]
         self.flags = blob[off_f : off_f + R * W].reshape(R, W)[lo:hi]
         if blob.size >= off_t + stats_rows * 32:  # a copy of the whole block; else the statistics come later
@@ -152,34 +157,42 @@ class _ScoreSource:
         if self.scores is None:
             pend = self.pending
             if pend is not None:
-                # a private copy of the block (ndarray), the live block of a synchronous report, or the block still in
-                # flight of an asynchronous one
                 t = type(pend)
-                self.cut(pend if t is np.ndarray else (pend.head() if t is _LiveBlock else pend.wait()))
+                if t is _LiveBlock:
+                    self.stats = pend  # resolved by statistics()
+                    self.cut(pend.head())
+                else:
+                    self.cut(pend if t is np.ndarray else pend.wait())
                 self.pending = None
         return self
 
+    def device_flags(self) -> "_DeviceFlags":
+        v = self.view
+        return _DeviceFlags(v.thresholds, self, v.ranks, v.names, v.cols, v.S, v.has_rel, v.has_indiv)
+
     def build(self, field: str):
         self.ensure()
-        S = self.S
+        v = self.view
+        S = v.S
         if field == "gpu_relative_perf_scores":
-            return dict(zip(self.ranks, self.scores[:, 1].tolist())) if self.has_rel else {}
+            return dict(zip(v.ranks, self.scores[:, 1].tolist())) if v.has_rel else {}
         if field == "gpu_individual_perf_scores":
-            return dict(zip(self.ranks, self.scores[:, 0].tolist())) if self.has_indiv else {}
+            return dict(zip(v.ranks, self.scores[:, 0].tolist())) if v.has_indiv else {}
         if field == "section_relative_perf_scores":
-            return self._sections(2 + S) if (self.has_rel and self.names) else {}
+            return self._sections(2 + S) if (v.has_rel and v.names) else {}
         if field == "section_individual_perf_scores":
-            return self._sections(2) if (self.has_indiv and self.names) else {}
+            return self._sections(2) if (v.has_indiv and v.names) else {}
         if field == "local_section_summaries":
-            return _summaries_from_rows(self.section_rows, self.statistics())
+            return _summaries_from_rows(v.section_rows, self.statistics())
         if field == "local_kernel_summaries":
-            return _summaries_from_rows(self.kernel_rows, self.statistics())
+            return _summaries_from_rows(v.kernel_rows, self.statistics())
         raise AttributeError(field)
 
     def _sections(self, first_col: int) -> Dict[str, Dict[int, float]]:
-        ranks, cols = self.ranks, self.cols
-        by_col = self.scores[:, first_col : first_col + self.S].T.tolist()  # one C-level conversion
-        return {name: dict(zip(ranks, by_col[cols[name]])) for name in self.names}
+        v = self.view
+        ranks, cols = v.ranks, v.cols
+        by_col = self.scores[:, first_col : first_col + v.S].T.tolist()  # one C-level conversion
+        return {name: dict(zip(ranks, by_col[cols[name]])) for name in v.names}
 
 
 _LAZY_FIELDS = frozenset((
@@ -227,7 +240,7 @@ class Report:
     # ---- construction from the device result block -------------------------------------------------
     @classmethod
     def _from_device(cls, source: _ScoreSource, rank_to_node, elapsed_ms: float, gather_on_rank0: bool,
-                     rank: Optional[int], device_flags: "Optional[_DeviceFlags]") -> "Report":
+                     rank: Optional[int]) -> "Report":
         self = object.__new__(cls)
         d = self.__dict__
         d["rank_to_node"] = rank_to_node
@@ -235,8 +248,17 @@ class Report:
         d["gather_on_rank0"] = gather_on_rank0
         d["rank"] = rank
         d["_src"] = source
-        d["_device_flags"] = device_flags
         return self
+
+    def _flags(self) -> "Optional[_DeviceFlags]":
+        """The score kernel's below-threshold bytes (built from the source on first use), or None."""
+        d = self.__dict__
+        flags = d.get("_device_flags")
+        if flags is None:
+            src = d.get("_src")
+            if src is not None and src.view.thresholds is not None:
+                flags = d["_device_flags"] = src.device_flags()
+        return flags
 
     def __getattr__(self, name: str):
         # reached only when normal lookup fails, i.e. for a mapping field that has not been built yet
@@ -255,7 +277,7 @@ class Report:
         """Plain fields only (every mapping built): what pickle / copy / multiprocessing queues carry."""
         self._materialise()
         state = {f.name: self.__dict__[f.name] for f in dataclasses.fields(self)}
-        flags = self.__dict__.get("_device_flags")
+        flags = self._flags()
         if flags is not None:
             state["_device_flags"] = flags
         return state
@@ -283,7 +305,7 @@ class Report:
         'straggler_sections_relative': {section: set}, 'straggler_sections_individual': {section:
         set}}``; a section appears only if at least one rank is flagged for it.
         """
-        flags = self.__dict__.get("_device_flags")
+        flags = self._flags()
         if flags is not None and flags.matches(
             gpu_rel_threshold, section_rel_threshold, gpu_indiv_threshold, section_indiv_threshold
         ):
@@ -536,16 +558,18 @@ class ReportGenerator:
             ranks = range(self.rank * local_ranks, (self.rank + 1) * local_ranks)
             names = list(local_section_names)
             cols = {n: mapper.get_section_id(n) for n in names}
-        src = _ScoreSource()
+        view = _View()
+        view.S, view.ranks, view.names, view.cols = S, ranks, names, cols
+        view.has_rel, view.has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
+        view.section_rows = section_summaries if stats is not None else None
+        view.kernel_rows = kernel_summaries if stats is not None else None
+        view.layout, view.thresholds = None, self.thresholds
+        src = _ScoreSource(view)
         src.scores = ws.scores[lo:hi].copy()
-        src.S, src.ranks, src.names, src.cols = S, ranks, names, cols
-        src.has_rel, src.has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
+        src.flags = ws.flags[lo:hi].copy()
         src.stats = stats
-        src.section_rows = section_summaries if stats is not None else None
-        src.kernel_rows = kernel_summaries if stats is not None else None
-        flags = _DeviceFlags(self.thresholds, ws.flags[lo:hi].copy(), ranks, names, cols, S, src.has_rel, src.has_indiv)
         report = Report._from_device(src, dict(self.rank_to_node), (time.perf_counter_ns() - t_start_ns) * 1e-6,
-                                     self.gather_on_rank0, self.rank, flags)
+                                     self.gather_on_rank0, self.rank)
         if stats is None:
             # the caller's own summaries travel with the report, untouched
             report.__dict__["local_section_summaries"] = section_summaries
@@ -557,7 +581,7 @@ class ReportGenerator:
         """Everything about a ring report that only changes when names, ids or topology change."""
 
         __slots__ = ("key", "ws", "mapper", "snames", "knames", "names", "cols", "ranks", "row_lo", "row_hi",
-                     "rows_used", "stats_needed", "section_rows", "kernel_rows", "fused")
+                     "rows_used", "stats_needed", "section_rows", "kernel_rows", "fused", "view")
 
     def _build_ring_plan(self, key, rings, section_rows, kernel_rows, local_ranks):
         be = _backend_mod.get_backend()
@@ -601,6 +625,7 @@ class ReportGenerator:
             g = mapper.section_name_to_id.get(name)
             rings.configure(row, 0, K + g if g is not None else -1)
         plan.ws.send_initialised = False
+        plan.view = self._view_of(plan)
         self._ring_gid_state = None  # the general path must re-derive its own view if it runs next
         return plan
 
@@ -621,13 +646,16 @@ class ReportGenerator:
         if check is not None:
             check()
 
-    def _source_for(self, plan, ws) -> _ScoreSource:
-        src = _ScoreSource()
-        src.layout = (ws._off_scores, ws._off_flags, ws._off_stats, ws.R, ws.W, plan.row_lo, plan.row_hi, plan.stats_needed)
-        src.S, src.ranks, src.names, src.cols = ws.S, plan.ranks, plan.names, plan.cols
-        src.has_rel, src.has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
-        src.section_rows, src.kernel_rows = plan.section_rows, plan.kernel_rows
-        return src
+    def _view_of(self, plan) -> _View:
+        """The part of a report that every report of ``plan`` shares (built once per plan)."""
+        ws = plan.ws
+        v = _View()
+        v.S, v.ranks, v.names, v.cols = ws.S, plan.ranks, plan.names, plan.cols
+        v.has_rel, v.has_indiv = self.is_computing_rel_scores, self.is_computing_indiv_scores
+        v.section_rows, v.kernel_rows = plan.section_rows, plan.kernel_rows
+        v.layout = (ws._off_scores, ws._off_flags, ws._off_stats, ws.R, ws.W, plan.row_lo, plan.row_hi, plan.stats_needed)
+        v.thresholds = self.thresholds
+        return v
 
     def _report_from_plan(self, plan, rings, t0, order_after=None, names_ok: bool = True):
         """The steady-state report: ONE C call (statistics kernel, the collective, score kernel, wait), one host
@@ -648,12 +676,10 @@ class ReportGenerator:
                 pend = self._inflight = _PendingBlock(be, ws, seq)
                 if self.gather_on_rank0 and self.rank != 0:
                     return None
-                src = self._source_for(plan, ws)
-                src.pending = pend
-                flags = _DeviceFlags(self.thresholds, src, plan.ranks, plan.names, plan.cols, ws.S, src.has_rel, src.has_indiv)
                 return Report._from_device(
-                    src, self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
-                    (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank, flags)
+                    _ScoreSource(plan.view, pend),
+                    self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
+                    (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank)
         elif multi:
             rings.report_local(ws, True, rows_active=plan.rows_used)
             table = self._exchange(be, ws)
@@ -669,18 +695,17 @@ class ReportGenerator:
             return False  # another rank met a new name: fall back to the general (name-syncing) path
         if self.gather_on_rank0 and self.rank != 0:
             return None
-        src = self._source_for(plan, ws)
         if fused:
             # nothing is copied now: scores / flags / statistics leave the block when the report is first read, or when
             # the workspace is about to be reused and the report is still held
-            live = src.pending = src.stats = _LiveBlock(be, ws, ws.seq, plan.stats_needed)
-            ws.attach(live)  # the workspace collects it (if still held) before the block is reused by anybody
+            pending = _LiveBlock(be, ws, ws.seq, plan.stats_needed)
+            ws.attach(pending)  # the workspace collects it (if still held) before the block is reused by anybody
         else:
-            src.pending = ws.host_block()
-        flags = _DeviceFlags(self.thresholds, src, plan.ranks, plan.names, plan.cols, ws.S, src.has_rel, src.has_indiv)
+            pending = ws.host_block()
         return Report._from_device(
-            src, self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
-            (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank, flags)
+            _ScoreSource(plan.view, pending),
+            self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
+            (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank)
 
     # ---- public: summaries given as dicts (reference signature) -------------------------------------
     def generate_report(self, section_summaries: Mapping[str, _SummaryType],

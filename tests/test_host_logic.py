@@ -302,21 +302,22 @@ def test_name_mapper_ids_are_stable_and_consecutive():
 
 def _device_report(scores, flags_thr=(0.75,) * 4, stats=None, section_rows=None):
     """A Report built the way the ring path builds it (lazy fields over private arrays)."""
-    from nvrx_straggler.reporting import Report, _DeviceFlags, _ScoreSource
+    from nvrx_straggler.reporting import Report, _ScoreSource, _View
 
     S = (scores.shape[1] - 2) // 2
     ranks, names = range(scores.shape[0]), [f"s{i}" for i in range(S)]
-    cols = {n: i for i, n in enumerate(names)}
-    src = _ScoreSource()
-    src.scores, src.S, src.ranks, src.names, src.cols = scores, S, ranks, names, cols
-    src.has_rel = src.has_indiv = True
+    view = _View()
+    view.S, view.ranks, view.names, view.cols = S, ranks, names, {n: i for i, n in enumerate(names)}
+    view.has_rel = view.has_indiv = True
+    view.section_rows, view.kernel_rows = section_rows or {}, {}
+    view.layout, view.thresholds = None, tuple(float(t) for t in flags_thr)
+    src = _ScoreSource(view)
+    src.scores = scores
     src.stats = stats if stats is not None else np.zeros((0, 8), dtype=np.float32)
-    src.section_rows, src.kernel_rows = section_rows or {}, {}
     thr = np.concatenate([[flags_thr[2], flags_thr[0]], np.full(S, flags_thr[3]), np.full(S, flags_thr[1])])
     with np.errstate(invalid="ignore"):
-        flags = (scores.astype(np.float64) < thr).astype(np.uint8)
-    return Report._from_device(src, {r: f"n{r}" for r in ranks}, 0.1, True, 0,
-                               _DeviceFlags(flags_thr, flags, ranks, names, cols, S, True, True))
+        src.flags = (scores.astype(np.float64) < thr).astype(np.uint8)
+    return Report._from_device(src, {r: f"n{r}" for r in ranks}, 0.1, True, 0)
 
 
 def test_report_is_plain_dicts_and_flag_paths_agree():
