@@ -31,9 +31,14 @@ def test_report_generator_on_hip_backend_matches_reference(name):
         assert res[r]["ids"] == g["per_rank"][r]["ids"], (name, r)
 
 
-def test_detector_name_change_midway_on_hip_backend():
-    """Cached-plan reports, then ONE rank meets a new section: every rank must leave the planned path together."""
-    res = run_ranks(workers.detector_name_change_midway, 4, timeout=300, use_oracle_backend=False, device=0)
+@pytest.mark.parametrize("route", ["gloo", "peer+resident"])
+def test_detector_name_change_midway_on_hip_backend(route):
+    """Cached-plan reports, then ONE rank meets a new section: every rank must leave the planned path together.
+    ``peer+resident``: the real Detector over peer windows with the resident score kernel forced on (its stream is
+    ordered after the caller's stream, as in a one-process-per-GPU job)."""
+    env = {} if route == "gloo" else {"NVRX_EXCHANGE": "peer", "NVRX_REPORT_TIMEOUT_S": "20", "NVRX_PEER_TRIAL_TIMEOUT_S": "5",
+                                      "NVRX_RESIDENT_SHARED_OK": "1"}
+    res = run_ranks(workers.detector_name_change_midway, 4, timeout=300, use_oracle_backend=False, device=0, env=env)
     ref = run_ranks(workers.detector_name_change_midway, 4, timeout=300)  # CPU checker backend, same protocol
     for r in range(4):
         assert res[r]["ids"] == ref[r]["ids"] and res[r]["planned"] == ref[r]["planned"]
