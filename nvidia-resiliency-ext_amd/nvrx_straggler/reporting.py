@@ -83,6 +83,9 @@ class _PendingBlock:
         return self.blob
 
 
+_LIVE_LOCK = threading.Lock()  # a report may be read on another thread while the generator collects it
+
+
 class _LiveBlock:
     """The result block of the LAST synchronous one-call report on a workspace, still in place.  Nothing is copied when
     the report returns: ``head()`` / ``stats()`` take private copies when the report is first read, and the workspace
@@ -98,15 +101,19 @@ class _LiveBlock:
 
     def head(self) -> np.ndarray:
         if self._head is None:
-            self._head = self.ws.host_head()
-            self._release()
+            with _LIVE_LOCK:
+                if self._head is None:
+                    self._head = self.ws.host_head()
+                    self._release()
         return self._head
 
     def stats(self) -> np.ndarray:
         if self._stats is None:
-            self.backend.wait_seq(self.ws, self.seq, stats=True)
-            self._stats = self.ws.host_stats(self.rows)
-            self._release()
+            with _LIVE_LOCK:
+                if self._stats is None:
+                    self.backend.wait_seq(self.ws, self.seq, stats=True)
+                    self._stats = self.ws.host_stats(self.rows)
+                    self._release()
         return self._stats
 
     def detach(self) -> None:
