@@ -513,6 +513,10 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_us_avg": round(kern_us, 3),
                 "launches_timed": kern_launches,
+                "note": "hipExtLaunchKernel start/stop events on the launch stream. With the score kernel resident on its own "
+                        "stream k_row_stats has no queued neighbour; under rocprofv3 the same launches read ~1 us longer, "
+                        "because the profiler's own packets behind every dispatch are queued successors (DESIGN.md 3.5, "
+                        "kbench between-launch modes)",
             },
         }
         if score_tail:
