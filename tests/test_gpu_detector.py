@@ -309,3 +309,43 @@ def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
         assert again.section_relative_perf_scores == first.section_relative_perf_scores
     finally:
         job.close()
+
+
+def test_resident_scorer_never_reads_a_stale_row():
+    """3000 one-call reports on one set of rings whose valid counts cycle through three values: every report's
+    medians, scores and statistics must be the ones of ITS counts.  The score kernel is resident on its own stream and
+    takes the rows' results from 8-byte {epoch, value} granules (two parities); a granule of an older report, a row
+    read before it was published or statistics forwarded under the wrong completion word would all show up here."""
+    from nvrx_straggler import Statistic
+    from nvrx_straggler.folded import FoldedJob
+
+    S, N, R = 6, 1000, 4
+    names = [synth.section_name(s) for s in range(S)]
+    job = FoldedJob(total_ranks=R, section_names=names, ring_cap=N, node_name="n")
+    try:
+        data = [synth.stress_samples(r, S, N, slow_rank=2, slow_factor=1.3) for r in range(R)]
+        for r in range(R):
+            job.load(r, data[r])
+        counts = (N, 617, 333)
+        exp = {}
+        for n in counts:
+            med = np.array([[oracle.section_stats(data[r][s, :n].astype(np.float64))[2] for s in range(S)] for r in range(R)])
+            med32 = med.astype(np.float32)
+            exp[n] = (med32, med32.min(axis=0).astype(np.float64)[None, :] / med32.astype(np.float64))
+        held = []
+        for i in range(3000):
+            n = counts[i % 3]
+            job.rearm(n)
+            rep = job.report()
+            if i % 7 == 0:
+                held.append((n, rep))          # read later: collected by the workspace before the block is reused
+                if len(held) > 5:
+                    n, rep = held.pop(0)
+            med32, rel = exp[n]
+            for s, name in enumerate(names):
+                got = [rep.section_relative_perf_scores[name][r] for r in range(R)]
+                assert np.allclose(got, rel[:, s], rtol=1e-6, atol=0), (i, n, name, got, rel[:, s])
+            st = rep.local_section_summaries[names[i % S]]
+            assert st[Statistic.NUM] == n and st[Statistic.MED] == med32[0, i % S], (i, n, st)
+    finally:
+        job.close()
