@@ -333,7 +333,11 @@ def test_resident_scorer_never_reads_a_stale_row():
             med32 = med.astype(np.float32)
             exp[n] = (med32, med32.min(axis=0).astype(np.float64)[None, :] / med32.astype(np.float64))
         held = []
+        busy = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
         for i in range(3000):
+            if i % 100 == 0 and i < 2000:
+                for _ in range(8):   # the first 2000 reports share the GPU with a stream of matmuls (uneven load)
+                    busy = torch.matmul(busy, busy) * 1e-3
             n = counts[i % 3]
             job.rearm(n)
             rep = job.report()
