@@ -42,6 +42,8 @@ for _p in (REPO, os.path.join(REPO, "nvidia-resiliency-ext_amd"), os.path.join(R
     if _p not in sys.path:
         sys.path.insert(0, _p)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# a benchmark must not sit out c10d's 30 minutes if an exchange route misbehaves on a box nobody has seen yet
+os.environ.setdefault("NVRX_REPORT_TIMEOUT_S", "60")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

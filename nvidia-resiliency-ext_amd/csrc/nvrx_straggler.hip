@@ -77,40 +77,47 @@ template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ uint32_t dpp(uint32_t old, uint32_t src) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
 }
+// lanes a DPP step has no source for read 0 (bound_ctrl): no `old` register has to be prepared
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp0(uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, 0xf, 0xf, true);
+}
 constexpr int DPP_QUAD_1032 = 0xb1, DPP_QUAD_2301 = 0x4e, DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112,
               DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
 
+// min / max steps hand the operation's identity to lanes without a source, which lets the compiler fold the DPP
+// move into the min / max itself (one instruction per step instead of three)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    v = min(v, dpp<DPP_QUAD_1032>(v, v));
-    v = min(v, dpp<DPP_QUAD_2301>(v, v));
-    v = min(v, dpp<DPP_ROW_SHR4>(v, v));
-    v = min(v, dpp<DPP_ROW_SHR8>(v, v));
-    v = min(v, dpp<DPP_BCAST15>(v, v));
-    v = min(v, dpp<DPP_BCAST31>(v, v));
+    v = min(v, dpp<DPP_QUAD_1032>(0xFFFFFFFFu, v));
+    v = min(v, dpp<DPP_QUAD_2301>(0xFFFFFFFFu, v));
+    v = min(v, dpp<DPP_ROW_SHR4>(0xFFFFFFFFu, v));
+    v = min(v, dpp<DPP_ROW_SHR8>(0xFFFFFFFFu, v));
+    v = min(v, dpp<DPP_BCAST15>(0xFFFFFFFFu, v));
+    v = min(v, dpp<DPP_BCAST31>(0xFFFFFFFFu, v));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    v = max(v, dpp<DPP_QUAD_1032>(v, v));
-    v = max(v, dpp<DPP_QUAD_2301>(v, v));
-    v = max(v, dpp<DPP_ROW_SHR4>(v, v));
-    v = max(v, dpp<DPP_ROW_SHR8>(v, v));
-    v = max(v, dpp<DPP_BCAST15>(v, v));
-    v = max(v, dpp<DPP_BCAST31>(v, v));
+    v = max(v, dpp0<DPP_QUAD_1032>(v));
+    v = max(v, dpp0<DPP_QUAD_2301>(v));
+    v = max(v, dpp0<DPP_ROW_SHR4>(v));
+    v = max(v, dpp0<DPP_ROW_SHR8>(v));
+    v = max(v, dpp0<DPP_BCAST15>(v));
+    v = max(v, dpp0<DPP_BCAST31>(v));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-    v += dpp<DPP_QUAD_1032>(0u, v);
-    v += dpp<DPP_QUAD_2301>(0u, v);
-    v += dpp<DPP_ROW_SHR4>(0u, v);
-    v += dpp<DPP_ROW_SHR8>(0u, v);
-    v += dpp<DPP_BCAST15>(0u, v);
-    v += dpp<DPP_BCAST31>(0u, v);
+    v += dpp0<DPP_QUAD_1032>(v);
+    v += dpp0<DPP_QUAD_2301>(v);
+    v += dpp0<DPP_ROW_SHR4>(v);
+    v += dpp0<DPP_ROW_SHR8>(v);
+    v += dpp0<DPP_BCAST15>(v);
+    v += dpp0<DPP_BCAST31>(v);
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double src) {
     const uint64_t u = (uint64_t)__double_as_longlong(src);
-    const uint32_t lo = dpp<CTRL>(0u, (uint32_t)u), hi = dpp<CTRL>(0u, (uint32_t)(u >> 32));
+    const uint32_t lo = dpp0<CTRL>((uint32_t)u), hi = dpp0<CTRL>((uint32_t)(u >> 32));
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));  // +0.0 where no source lane
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -168,14 +175,28 @@ __device__ unsigned long long g_phase[4096][12];
     do {                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x < 4096) g_phase[blockIdx.x][i] = clock64(); \
     } while (0)
+// finer marks inside the selection, taken by the first and the last wave of the workgroup
+__device__ unsigned long long g_sub[4096][2][16];
+#define NVRX_SUB(i)                                                                                              \
+    do {                                                                                                         \
+        if ((threadIdx.x == 0 || threadIdx.x == blockDim.x - 64) && blockIdx.x < 4096)                           \
+            g_sub[blockIdx.x][threadIdx.x ? 1 : 0][i] = clock64();                                               \
+    } while (0)
 #else
 #define NVRX_PHASE(i) \
     do {              \
     } while (0)
+#define NVRX_SUB(i) \
+    do {            \
+    } while (0)
 #endif
 
-constexpr int HIST_BITS = 11;
-constexpr int HIST_BINS = 1 << HIST_BITS;
+// Histogram size: 2^12 bins for the 512- and 1024-thread launches (rows beyond 2048 samples: the selected bin then holds
+// 20-40 of 10 000 samples, few enough for one wave to rank), 2^11 for the 256-thread ones.  NVRX_HIST_BITS_WIDE is a
+// tools/kbench.cpp switch.
+#ifndef NVRX_HIST_BITS_WIDE
+#define NVRX_HIST_BITS_WIDE 12
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Cross-rank scoring on the exchanged table (layout in nvrx_straggler.h).  (Fusing this into the tail
@@ -344,18 +365,18 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 
 // min and max reductions interleaved so that the two dependent DPP chains hide each other's latency
 __device__ __forceinline__ void wave_minmax_u32(uint32_t &mn, uint32_t &mx) {
-    mn = min(mn, dpp<DPP_QUAD_1032>(mn, mn));
-    mx = max(mx, dpp<DPP_QUAD_1032>(mx, mx));
-    mn = min(mn, dpp<DPP_QUAD_2301>(mn, mn));
-    mx = max(mx, dpp<DPP_QUAD_2301>(mx, mx));
-    mn = min(mn, dpp<DPP_ROW_SHR4>(mn, mn));
-    mx = max(mx, dpp<DPP_ROW_SHR4>(mx, mx));
-    mn = min(mn, dpp<DPP_ROW_SHR8>(mn, mn));
-    mx = max(mx, dpp<DPP_ROW_SHR8>(mx, mx));
-    mn = min(mn, dpp<DPP_BCAST15>(mn, mn));
-    mx = max(mx, dpp<DPP_BCAST15>(mx, mx));
-    mn = min(mn, dpp<DPP_BCAST31>(mn, mn));
-    mx = max(mx, dpp<DPP_BCAST31>(mx, mx));
+    mn = min(mn, dpp<DPP_QUAD_1032>(0xFFFFFFFFu, mn));
+    mx = max(mx, dpp0<DPP_QUAD_1032>(mx));
+    mn = min(mn, dpp<DPP_QUAD_2301>(0xFFFFFFFFu, mn));
+    mx = max(mx, dpp0<DPP_QUAD_2301>(mx));
+    mn = min(mn, dpp<DPP_ROW_SHR4>(0xFFFFFFFFu, mn));
+    mx = max(mx, dpp0<DPP_ROW_SHR4>(mx));
+    mn = min(mn, dpp<DPP_ROW_SHR8>(0xFFFFFFFFu, mn));
+    mx = max(mx, dpp0<DPP_ROW_SHR8>(mx));
+    mn = min(mn, dpp<DPP_BCAST15>(0xFFFFFFFFu, mn));
+    mx = max(mx, dpp0<DPP_BCAST15>(mx));
+    mn = min(mn, dpp<DPP_BCAST31>(0xFFFFFFFFu, mn));
+    mx = max(mx, dpp0<DPP_BCAST31>(mx));
     mn = (uint32_t)__builtin_amdgcn_readlane((int)mn, 63);
     mx = (uint32_t)__builtin_amdgcn_readlane((int)mx, 63);
 }
@@ -366,21 +387,23 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                                                        const uint8_t *__restrict__ kinds, int row_stride,
                                                        float *__restrict__ stats, Epilogue ep, int uniform_n) {
     constexpr int WAVES = THREADS / 64;
+    constexpr int HIST_BITS = THREADS >= 512 ? NVRX_HIST_BITS_WIDE : 11;
+    constexpr int HIST_BINS = 1 << HIST_BITS;
     constexpr int PER = HIST_BINS / THREADS;  // histogram bins summed per thread
     constexpr int G = THREADS / 64;           // thread sums per lane in the wave-redundant scan
     constexpr int NKEY = VPT * 4;
     constexpr int CAND_MAX = 256;  // a selected bin this small is finished by direct ranking
-    constexpr int SEG = CAND_MAX / WAVES;  // candidate slots per wave
+    constexpr int CAND_ONE = 64;   // ... and one this small by every wave on its own, without a further exchange
     static_assert(HIST_BINS % THREADS == 0, "THREADS must divide the histogram size");
     static_assert(THREADS >= CAND_MAX, "candidate list is initialised one word per thread");
 
     __shared__ __attribute__((aligned(16))) uint32_t s_hist[HIST_BINS];
     __shared__ __attribute__((aligned(16))) uint32_t s_sum[THREADS];
-    __shared__ __attribute__((aligned(16))) uint32_t s_cand[CAND_MAX];  // WAVES private segments of SEG slots
+    __shared__ __attribute__((aligned(16))) uint32_t s_cand[CAND_MAX];  // compact candidate list (unused slots: 0xFFFFFFFF)
     __shared__ __attribute__((aligned(16))) uint32_t s_lt[CAND_MAX];    // per slot: how many candidates are smaller
     __shared__ __attribute__((aligned(16))) double s_d[2 * WAVES];  // [0,W) partial sums, [W,2W) squared deviations
     __shared__ __attribute__((aligned(16))) uint32_t s_mm[4];       // {tile-0 min, tile-0 max, row min, row max}
-    __shared__ uint32_t s_cur[1];                                   // set when a wave's candidate segment overflowed
+    __shared__ uint32_t s_cur[1];                                   // append cursor of the candidate list
 
     const int row = ep.rows_active ? (int)(blockIdx.x / ep.rows_active) * ep.rows_per_rank + (int)(blockIdx.x % ep.rows_active)
                                    : (int)blockIdx.x;
@@ -418,8 +441,13 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             if ((uint32_t)(v * 4) < n) x[i] = src[v];
         }
         // LDS scratch is initialised while the loads are in flight
+        if constexpr (PER % 4 == 0) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) s_hist[tid * PER + j] = 0u;
+            for (int j = 0; j < PER; j += 4) reinterpret_cast<uint4 *>(s_hist)[(tid * PER + j) >> 2] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; j++) s_hist[tid * PER + j] = 0u;
+        }
         if (tid < CAND_MAX) {
             s_cand[tid] = 0xFFFFFFFFu;
             s_lt[tid] = 0u;
@@ -432,7 +460,10 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         // slots past the row's end get the key 0xFFFFFFFF and never take part in anything.
         const int full_tiles = (int)(n / (uint32_t)(THREADS * 4));
         const uint32_t k_rank = (n - 1u) >> 1;
-        const double inv_n = 1.0 / (double)n;  // off the critical path: computed while the loads are in flight
+        // reciprocals off the critical path (computed while the loads are in flight): 1/n for the mean, and the
+        // variance's denominator (n-1 for sections, n for kernel rows: CuptiProfiler.cpp:66-72)
+        const double inv_n = 1.0 / (double)n;
+        const double inv_den = kind == NVRX_KIND_KERNEL ? inv_n : 1.0 / (double)(n - 1u);
 
         // ---- tile 0: keys, and the range estimate the histogram is laid over ---------------------------
         uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
@@ -541,7 +572,9 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                 for (int j = 0; j < PER; j++) local += s_hist[tid * PER + j];
                 s_sum[tid] = local;
             }
+            NVRX_SUB(0);
             __syncthreads();  // thread sums published
+            NVRX_SUB(1);
             uint32_t ts[G];
             uint32_t local = 0u;
 #pragma unroll
@@ -551,43 +584,48 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             }
             const uint32_t incl = wave_scan_u32(local);
             const uint32_t excl = incl - local;
-            // inside every lane: how many of its G sums lie wholly below rank k, and their total
-            // (plain VALU in all lanes at once; only the owner lane's answer is read back)
-            uint32_t gcnt = 0u, gblw = 0u;
+            NVRX_SUB(2);
+            // inside every lane: how many of its G sums lie wholly below rank k, and their total -- written as
+            // independent compares / selects over the lane's inclusive prefix (short dependent chains; plain VALU
+            // in all lanes at once, only the owner lane's answer is read back)
+            uint32_t gcnt = 0u, gblw = excl;
             {
+                uint32_t pre[G];
                 uint32_t run = excl;
 #pragma unroll
                 for (int g = 0; g < G - 1; g++) {
                     run += ts[g];
-                    const bool adv = k >= run;
+                    pre[g] = run;
+                }
+#pragma unroll
+                for (int g = 0; g < G - 1; g++) {
+                    const bool adv = k >= pre[g];
                     gcnt += adv ? 1u : 0u;
-                    gblw = adv ? run : gblw;
+                    gblw = max(gblw, adv ? pre[g] : 0u);
                 }
             }
-            gblw = max(gblw, excl);
             const int L = __builtin_ctzll(__ballot(k >= excl && k < incl));  // exactly one lane owns rank k
             const uint32_t gsel = (uint32_t)__builtin_amdgcn_readlane((int)gcnt, L);
             uint32_t krem = k - (uint32_t)__builtin_amdgcn_readlane((int)gblw, L);
             const uint32_t tsel = (uint32_t)L * G + gsel;  // thread whose PER bins hold rank k
-            uint32_t bsel = 0u;
+            uint32_t bsel;
             {
-                // same address in every lane (LDS broadcast): the values are wave-uniform VGPRs
-                uint32_t run = 0u, blw = 0u;
-                pop = s_hist[tsel * PER];
-#pragma unroll
-                for (int j = 0; j < PER - 1; j++) {
-                    run += s_hist[tsel * PER + j];
-                    const bool adv = krem >= run;
-                    bsel += adv ? 1u : 0u;
-                    blw = adv ? run : blw;
-                    pop = adv ? s_hist[tsel * PER + j + 1] : pop;
-                }
-                krem -= blw;
-                bsel = uni(bsel);
-                krem = uni(krem);
-                pop = uni(pop);
+                // the PER bins of that thread, one per lane: a prefix scan inside the first DPP row finds the bin
+                static_assert(PER <= 16, "the bins of one thread are scanned inside one DPP row");
+                const uint32_t val = lane < PER ? s_hist[tsel * PER + (uint32_t)(lane & (PER - 1))] : 0u;
+                uint32_t inc2 = val;
+                if (PER > 1) inc2 += dpp0<DPP_ROW_SHR1>(inc2);
+                if (PER > 2) inc2 += dpp0<DPP_ROW_SHR2>(inc2);
+                if (PER > 4) inc2 += dpp0<DPP_ROW_SHR4>(inc2);
+                if (PER > 8) inc2 += dpp0<DPP_ROW_SHR8>(inc2);
+                // first lane whose inclusive count exceeds the remaining rank (lane PER-1 always does)
+                const int B = __builtin_ctzll(__ballot(lane < PER && krem < inc2) | (1ull << (PER - 1)));
+                bsel = (uint32_t)B;
+                pop = (uint32_t)__builtin_amdgcn_readlane((int)val, B);
+                krem -= (uint32_t)__builtin_amdgcn_readlane((int)(inc2 - val), B);
             }
             k = krem;
+            NVRX_SUB(3);
             return tsel * PER + bsel;
         };
 
@@ -635,46 +673,122 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             while (sh > 0u) {
                 if (pop <= (uint32_t)CAND_MAX) {
                     // ---- finish by ranking the bin's few members directly ----------------------------------
-                    // Members go to this wave's private segment of s_cand: the wave-uniform cursor lives in an
-                    // SGPR, so appending costs no LDS atomic, and a wave only leaves the compare loop where
-                    // one of its lanes holds a member.
-                    uint32_t wcnt = 0u;
+                    // One branch-free stream over the keys: membership compare, the wave's member count from the
+                    // compare masks on the scalar unit, and per lane its own member count, its last member and the XOR
+                    // of its members.  One returning LDS add reserves the wave's stretch of the compact candidate list
+                    // (issued by hand: the compiler's uniform-atomic rewrite would wait for the result on the spot); its
+                    // latency hides under the moments.  Lanes holding one or two members -- all of them, bar one
+                    // workgroup in thirty -- place them from a prefix scan of the counts (two members: last, and
+                    // XOR ^ last); a wave in which some lane holds three or more revisits its keys one by one instead.
+                    uint32_t wcnt = 0u, wbase = 0u;
+                    if constexpr (NKEY <= 24) {
+                        uint32_t mcnt = 0u, last = 0u, mxor = 0u;
 #pragma unroll
-                    for (int j = 0; j < NKEY; j++) {
-                        const uint32_t r = key[j] - base;  // wraps to a huge value below the bin
-                        const bool member = (r >> sh) == 0u;
-                        const unsigned long long bal = __ballot(member);
-                        if (bal) {  // wave-uniform
-                            const uint32_t pos = wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                            if (member && pos < (uint32_t)SEG) s_cand[wave * SEG + pos] = r;
-                            wcnt += (uint32_t)__popcll(bal);
+                        for (int j = 0; j < NKEY; j++) {
+                            const uint32_t r = key[j] - base;  // wraps to a huge value below the bin
+                            const bool member = (r >> sh) == 0u;
+                            wcnt += (uint32_t)__popcll(__ballot(member));
+                            mcnt += member ? 1u : 0u;
+                            last = member ? r : last;
+                            mxor ^= member ? r : 0u;
+                        }
+                        NVRX_SUB(4);
+                        if (lane == 0 && wcnt) {
+                            const uint32_t cur_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s_cur;
+                            asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(wbase) : "v"(cur_addr), "v"(wcnt) : "memory");
+                        }
+                        if (!moments_done) {
+                            finish_moments();
+                            moments_done = true;
+                        }
+                        NVRX_SUB(5);
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wbase) : : "memory");
+                        wbase = uni(wbase);
+                        if (wcnt) {  // wave-uniform
+                            if (__ballot(mcnt > 2u) == 0ull) {
+                                const uint32_t pos = wbase + wave_scan_u32(mcnt) - mcnt;
+                                if (mcnt >= 1u && pos < (uint32_t)CAND_MAX) s_cand[pos] = last;
+                                if (mcnt >= 2u && pos + 1u < (uint32_t)CAND_MAX) s_cand[pos + 1u] = mxor ^ last;
+                            } else {
+                                uint32_t run = wbase;
+#pragma unroll
+                                for (int j = 0; j < NKEY; j++) {
+                                    const uint32_t r = key[j] - base;
+                                    const bool member = (r >> sh) == 0u;
+                                    const unsigned long long b = __ballot(member);
+                                    if (b) {  // wave-uniform
+                                        const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                                        if (member && pos < (uint32_t)CAND_MAX) s_cand[pos] = r;
+                                        run += (uint32_t)__popcll(b);
+                                    }
+                                }
+                            }
+                        }
+                    } else {
+                        // long register tiles (more masks than SGPRs): count first, then revisit mask by mask
+#pragma unroll
+                        for (int j = 0; j < NKEY; j++) wcnt += (uint32_t)__popcll(__ballot(((key[j] - base) >> sh) == 0u));
+                        if (lane == 0 && wcnt) wbase = atomicAdd(&s_cur[0], wcnt);
+                        wbase = uni(wbase);
+                        if (!moments_done) {
+                            finish_moments();
+                            moments_done = true;
+                        }
+                        if (wcnt) {  // wave-uniform
+                            uint32_t run = wbase;
+#pragma unroll
+                            for (int j = 0; j < NKEY; j++) {
+                                const uint32_t r = key[j] - base;
+                                const bool member = (r >> sh) == 0u;
+                                const unsigned long long b = __ballot(member);
+                                if (b) {  // wave-uniform
+                                    const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                                    if (member && pos < (uint32_t)CAND_MAX) s_cand[pos] = r;
+                                    run += (uint32_t)__popcll(b);
+                                }
+                            }
                         }
                     }
-                    if (wcnt > (uint32_t)SEG && lane == 0) s_cur[0] = 1u;
-                    if (!moments_done) {
-                        finish_moments();
-                        moments_done = true;
-                    }
+                    NVRX_SUB(6);
                     __syncthreads();  // candidates listed (unused slots hold 0xFFFFFFFF), deviation partials published
+                    NVRX_SUB(7);
                     NVRX_PHASE(5);
-                    if (uni(s_cur[0]) == 0u) {
+                    if (pop <= (uint32_t)CAND_ONE) {
+                        // Few enough for one wave: lane L owns candidate L and counts the candidates below it (the list is
+                        // read as LDS broadcasts, 32 slots per batch of loads); the value at rank k is the largest
+                        // candidate with lt <= k (empty slots compare as +inf: lt = pop > k).  Every wave does the same
+                        // work and reaches the same answer, so nothing is exchanged any more.
+                        const uint32_t own = s_cand[lane];
+                        uint32_t lt0 = 0u, lt1 = 0u, lt2 = 0u, lt3 = 0u;  // four short add chains instead of one long one
+#pragma unroll
+                        for (int half = 0; half < CAND_ONE / 32; half++) {
+                            if (half == 0 || pop > (uint32_t)(half * 32)) {  // wave-uniform
+                                uint4 v[8];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) v[q] = reinterpret_cast<const uint4 *>(s_cand)[half * 8 + q];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) {
+                                    lt0 += (v[q].x < own) ? 1u : 0u;
+                                    lt1 += (v[q].y < own) ? 1u : 0u;
+                                    lt2 += (v[q].z < own) ? 1u : 0u;
+                                    lt3 += (v[q].w < own) ? 1u : 0u;
+                                }
+                            }
+                        }
+                        base += wave_max_u32((lt0 + lt1) + (lt2 + lt3) <= k ? own : 0u);
+                    } else {
                         // All-pairs ranking split over the waves: every lane owns 4 of the CAND_MAX slots, each
                         // wave compares all owners with ITS OWN members only and adds its partial "smaller than"
                         // counts into s_lt; after one more exchange every wave picks the value at rank k on its
-                        // own -- the largest candidate with lt <= k (empty slots compare as +inf: lt = pop > k).
+                        // own -- the largest candidate with lt <= k.
                         const uint4 own = reinterpret_cast<const uint4 *>(s_cand)[lane];
                         const uint32_t cv[4] = {own.x, own.y, own.z, own.w};
                         uint32_t lt[4] = {0u, 0u, 0u, 0u};
-                        const uint4 *seg4 = reinterpret_cast<const uint4 *>(s_cand + wave * SEG);
-                        for (uint32_t j = 0; j < min(wcnt, (uint32_t)SEG); j += 4u) {
-                            const uint4 v = seg4[j >> 2];  // same address in every lane: LDS broadcast
+                        const uint32_t wend = min(wbase + wcnt, (uint32_t)CAND_MAX);
+                        for (uint32_t j = wbase; j < wend; j++) {
+                            const uint32_t v = s_cand[j];  // same address in every lane: LDS broadcast
 #pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                lt[q] += (v.x < cv[q]) ? 1u : 0u;
-                                lt[q] += (v.y < cv[q]) ? 1u : 0u;
-                                lt[q] += (v.z < cv[q]) ? 1u : 0u;
-                                lt[q] += (v.w < cv[q]) ? 1u : 0u;
-                            }
+                            for (int q = 0; q < 4; q++) lt[q] += (v < cv[q]) ? 1u : 0u;
                         }
                         if (wcnt) {  // wave-uniform
 #pragma unroll
@@ -687,15 +801,11 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                         best = max(best, tot.z <= k ? cv[2] : 0u);
                         best = max(best, tot.w <= k ? cv[3] : 0u);
                         base += wave_max_u32(best);
-                        sh = 0u;
-                        break;
                     }
-                    // a wave held more members than its segment takes: start over with a finer histogram
-                    __syncthreads();
-                    if (tid < CAND_MAX) s_cand[tid] = 0xFFFFFFFFu;
-                    if (tid == 0) s_cur[0] = 0u;
+                    sh = 0u;
+                    break;
                 }
-                // ---- too heavy to rank directly: spread the bin's members over up to 2048 finer bins -------
+                // ---- too heavy to rank directly: spread the bin's members over up to HIST_BINS finer bins -------
                 path |= 4;
                 const uint32_t sh2 = sh > (uint32_t)HIST_BITS ? sh - (uint32_t)HIST_BITS : 0u;
                 __syncthreads();  // every wave is done reading s_hist / s_sum
@@ -717,6 +827,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                 __syncthreads();
             }
             med_key = base;
+            NVRX_SUB(8);
             NVRX_PHASE(6);
         }
         const uint32_t dsel = med_key - kmn;
@@ -760,11 +871,8 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         r_max = key2f(kmx);
         r_med = med;
         r_avg = (float)mean;
-        if (kind == NVRX_KIND_KERNEL) {
-            r_std = sqrtf((float)(ss / (double)n));
-        } else {
-            r_std = n > 1u ? sqrtf((float)(ss / (double)(n - 1u))) : __builtin_nanf("");
-        }
+        r_std = (kind == NVRX_KIND_KERNEL || n > 1u) ? sqrtf((float)(ss * inv_den)) : __builtin_nanf("");
+        NVRX_SUB(9);
     }
 
     if (tid == 0) {

@@ -129,8 +129,10 @@ int main(int argc, char **argv) {
     std::vector<uint32_t> c(rows, (uint32_t)n);
     CK(hipMemcpy(d_c, c.data(), rows * 4, hipMemcpyHostToDevice));
     hipEvent_t a, b;
-    CK(hipEventCreate(&a));
-    CK(hipEventCreate(&b));
+    // KB_EVFLAGS: flags of the timing events (0x20000000 hipEventDisableSystemFence, 0x40000000 hipEventReleaseToDevice)
+    const unsigned evflags = getenv("KB_EVFLAGS") ? (unsigned)strtoul(getenv("KB_EVFLAGS"), nullptr, 0) : 0u;
+    CK(hipEventCreateWithFlags(&a, evflags));
+    CK(hipEventCreateWithFlags(&b, evflags));
     for (int threads : {256, 512, 1024}) {
         if (only_threads && only_threads != threads) continue;
         const StatsVariant *best = nullptr;
@@ -282,6 +284,21 @@ int main(int argc, char **argv) {
                 s += (double)(ph[r][8] - ph[r][0]);
                 stg += (double)(ph[r][10] - w0);
                 hi = std::max(hi, ph[r][10] - w0);
+            }
+            {
+                static unsigned long long sb[4096][2][16];
+                CK(hipMemcpyFromSymbol(sb, HIP_SYMBOL(g_sub), sizeof(sb)));
+                // sub-marks relative to phase mark 3 (all waves released from barrier (2)): first wave / last wave
+                printf("  sub-marks after the barrier (2) release, mean clk [first wave | last wave]:");
+                for (int i = 0; i < 10; i++) {
+                    double a0 = 0, a1 = 0;
+                    for (int r = 0; r < nb; r++) {
+                        a0 += (double)(long long)(sb[r][0][i] - ph[r][3]);
+                        a1 += (double)(long long)(sb[r][1][i] - ph[r][3]);
+                    }
+                    printf(" s%d %.0f|%.0f", i, a0 / nb, a1 / nb);
+                }
+                printf("\n");
             }
             printf("  block total: mean %.0f clk; start stagger (wall, 10 ns ticks): mean %.1f max %llu; kernel wall span %llu ticks\n",
                    s / nb, stg / nb, hi, w1 - w0);
