@@ -73,6 +73,8 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 // ---- wave64 reductions on the DPP cross-lane path (no LDS traffic) ------------------------------
 // quad_perm -> row_shr:4/8 -> row_bcast:15/31 leaves the wave total in lane 63; readlane broadcasts it
 // through an SGPR.  `old` supplies the value for lanes a DPP step has no source for.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ uint32_t dpp(uint32_t old, uint32_t src) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
@@ -381,6 +383,16 @@ __device__ __forceinline__ void wave_minmax_u32(uint32_t &mn, uint32_t &mx) {
     mx = (uint32_t)__builtin_amdgcn_readlane((int)mx, 63);
 }
 
+// 1 / c for a sample count (an exactly representable integer, no special cases to patch up): hardware estimate + two
+// Newton steps instead of the full division sequence; 1/0 = +inf (a one-sample section: its deviation is NaN anyway)
+__device__ __forceinline__ double recip_count(uint32_t c) {
+    const double d = (double)c;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return c ? r : __builtin_inf();
+}
+
 template <int THREADS, int VPT>
 __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__ samples,
                                                        const uint32_t *__restrict__ counts,
@@ -462,8 +474,8 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         const uint32_t k_rank = (n - 1u) >> 1;
         // reciprocals off the critical path (computed while the loads are in flight): 1/n for the mean, and the
         // variance's denominator (n-1 for sections, n for kernel rows: CuptiProfiler.cpp:66-72)
-        const double inv_n = 1.0 / (double)n;
-        const double inv_den = kind == NVRX_KIND_KERNEL ? inv_n : 1.0 / (double)(n - 1u);
+        const double inv_n = recip_count(n);
+        const double inv_den = kind == NVRX_KIND_KERNEL ? inv_n : recip_count(n - 1u);
 
         // ---- tile 0: keys, and the range estimate the histogram is laid over ---------------------------
         uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const bool valid = full_tiles > 0 || e + c < n;
-                const uint32_t kk = f2key(xs[c]);
+                const uint32_t kk = __float_as_uint(xs[c]);  // raw bits: see "keys" below
                 key[c] = valid ? kk : 0xFFFFFFFFu;
                 kmn = min(kmn, key[c]);
                 kmx = max(kmx, valid ? kk : 0u);
@@ -503,8 +515,10 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         // q = sum((x-p)^2).  Once the row mean m is known each lane turns them into its exact share of
         // sum((x-m)^2) = q - 2(m-p)s + cnt(m-p)^2 in f64; cross-lane sums are f64 throughout.
         const float pivot = x[0].x;
+        const f32x2 pivot2 = {pivot, pivot};
         uint32_t cnt = 0u;
-        float psum = 0.f, psq = 0.f;
+        float psum = 0.f, psq = 0.f;  // partial tiles (lane-masked), scalar
+        f32x2 psum2 = {0.f, 0.f}, psq2 = {0.f, 0.f};  // full tiles, packed
 #pragma unroll
         for (int i = 0; i < VPT; i++) {
             const float xs[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
@@ -515,16 +529,19 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                     if (i == 0) {
                         kk = key[c];
                     } else {
-                        kk = f2key(xs[c]);
+                        kk = __float_as_uint(xs[c]);
                         key[i * 4 + c] = kk;
                         kmn = min(kmn, kk);
                         kmx = max(kmx, kk);
                     }
-                    const float d = xs[c] - pivot;
-                    psum += d;
-                    psq = fmaf(d, d, psq);
                     if (NVRX_ABLATE == 0) atomicAdd(&s_hist[min(__builtin_elementwise_sub_sat(kk, lo0) >> sh, (uint32_t)(HIST_BINS - 1))], 1u);
                 }
+                // moments of the tile as two packed pairs (v_pk_add_f32 / v_pk_fma_f32)
+                const f32x2 d01 = f32x2{xs[0], xs[1]} - pivot2, d23 = f32x2{xs[2], xs[3]} - pivot2;
+                psum2 += d01;
+                psq2 = __builtin_elementwise_fma(d01, d01, psq2);
+                psum2 += d23;
+                psq2 = __builtin_elementwise_fma(d23, d23, psq2);
                 cnt += 4u;
             } else {
                 const uint32_t e = (uint32_t)(i * THREADS + tid) * 4u;
@@ -535,7 +552,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                     if (i == 0) {
                         kk = key[c];
                     } else {
-                        kk = valid ? f2key(xs[c]) : 0xFFFFFFFFu;
+                        kk = valid ? __float_as_uint(xs[c]) : 0xFFFFFFFFu;
                         key[i * 4 + c] = kk;
                         kmn = min(kmn, kk);
                         kmx = max(kmx, valid ? kk : 0u);
@@ -549,6 +566,8 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                 }
             }
         }
+        psum += psum2.x + psum2.y;
+        psq += psq2.x + psq2.y;
         wave_minmax_u32(kmn, kmx);
         double sum = wave_sum_f64((double)psum + (double)cnt * (double)pivot);
         if (lane == 0) {
@@ -641,19 +660,56 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             if (lane == 0) s_d[WAVES + wave] = wss;
         };
 
+        // Keys.  Up to here a sample's key is its raw bit pattern: for non-negative floats -- every timing row there
+        // is -- the bits order like the values, so the hot loop spends nothing on a key transform.  A set sign bit
+        // anywhere (a negative sample, -0.0, a signed NaN) shows up as a row maximum >= 0x80000000: such a row is
+        // re-keyed in its registers with the order-preserving map f2key, its range taken again, and it continues
+        // through the exact-range rebuild below (block-uniform; costs that row a few extra exchanges).
+        const bool conv = kmx >= 0x80000000u;
+        if (conv) {
+            uint32_t a = 0xFFFFFFFFu, b = 0u;
+#pragma unroll
+            for (int j = 0; j < NKEY; j++) {
+                const bool valid = (j >> 2) < full_tiles || (uint32_t)(((j >> 2) * THREADS + tid) * 4 + (j & 3)) < n;
+                const uint32_t kk = f2key(__uint_as_float(key[j]));
+                key[j] = valid ? kk : 0xFFFFFFFFu;
+                a = min(a, key[j]);
+                b = max(b, valid ? kk : 0u);
+            }
+            wave_minmax_u32(a, b);
+            __syncthreads();  // every thread holds the raw range
+            if (tid == 0) {
+                s_mm[2] = 0xFFFFFFFFu;
+                s_mm[3] = 0u;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                atomicMin(&s_mm[2], a);
+                atomicMax(&s_mm[3], b);
+            }
+            __syncthreads();
+            kmn = uni(s_mm[2]);
+            kmx = uni(s_mm[3]);
+        }
+        auto key_value = [&](uint32_t kk) -> float { return conv ? key2f(kk) : __uint_as_float(kk); };
+
         uint32_t med_key;
         if (NVRX_ABLATE != 0 || kmn == kmx) {
             med_key = kmn;  // all samples equal (or selection ablated)
             finish_moments();
             __syncthreads();
         } else {
-            uint32_t k = k_rank, pop;
-            uint32_t bin = locate(k, pop);
+            uint32_t k = k_rank, pop = 0u, bin = 0u;
             path = 1;
-            if (speculative && (bin == 0u || bin == (uint32_t)(HIST_BINS - 1))) {
-                // The estimate missed: the edge bins also hold everything that was clamped.  Rebuild the
-                // histogram over the exact range (nothing is clamped any more) and locate again.
-                path = 2;
+            bool rebuild = conv;
+            if (!conv) {
+                bin = locate(k, pop);
+                rebuild = speculative && (bin == 0u || bin == (uint32_t)(HIST_BINS - 1));
+            }
+            if (rebuild) {
+                // The estimate missed (the edge bins also hold everything that was clamped), or the row was re-keyed:
+                // rebuild the histogram over the exact range (nothing is clamped any more) and locate again.
+                path = conv ? 18 : 2;
                 lo0 = kmn;
                 const int top = 32 - __clz((int)(kmx - kmn));
                 sh = (uint32_t)(top > HIST_BITS ? top - HIST_BITS : 0);
@@ -670,6 +726,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             uint32_t base = lo0 + (bin << sh);  // first key of the bin that holds the median
             NVRX_PHASE(4);
             bool moments_done = false;
+            const bool all_waves_finish = kind == NVRX_KIND_KERNEL && (n & 1u) == 0u;
             while (sh > 0u) {
                 if (pop <= (uint32_t)CAND_MAX) {
                     // ---- finish by ranking the bin's few members directly ----------------------------------
@@ -756,8 +813,14 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                     if (pop <= (uint32_t)CAND_ONE) {
                         // Few enough for one wave: lane L owns candidate L and counts the candidates below it (the list is
                         // read as LDS broadcasts, 32 slots per batch of loads); the value at rank k is the largest
-                        // candidate with lt <= k (empty slots compare as +inf: lt = pop > k).  Every wave does the same
-                        // work and reaches the same answer, so nothing is exchanged any more.
+                        // candidate with lt <= k (empty slots compare as +inf: lt = pop > k).  Nothing is exchanged
+                        // any more: section rows are finished by wave 0 alone (only thread 0 stores results; the other
+                        // waves are done and leave the SIMDs to it), kernel rows with an even count need the median in
+                        // every wave for their second middle element, so every wave ranks.
+                        if (wave != 0 && !all_waves_finish) {
+                            sh = 0u;
+                            break;
+                        }
                         const uint32_t own = s_cand[lane];
                         uint32_t lt0 = 0u, lt1 = 0u, lt2 = 0u, lt3 = 0u;  // four short add chains instead of one long one
 #pragma unroll
@@ -831,7 +894,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             NVRX_PHASE(6);
         }
         const uint32_t dsel = med_key - kmn;
-        float med = key2f(med_key);
+        float med = key_value(med_key);
 
         if (kind == NVRX_KIND_KERNEL && (n & 1u) == 0u) {
             // mean of the two middle order statistics (CuptiProfiler.cpp:57-59): also need rank k+1.
@@ -859,7 +922,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                 mn_gt = min(mn_gt, s_sum[WAVES + w]);
             }
             const uint32_t dnext = (cnt_le >= k_rank + 2u) ? dsel : mn_gt;
-            med = (med + key2f(kmn + dnext)) / 2.0f;
+            med = (med + key_value(kmn + dnext)) / 2.0f;
         }
 
         NVRX_PHASE(7);
@@ -867,8 +930,8 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         double ss = 0.0;
 #pragma unroll
         for (int w = 0; w < WAVES; w++) ss += s_d[WAVES + w];
-        r_min = key2f(kmn);
-        r_max = key2f(kmx);
+        r_min = key_value(kmn);
+        r_max = key_value(kmx);
         r_med = med;
         r_avg = (float)mean;
         r_std = (kind == NVRX_KIND_KERNEL || n > 1u) ? sqrtf((float)(ss * inv_den)) : __builtin_nanf("");
