@@ -604,56 +604,49 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             const uint32_t incl = wave_scan_u32(local);
             const uint32_t excl = incl - local;
             NVRX_SUB(2);
-            // inside every lane: how many of its G sums lie wholly below rank k, and their total -- written as
-            // independent compares / selects over the lane's inclusive prefix (short dependent chains; plain VALU
-            // in all lanes at once, only the owner lane's answer is read back)
-            uint32_t gcnt = 0u, gblw = excl;
-            {
-                uint32_t pre[G];
-                uint32_t run = excl;
-#pragma unroll
-                for (int g = 0; g < G - 1; g++) {
-                    run += ts[g];
-                    pre[g] = run;
-                }
-#pragma unroll
-                for (int g = 0; g < G - 1; g++) {
-                    const bool adv = k >= pre[g];
-                    gcnt += adv ? 1u : 0u;
-                    gblw = max(gblw, adv ? pre[g] : 0u);
-                }
-            }
             const int L = __builtin_ctzll(__ballot(k >= excl && k < incl));  // exactly one lane owns rank k
-            const uint32_t gsel = (uint32_t)__builtin_amdgcn_readlane((int)gcnt, L);
-            uint32_t krem = k - (uint32_t)__builtin_amdgcn_readlane((int)gblw, L);
-            const uint32_t tsel = (uint32_t)L * G + gsel;  // thread whose PER bins hold rank k
-            uint32_t bsel;
-            {
-                // the PER bins of that thread, one per lane: a prefix scan inside the first DPP row finds the bin
-                static_assert(PER <= 16, "the bins of one thread are scanned inside one DPP row");
-                const uint32_t val = lane < PER ? s_hist[tsel * PER + (uint32_t)(lane & (PER - 1))] : 0u;
+            uint32_t krem = k - (uint32_t)__builtin_amdgcn_readlane((int)excl, L);
+            // Two more levels, each resolved by the lanes of the first DPP row in parallel (one value per lane, a prefix
+            // scan inside the row, a ballot): which of that lane's G thread sums holds the rank, then which of that
+            // thread's PER bins.  `cnt` <= 16 values at `src`; returns the index, leaves the rank inside it in krem
+            // and the value itself in `picked`.
+            auto row_pick = [&](const uint32_t *src, int cnt, uint32_t &picked) -> uint32_t {
+                const uint32_t val = lane < cnt ? src[lane & 15] : 0u;
                 uint32_t inc2 = val;
-                if (PER > 1) inc2 += dpp0<DPP_ROW_SHR1>(inc2);
-                if (PER > 2) inc2 += dpp0<DPP_ROW_SHR2>(inc2);
-                if (PER > 4) inc2 += dpp0<DPP_ROW_SHR4>(inc2);
-                if (PER > 8) inc2 += dpp0<DPP_ROW_SHR8>(inc2);
-                // first lane whose inclusive count exceeds the remaining rank (lane PER-1 always does)
-                const int B = __builtin_ctzll(__ballot(lane < PER && krem < inc2) | (1ull << (PER - 1)));
-                bsel = (uint32_t)B;
-                pop = (uint32_t)__builtin_amdgcn_readlane((int)val, B);
+                if (cnt > 1) inc2 += dpp0<DPP_ROW_SHR1>(inc2);
+                if (cnt > 2) inc2 += dpp0<DPP_ROW_SHR2>(inc2);
+                if (cnt > 4) inc2 += dpp0<DPP_ROW_SHR4>(inc2);
+                if (cnt > 8) inc2 += dpp0<DPP_ROW_SHR8>(inc2);
+                // first lane whose inclusive count exceeds the remaining rank (the last one always does)
+                const int B = __builtin_ctzll(__ballot(lane < cnt && krem < inc2) | (1ull << (cnt - 1)));
+                picked = (uint32_t)__builtin_amdgcn_readlane((int)val, B);
                 krem -= (uint32_t)__builtin_amdgcn_readlane((int)(inc2 - val), B);
-            }
+                return (uint32_t)B;
+            };
+            static_assert(PER <= 16 && G <= 16, "one DPP row resolves a level");
+            uint32_t tsum;
+            const uint32_t tsel = (uint32_t)L * G + row_pick(s_sum + L * G, G, tsum);  // thread whose PER bins hold rank k
+            const uint32_t bsel = row_pick(s_hist + tsel * PER, PER, pop);
             k = krem;
             NVRX_SUB(3);
             return tsel * PER + bsel;
         };
 
+        // pairwise sum of WAVES per-wave partials (a 2- or 3-level tree instead of a chain of dependent f64 adds)
+        auto sum_partials = [&](const double *q) -> double {
+            double t[WAVES];
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) t[w] = q[w];
+#pragma unroll
+            for (int step = 1; step < WAVES; step *= 2)
+#pragma unroll
+                for (int w = 0; w + step < WAVES; w += 2 * step) t[w] += t[w + step];
+            return t[0];
+        };
         // mean and this wave's share of the squared deviations (needs the partial sums of barrier (2))
         double mean = 0.0;
         auto finish_moments = [&]() {
-#pragma unroll
-            for (int w = 0; w < WAVES; w++) mean += s_d[w];  // = row sum, same order in every thread
-            mean = mean * inv_n;
+            mean = sum_partials(s_d) * inv_n;  // row sum: the same fixed pairing in every thread
             const double dm = mean - (double)pivot;
             const double lane_ss = (double)psq - 2.0 * dm * (double)psum + (double)cnt * dm * dm;
             const double wss = wave_sum_f64(lane_ss);
@@ -739,16 +732,25 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                     // XOR ^ last); a wave in which some lane holds three or more revisits its keys one by one instead.
                     uint32_t wcnt = 0u, wbase = 0u;
                     if constexpr (NKEY <= 24) {
-                        uint32_t mcnt = 0u, last = 0u, mxor = 0u;
+                        uint32_t mcnt = 0u, mcnt_hi = 0u, last = 0u, last_hi = 0u, mxor = 0u, mxor_hi = 0u;
 #pragma unroll
                         for (int j = 0; j < NKEY; j++) {
                             const uint32_t r = key[j] - base;  // wraps to a huge value below the bin
                             const bool member = (r >> sh) == 0u;
                             wcnt += (uint32_t)__popcll(__ballot(member));
-                            mcnt += member ? 1u : 0u;
-                            last = member ? r : last;
-                            mxor ^= member ? r : 0u;
+                            if (j < NKEY / 2) {  // two half-length chains per quantity
+                                mcnt += member ? 1u : 0u;
+                                last = member ? r : last;
+                                mxor ^= member ? r : 0u;
+                            } else {
+                                mcnt_hi += member ? 1u : 0u;
+                                last_hi = member ? r : last_hi;
+                                mxor_hi ^= member ? r : 0u;
+                            }
                         }
+                        last = mcnt_hi ? last_hi : last;
+                        mcnt += mcnt_hi;
+                        mxor ^= mxor_hi;
                         NVRX_SUB(4);
                         if (lane == 0 && wcnt) {
                             const uint32_t cur_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s_cur;
@@ -925,11 +927,10 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             med = (med + key_value(kmn + dnext)) / 2.0f;
         }
 
+        if (wave != 0) return;  // thread 0 stores the row's results: the other waves are done
         NVRX_PHASE(7);
         // squared-deviation partials were published before the last barrier each path went through
-        double ss = 0.0;
-#pragma unroll
-        for (int w = 0; w < WAVES; w++) ss += s_d[WAVES + w];
+        const double ss = sum_partials(s_d + WAVES);
         r_min = key_value(kmn);
         r_max = key_value(kmx);
         r_med = med;

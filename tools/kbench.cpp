@@ -74,6 +74,8 @@ static void gen(std::vector<float> &h, int rows, int n, int stride, int dist, fl
                 case 3: v = 10.f + 5.f * (float)i / (float)n + 0.1f * nd(g_rng); break;
                 case 4: v = (g_rng() % 100 == 0) ? 1000.f * nd(g_rng) : nd(g_rng); break;  // outliers
                 case 5: v = -nd(g_rng); break;                                               // negative values
+                case 6: v = 10.f + 0.01f * (float)(g_rng() % 100); break;                   // 100 distinct values: ~100 equal members per bin
+                case 7: v = 10.f + 0.001f * (float)(g_rng() % 400); break;                  // 400 distinct values: ~25 equal members per bin
                 default: v = nd(g_rng);
             }
             h[(size_t)r * stride + i] = v * scale;
