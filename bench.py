@@ -397,13 +397,14 @@ def main():
     job.rings.timing_enable(True)
     sync_all()
     t1 = time.perf_counter()
-    score_wait, score_tail = [], []
+    score_wait, score_tail, score_staged = [], [], []
     for _ in range(args.steps):
         step()
         plan = job.reporter._ring_plan
         if plan is not None:  # the score kernel's own clocks (10 ns ticks of the constant-rate wall clock), see nvrx_score
             score_wait.append(int(plan.ws.meta[6]))
-            score_tail.append(int(plan.ws.meta[7]))
+            score_tail.append(int(plan.ws.meta[7]) & 0xFFFF)
+            score_staged.append(int(plan.ws.meta[7]) >> 16)
     sync_all()
     elapsed_instr = time.perf_counter() - t1
     kern_total_us, kern_launches = job.rings.timing_read(reset=True)
@@ -525,6 +526,7 @@ def main():
             out["score_kernel"] = {
                 "waited_for_rows_us": round(float(np.median(score_wait)) / 100.0, 2),
                 "last_row_to_completion_word_us": round(float(np.median(score_tail)) / 100.0, 2),
+                "last_row_to_scores_staged_us": round(float(np.median(score_staged)) / 100.0, 2),
                 "note": "device clocks of the score kernel: resident on its own stream it waits for the statistics kernel's "
                         "granules; queued behind it (or behind an RCCL exchange) the first figure is ~0 and the second "
                         "is the kernel's whole body",

@@ -100,7 +100,8 @@ int nvrx_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8
  *      aligned: pad each array to a multiple of 16 bytes;
  *   d_flags  [R][NVRX_SCORE_LEN(S)] u8 out, 1 where score < threshold (strict; NaN never flagged);
  *   d_meta   [NVRX_META_WORDS] u32 out: {all ranks' name flags set, R, K, S, seq, seq of the statistics rows,
- *      wait for the rows [10 ns ticks], last row -> completion word [10 ns ticks]} (the last two: single-workgroup kernel only);
+ *      wait for the rows [10 ns ticks], (last row -> scores staged) << 16 | (last row -> completion word) [10 ns ticks, 16 bits each]}
+ *      (the last two: single-workgroup kernel only);
  *   d_done_counter  device word (zero before the first launch) or NULL.  When given, d_scores /
  *      d_flags / d_meta may point into pinned host memory (nvrx_host_alloc): after every block's
  *      results are visible system-wide the kernel stores `seq` into d_meta[4] with release

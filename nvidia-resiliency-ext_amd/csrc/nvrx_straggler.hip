@@ -224,14 +224,21 @@ struct ScoreArgs {
 };
 
 // all_reduce(MIN) of the f32 MED tensor with -1 sentinels (reporting.py:273-295) into s_min[KS]
-__device__ __forceinline__ void score_colmin(const ScoreArgs &a, int tid, int nthr, float *s_min) {
+// `tab` is the table ([R][L]) wherever it lives: the callers pass a pointer whose address space the compiler can see (LDS
+// in the kernels that assemble the table themselves: ds_read instead of flat loads), and eight ranks are loaded at a
+// time so that the loads are in flight together instead of one round trip per rank.
+__device__ __forceinline__ void score_colmin(const ScoreArgs &a, const float *tab, int tid, int nthr, float *s_min) {
     const int KS = a.K + a.S;
     const int L = NVRX_TABLE_LEN(a.K, a.S);
     for (int j = tid; j < KS; j += nthr) {
         float m = INFINITY;
-        for (int q = 0; q < a.R; q++) {
-            const float v = a.table[(size_t)q * L + j];
-            if (v < m) m = v;
+        for (int q = 0; q < a.R; q += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = q + u < a.R ? tab[(size_t)(q + u) * L + j] : INFINITY;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (v[u] < m) m = v[u];
         }
         s_min[j] = m >= 0.0f ? m : __builtin_nanf("");  // reporting.py:289,295
     }
@@ -239,13 +246,13 @@ __device__ __forceinline__ void score_colmin(const ScoreArgs &a, int tid, int nt
 
 // Scores and flags of rank r, by all NTHR threads of the workgroup (contains one barrier).
 template <int NTHR>
-__device__ __forceinline__ void score_rank(const ScoreArgs &a, int r, int tid, const float *minmed,
+__device__ __forceinline__ void score_rank(const ScoreArgs &a, const float *tab, int r, int tid, const float *minmed,
                                            double (*s_red)[NTHR / 64], uint32_t (*s_cnt)[NTHR / 64],
                                            float *__restrict__ out, uint8_t *__restrict__ fl) {
     const int K = a.K, S = a.S, KS = K + S;
     const int L = NVRX_TABLE_LEN(K, S);
     const int lane = tid & 63, wave = tid >> 6;
-    const float *__restrict__ row = a.table + (size_t)r * L;
+    const float *__restrict__ row = tab + (size_t)r * L;
     const float NaN = __builtin_nanf("");
 
     // section scores: reference / MED (reporting.py:196-217), rounded to f32 (reporting.py:352)
@@ -322,10 +329,10 @@ __device__ __forceinline__ void score_rank(const ScoreArgs &a, int r, int tid, c
 }
 
 // is_all_true(has_all_names) (name_mapper.py:68-69, dist_utils.py:107-115) folded into the table; one wave
-__device__ __forceinline__ void score_meta(const ScoreArgs &a, int lane) {
+__device__ __forceinline__ void score_meta(const ScoreArgs &a, const float *tab, int lane) {
     const int L = NVRX_TABLE_LEN(a.K, a.S);
     uint32_t bad = 0;
-    for (int q = lane; q < a.R; q += 64) bad += (a.table[(size_t)q * L + (L - 1)] > 0.0f) ? 0u : 1u;
+    for (int q = lane; q < a.R; q += 64) bad += (tab[(size_t)q * L + (L - 1)] > 0.0f) ? 0u : 1u;
     bad = wave_sum_u32(bad);
     if (lane == 0) {
         a.meta[0] = bad ? 0u : 1u;
@@ -338,30 +345,35 @@ __device__ __forceinline__ void score_meta(const ScoreArgs &a, int lane) {
 // ------------------------------------------------------------------------------------------------
 // k_row_stats: one workgroup per timing row.
 //   HBM: the row is read once, 16 B per lane per load, VPT independent loads in flight per lane.
-//   Registers: the row lives in VPT*4 order-preserving keys per lane for the rest of the kernel.
-//   LDS: 8 KB histogram + thread sums + a 1 KB candidate list + a few words of reduction scratch.
+//   Registers: the row lives in VPT*4 order-preserving keys per lane for the rest of the kernel (the raw bit patterns:
+//   non-negative floats order like their bits; a row with a set sign bit is re-keyed on a cold path).
+//   LDS: 16 KB histogram (4096 bins; 2048 for the 256-thread launches) + thread sums + a 1 KB candidate list + a
+//   few words of reduction scratch.
 //
-// What bounds it (tools/micro/*.cpp, phase clocks of tools/kbench.cpp): a row of n keys on one CU costs
-// n/64 clk per VALU instruction applied to every key (156 clk at n = 10 000), ~10 clk of the CU's LDS
-// pipe per DS instruction however few lanes are active (one histogram pass = n/64 DS instructions =
-// ~1600 clk), and every exchange between waves is a dependent chain (LDS round trip ~75 clk, returning
-// LDS atomic ~250, 6-step DPP reduction ~150, exchange through a barrier ~175).  So the kernel
-// (1) keeps the per-key instruction count low, (2) starts the histogram before the row's exact range
-// is known, so that its DS traffic runs under the HBM load instead of after it, and (3) keeps the
-// number of exchanges after the last tile small:
+// What bounds it (tools/micro/*.cpp, phase clocks and PMC passes of tools/kbench.cpp): with one row per CU the kernel
+// is a chain of dependent steps (a dependent VALU instruction issues every ~8 clk per wave, an LDS round trip is ~75-130
+// clk, a returning LDS atomic ~250, a 6-step DPP reduction ~100, an exchange through a barrier ~175): chain length
+// matters, instruction counts do not.  With two rows per CU (the folded bench shape) the CU's VALU issue and its LDS
+// pipe (~10 clk per histogram ds_add under random bank conflicts, n/64 of them per row) are shared by 16 waves and
+// the instruction count per wave matters as well (871 -> 673 VALU per wave was worth 0.7 us).  So the kernel (1) keeps
+// the per-key instruction count low (6.5 VALU + one ds_add per key in the hot loop), (2) starts the histogram before
+// the row's exact range is known, so that its DS traffic runs under the HBM load instead of after it, (3) keeps the
+// exchanges after the last tile few and every chain between them short, and (4) lets work that only one wave needs
+// be done by one wave:
 //
 //   tile 0 (the first THREADS*4 samples) gives a range estimate [mn0 - R, mx0 + R], R = mx0 - mn0
-//   -> every key of every tile goes into a 2048-bin LDS histogram over that range as its tile arrives
-//      (keys outside are clamped into the two edge bins), while min / max / moments accumulate
-//   -> ONE exchange (thread sums; every wave then scans them on its own, results wave-uniform in SGPRs)
-//      locates the bin holding rank k = (n-1)/2
-//   -> the bin's few members append themselves to a candidate list (a wave only leaves its compare
-//      loop where one of its lanes holds a member) and every wave ranks the candidates on its own.
+//   -> every key of every tile goes into the LDS histogram over that range as its tile arrives (keys outside are
+//      clamped into the two edge bins), while min / max / packed f32 moments accumulate
+//   -> ONE exchange (thread sums); every wave scans them on its own (DPP prefix scan), then the lanes of one DPP row
+//      resolve the thread and the bin holding rank k = (n-1)/2 in parallel
+//   -> the bin's 20-40 members are collected without a branch per key (per lane: member count, last member, XOR of
+//      members) into a compact list (one returning LDS add per wave reserves its stretch), and wave 0 ranks them
+//      directly: lane L counts the candidates below candidate L.
 //
-// The result is always exact: if the median lands in an edge bin (the estimate missed: drifting or
-// heavy-tailed rows) the histogram is rebuilt over the exact [kmin, kmax]; a bin too heavy to rank
-// directly (> CAND_MAX members, e.g. many equal samples) is refined by further 11-bit passes until it
-// is a single key value.  Rows that fit in one tile skip the estimate: tile 0 is the whole row.
+// The result is always exact: if the median lands in an edge bin (the estimate missed: drifting or heavy-tailed rows)
+// the histogram is rebuilt over the exact [kmin, kmax]; a bin too heavy to rank directly (> CAND_MAX members, e.g.
+// many equal samples) is refined by further passes until it is a single key value; bins of 65-256 members are
+// ranked by all waves together.  Rows that fit in one tile skip the estimate: tile 0 is the whole row.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -1078,13 +1090,13 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
 
     const float *minmed = a.minmed_pre;
     if (!minmed) {
-        score_colmin(a, tid, SCORE_THREADS, s_min);
+        score_colmin(a, a.table, tid, SCORE_THREADS, s_min);
         __syncthreads();
         minmed = s_min;
     }
-    score_rank<SCORE_THREADS>(a, r, tid, minmed, s_red, s_cnt, a.scores + (size_t)r * NVRX_SCORE_LEN(a.S),
+    score_rank<SCORE_THREADS>(a, a.table, r, tid, minmed, s_red, s_cnt, a.scores + (size_t)r * NVRX_SCORE_LEN(a.S),
                               a.flags ? a.flags + (size_t)r * NVRX_SCORE_LEN(a.S) : nullptr);
-    if (r == 0 && a.meta && (tid >> 6) == 1) score_meta(a, tid & 63);
+    if (r == 0 && a.meta && (tid >> 6) == 1) score_meta(a, a.table, tid & 63);
 
     if (a.done_counter) {
         // Completion word for a polling host (results may live in pinned host memory): every block
@@ -1273,8 +1285,6 @@ __device__ __forceinline__ float wait_granule(const unsigned long long *p, const
 template <int NTHR>
 __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArgs pa, GatherArgs ga) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    __shared__ double s_red[8][NTHR / 64];   // two alternating sets of 4 (see the rank loop)
-    __shared__ uint32_t s_cnt[4][NTHR / 64];
 
     const int K = a.K, S = a.S, KS = K + S, R = a.R;
     const int L = NVRX_TABLE_LEN(K, S);
@@ -1290,6 +1300,20 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
     const int tid = threadIdx.x;
     const float NaN = __builtin_nanf("");
     const unsigned long long t_begin = wall_clock64();
+    // (rank, section) of this thread's first pair in the flat scoring pass, and the step to its next one: the integer
+    // divisions happen here, before the wait for the rows, not behind it
+    const int pair_r0 = tid / max(S, 1), pair_s0 = tid - pair_r0 * S;
+    const int pair_dr = NTHR / max(S, 1), pair_ds = NTHR - pair_dr * S;
+    // Resident scorer: everything the waves hand each other travels through LDS, so its barriers only wait for the LDS
+    // queue.  A full __syncthreads() also waits for every global store in flight -- the exchange rows written to
+    // device memory and, worse, the meta words stored to pinned HOST memory: a PCIe round trip in the middle of the tail.
+    const bool lds_only = ga.g && s_send;
+    auto sync = [&]() {
+        if (lds_only)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            __syncthreads();
+    };
 
     if (ga.g && s_send) {
         // sentinels of the exchange row (nvrx_send_init): -1 = no statistics, NaN history, zero weight
@@ -1307,10 +1331,21 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
         const int total = ga.n_blocks * 3;
         for (int base = tid; base < total; base += NTHR * CH) {
             unsigned long long x[CH];
+            int slot[CH];  // where a granule's value goes in the exchange rows (-1: nowhere) -- looked up BEFORE the wait,
+                           // so that the ring-row -> slot loads are not a dependent step behind the last arrival
             uint32_t pending = 0;
 #pragma unroll
-            for (int c = 0; c < CH; c++)
-                if (base + c * NTHR < total) pending |= 1u << c;
+            for (int c = 0; c < CH; c++) {
+                slot[c] = -1;
+                const int idx = base + c * NTHR;
+                if (idx < total) {
+                    pending |= 1u << c;
+                    const int b = idx / 3, q = idx - 3 * b;
+                    const int lr = b / ga.rows_active;
+                    const int gidv = ga.gid[lr * ga.rows_per_rank + (b - lr * ga.rows_active)];
+                    if (gidv >= 0 && gidv < KS && (q < 2 || gidv < K)) slot[c] = lr * L + q * KS + gidv;
+                }
+            }
             uint32_t spins = 0;
             while (pending) {
 #pragma unroll
@@ -1331,13 +1366,9 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
                         got = true;
                     }
                     if (got) {
-                        const int idx = base + c * NTHR;
-                        const int b = idx / 3, q = idx - 3 * b;
-                        const int lr = b / ga.rows_active;
-                        const int gidv = ga.gid[lr * ga.rows_per_rank + (b - lr * ga.rows_active)];
-                        if (gidv >= 0 && gidv < KS && (q < 2 || gidv < K)) {
-                            ga.send[(size_t)lr * L + q * KS + gidv] = v;
-                            if (s_send) s_send[lr * L + q * KS + gidv] = v;
+                        if (slot[c] >= 0) {
+                            ga.send[slot[c]] = v;
+                            if (s_send) s_send[slot[c]] = v;
                         }
                         pending &= ~(1u << c);
                     }
@@ -1352,7 +1383,7 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
             ga.send[(size_t)lr * L + (L - 1)] = ga.names_ok;
             if (s_send) s_send[lr * L + (L - 1)] = ga.names_ok;
         }
-        __syncthreads();
+        sync();
     }
     const unsigned long long t_rows = wall_clock64();  // resident scorer: every row's exchange values have arrived
     if (pa.windows) {
@@ -1369,44 +1400,103 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
         const float4 v = a.stats_src[i];
         store16_sys(a.stats_dst + i, nvrx_f4{v.x, v.y, v.z, v.w});
     }
-    score_colmin(a, tid, NTHR, s_min);
-    if (a.meta && (tid >> 6) == NTHR / 64 - 1) score_meta(a, tid & 63);
-    // zero the padding of the staged arrays (it is stored too)
-    if (tid < nout4 - nout) s_out[nout + tid] = 0.f;
-    if (tid < ((nout + 15) & ~15) - nout) s_fl[nout + tid] = 0;
-    __syncthreads();
+    // The scoring proper, instantiated twice: over the table in LDS (the variants that assemble it themselves; the
+    // pointer's address space is visible to the compiler there, so every access is a ds_read) or over the table in
+    // device memory.  Through one generic pointer the same loads are FLAT loads with the latency of a memory access:
+    // eight dependent ones per column made up most of the resident scorer's tail.
+    auto score_all = [&](const float *tab) {
+        score_colmin(a, tab, tid, NTHR, s_min);
+        if (a.meta && (tid >> 6) == NTHR / 64 - 1) score_meta(a, tab, tid & 63);
+        // zero the padding of the staged arrays (it is stored too)
+        if (tid < nout4 - nout) s_out[nout + tid] = 0.f;
+        if (tid < ((nout + 15) & ~15) - nout) s_fl[nout + tid] = 0;
+        sync();
 
-    if (K == 0) {
-        // no GPU-timed rows anywhere: every (rank, section) pair is independent -> one flat pass, no barriers
-        for (int idx = tid; idx < R * S; idx += NTHR) {
-            const int r = idx / S, sct = idx - r * S;
-            const float *__restrict__ row = a.table + (size_t)r * L;
-            const float med = row[sct];
-            float si = NaN, sr = NaN;
-            if (med >= 0.0f) {
-                if (a.do_indiv) si = (float)((double)row[KS + sct] / (double)med);
-                if (a.do_rel) sr = (float)((double)s_min[sct] / (double)med);
+        // Section scores of every rank in one flat pass: each (rank, section) pair is independent, no barriers.  (reference
+        // / MED, reporting.py:196-217, rounded to f32 as in reporting.py:352.  The reference divides in f64 and rounds to
+        // f32; the correctly rounded f32 quotient is the same number -- 53 >= 2 * 24 + 2 significand bits: rounding
+        // twice is innocuous for a quotient -- at a third of the dependent chain.)
+        {
+            int r = pair_r0, sct = pair_s0;  // (rank, section) of pair `tid`, worked out before the wait for the rows
+#pragma unroll 2
+            for (int idx = tid; idx < R * S; idx += NTHR) {
+                const float *__restrict__ row = tab + (size_t)r * L;
+                const float med = row[K + sct];
+                float si = NaN, sr = NaN;
+                if (med >= 0.0f) {
+                    if (a.do_indiv) si = __fdiv_rn(row[KS + K + sct], med);
+                    if (a.do_rel) sr = __fdiv_rn(s_min[K + sct], med);
+                }
+                s_out[r * W + 2 + sct] = si;
+                s_out[r * W + 2 + S + sct] = sr;
+                s_fl[r * W + 2 + sct] = ((double)si < a.thr[3]) ? 1 : 0;
+                s_fl[r * W + 2 + S + sct] = ((double)sr < a.thr[1]) ? 1 : 0;
+                r += pair_dr;
+                sct += pair_ds;
+                if (sct >= S) {
+                    sct -= S;
+                    r++;
+                }
             }
-            s_out[r * W + 2 + sct] = si;
-            s_out[r * W + 2 + S + sct] = sr;
-            s_fl[r * W + 2 + sct] = ((double)si < a.thr[3]) ? 1 : 0;
-            s_fl[r * W + 2 + S + sct] = ((double)sr < a.thr[1]) ? 1 : 0;
         }
-        for (int r = tid; r < R; r += NTHR) {  // reporting.py:226-228: no kernels -> NaN, never flagged
-            s_out[r * W] = NaN;
-            s_out[r * W + 1] = NaN;
-            s_fl[r * W] = 0;
-            s_fl[r * W + 1] = 0;
+        // GPU scores: weighted mean of per-kernel ratios (reporting.py:219-253).  One WAVE per rank (ranks w, w + waves,
+        // ...): a rank's few GPU-timed rows fit the lanes of a wave, its sums are wave reductions, and nothing is
+        // exchanged between waves -- R ranks cost one pass instead of R barrier-separated ones.
+        if (K == 0) {
+            for (int r = tid; r < R; r += NTHR) {  // reporting.py:226-228: no kernels -> NaN, never flagged
+                s_out[r * W] = NaN;
+                s_out[r * W + 1] = NaN;
+                s_fl[r * W] = 0;
+                s_fl[r * W + 1] = 0;
+            }
+        } else {
+            const int lane = tid & 63;
+            for (int r = tid >> 6; r < R; r += NTHR / 64) {
+                const float *__restrict__ row = tab + (size_t)r * L;
+                double wi = 0.0, si = 0.0, wr = 0.0, sr = 0.0;
+                uint32_t nk = 0, ncommon = 0;
+                for (int k = lane; k < K; k += 64) {
+                    const float medf = row[k];
+                    if (!(medf >= 0.0f)) continue;
+                    const double med = (double)medf;
+                    const double w = (double)row[2 * KS + k];
+                    nk++;
+                    si += ((double)row[KS + k] / med) * w;
+                    wi += w;
+                    const float mm = s_min[k];
+                    if (mm == mm) {
+                        ncommon++;
+                        sr += ((double)mm / med) * w;
+                        wr += w;
+                    }
+                }
+                wi = wave_sum_f64(wi);
+                si = wave_sum_f64(si);
+                wr = wave_sum_f64(wr);
+                sr = wave_sum_f64(sr);
+                nk = wave_sum_u32(nk);
+                ncommon = wave_sum_u32(ncommon);
+                if (lane == 0) {
+                    const float gi = (a.do_indiv && nk > 0) ? (float)(si / wi) : NaN;
+                    const float gr = (a.do_rel && ncommon > 0) ? (float)(sr / wr) : NaN;
+                    s_out[r * W] = gi;
+                    s_out[r * W + 1] = gr;
+                    s_fl[r * W] = ((double)gi < a.thr[2]) ? 1 : 0;
+                    s_fl[r * W + 1] = ((double)gr < a.thr[0]) ? 1 : 0;
+                }
+            }
         }
-    } else {
-        // rank r's reduction scratch alternates between two sets: thread 0 may still be summing set r&1 while the
-        // other waves already fill set (r+1)&1; set r&1 is rewritten only after the barrier of rank r+1.
-        for (int r = 0; r < R; r++)
-            score_rank<NTHR>(a, r, tid, s_min, s_red + 4 * (r & 1), s_cnt + 2 * (r & 1), s_out + r * W, s_fl + r * W);
-    }
-    __syncthreads();
+        sync();
+    };
+    if (s_tab && pa.windows)
+        score_all(s_tab);
+    else if (ga.g && s_send && !pa.windows)
+        score_all(s_send);
+    else
+        score_all(a.table);
 
     // staged results -> result block, 16 bytes per lane
+    const unsigned long long t_staged = wall_clock64();
     {
         const nvrx_f4 *src = reinterpret_cast<const nvrx_f4 *>(s_out);
         nvrx_f4 *dst = reinterpret_cast<nvrx_f4 *>(a.scores);
@@ -1430,7 +1520,9 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
         // diagnostics (constant-rate wall clock, 10 ns ticks): how long this kernel waited for the rows, and how long
         // it took from the last row to this store
         __hip_atomic_store(&a.meta[6], (uint32_t)(t_rows - t_begin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&a.meta[7], (uint32_t)(wall_clock64() - t_rows), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (low half: last row -> this store; high half: last row -> scores staged in LDS, i.e. before the host stores)
+        __hip_atomic_store(&a.meta[7], (uint32_t)min(wall_clock64() - t_rows, 0xFFFFull) | ((uint32_t)min(t_staged - t_rows, 0xFFFFull) << 16),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (ga.g && ga.stats_out) {

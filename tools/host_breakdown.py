@@ -22,7 +22,7 @@ gc.collect()
 tot, rearm, wait, tail = [], [], [], []
 for _ in range(400):
     t0 = time.perf_counter_ns(); job.rearm(N); t1 = time.perf_counter_ns(); job.report(); t2 = time.perf_counter_ns()
-    rearm.append(t1 - t0); tot.append(t2 - t1); wait.append(int(ws.meta[6])); tail.append(int(ws.meta[7]))
+    rearm.append(t1 - t0); tot.append(t2 - t1); wait.append(int(ws.meta[6])); tail.append(int(ws.meta[7]) & 0xFFFF)
 f = job.rings.lib.nvrx_abi_version
 empty = []
 for _ in range(2000):

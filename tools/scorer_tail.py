@@ -18,6 +18,6 @@ for tr in (8, 1):
     for _ in range(300):
         job.rearm(N)
         t0 = time.perf_counter_ns(); job.report(); tot.append(time.perf_counter_ns() - t0)
-        wait.append(int(ws.meta[6])); tail.append(int(ws.meta[7]))
+        wait.append(int(ws.meta[6])); tail.append(int(ws.meta[7]) & 0xFFFF)
     print(f"total_ranks={tr} resident={os.environ.get('NVRX_RESIDENT_SCORER','1')}: report {np.median(tot)/1e3:.2f} us | scorer waited for rows {np.median(wait)/100:.2f} us, last row -> completion store {np.median(tail)/100:.2f} us (p95 {np.percentile(tail,95)/100:.2f})", flush=True)
     job.close()
