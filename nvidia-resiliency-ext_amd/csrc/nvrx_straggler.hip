@@ -1637,14 +1637,12 @@ int score_fence_enabled() {
     return v;
 }
 
-// NVRX_RESIDENT_SCORER=0 keeps the score kernel behind the statistics kernel on the report's stream (A/B measurements).
-int resident_scorer_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("NVRX_RESIDENT_SCORER");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v;
+// NVRX_RESIDENT_SCORER: 0 = the score kernel always behind the statistics kernel on the report's stream, 2 = resident
+// whenever the shape allows it (A/B measurements), 1 / unset = the library decides (see nvrx_report).
+int resident_scorer_mode() {  // read per report (a getenv is nothing next to two launches): tests flip it
+    const char *e = getenv("NVRX_RESIDENT_SCORER");
+    const int v = e ? atoi(e) : 1;
+    return (v < 0 || v > 2) ? 1 : v;
 }
 
 // NVRX_PEER_PROLOGUE=0 keeps the peer-window exchange in its own kernel (A/B measurements).
@@ -1749,6 +1747,7 @@ struct nvrx_ctx {
     uint32_t *h_gather_err = nullptr, *d_gather_err = nullptr;  // pinned: epoch of a granule wait that gave up
     uint32_t gran_epoch = 0;
     int wall_khz = 100000;
+    int cu_count = 256;  // compute units of the device (a resident score kernel wants one to itself)
     hipEvent_t report_ev = nullptr;
     uint64_t report_epoch = 0;  // bumped by every guarded report
     struct StreamEpoch {
@@ -2068,6 +2067,8 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
             ctx->us_per_tick = 1000.0f / (float)khz;
             ctx->wall_khz = khz;
         }
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->cu_count = cus;
     }
     CTX_TRY(hipDeviceSynchronize());
 #undef CTX_TRY
@@ -2501,8 +2502,20 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     // Synchronous reports only, no exchange or the peer-window exchange (an RCCL all-gather needs the stream order).
     const int rows_launch = (d->rows_active > 0 ? d->rows_active : ctx->rows_per_rank) * ctx->local_ranks;
     const bool peer_route = exchanging && d->allgather_fn == reinterpret_cast<void *>(&nvrx_peer_allgather) && peer_prologue_enabled();
+    // When it pays (same-box A/B, r02k): a resident score kernel needs a CU of its own -- beside two row workgroups it
+    // slows exactly the rows everybody then waits for (512 rows on 256 CUs: 25.9 us per report resident, 24.4 queued) --
+    // and it must not have to be ordered after other streams' work (the event waits of a report behind a training
+    // step cost more than the kernel boundary they avoid: +74 vs +51 us per step).  With fewer rows than CUs and
+    // nothing to wait for it saves the boundary (64 rows: 21.2 vs 22.4 us).
+    bool cross_stream = d->order_after_enabled && d->order_after_stream != stream;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        cross_stream = cross_stream || !ctx->stamp_streams.empty();
+    }
+    const int rmode = resident_scorer_mode();
     const bool resident = d->resident && d->h_seq_word && !d->guard_rings && (!exchanging || peer_route) && rows_launch > 0 &&
-                          score_fits_single_wg(d->R, d->K, d->S, d->d_scores, d->d_flags) && resident_scorer_enabled();
+                          score_fits_single_wg(d->R, d->K, d->S, d->d_scores, d->d_flags) &&
+                          (rmode == 2 || (rmode == 1 && !cross_stream && rows_launch < ctx->cu_count));
     if (resident) {
         {
             std::lock_guard<std::mutex> lk(ctx->mu);

@@ -311,7 +311,7 @@ def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
         job.close()
 
 
-def test_resident_scorer_never_reads_a_stale_row():
+def test_resident_scorer_never_reads_a_stale_row(monkeypatch):
     """3000 one-call reports on one set of rings whose valid counts cycle through three values: every report's
     medians, scores and statistics must be the ones of ITS counts.  The score kernel is resident on its own stream and
     takes the rows' results from 8-byte {epoch, value} granules (two parities); a granule of an older report, a row
@@ -319,6 +319,7 @@ def test_resident_scorer_never_reads_a_stale_row():
     from nvrx_straggler import Statistic
     from nvrx_straggler.folded import FoldedJob
 
+    monkeypatch.setenv("NVRX_RESIDENT_SCORER", "2")  # resident whatever the library's own choice would be
     S, N, R = 6, 1000, 4
     names = [synth.section_name(s) for s in range(S)]
     job = FoldedJob(total_ranks=R, section_names=names, ring_cap=N, node_name="n")

@@ -37,7 +37,7 @@ def test_detector_name_change_midway_on_hip_backend(route):
     ``peer+resident``: the real Detector over peer windows with the resident score kernel forced on (its stream is
     ordered after the caller's stream, as in a one-process-per-GPU job)."""
     env = {} if route == "gloo" else {"NVRX_EXCHANGE": "peer", "NVRX_REPORT_TIMEOUT_S": "20", "NVRX_PEER_TRIAL_TIMEOUT_S": "5",
-                                      "NVRX_RESIDENT_SHARED_OK": "1"}
+                                      "NVRX_RESIDENT_SHARED_OK": "1", "NVRX_RESIDENT_SCORER": "2"}
     res = run_ranks(workers.detector_name_change_midway, 4, timeout=300, use_oracle_backend=False, device=0, env=env)
     ref = run_ranks(workers.detector_name_change_midway, 4, timeout=300)  # CPU checker backend, same protocol
     for r in range(4):
@@ -155,7 +155,7 @@ def test_config2_loop_over_peer_windows_with_the_resident_scorer():
     process slows processes that poll for each other); forced on here, two processes x 4 logical ranks."""
     g = load_golden("loop.json")
     res = run_ranks(workers.folded_loop_config2, 2, timeout=150, use_oracle_backend=False, device=0,
-                    env={**_PEER_ENV, "NVRX_RESIDENT_SHARED_OK": "1"}, asynchronous=False)
+                    env={**_PEER_ENV, "NVRX_RESIDENT_SHARED_OK": "1", "NVRX_RESIDENT_SCORER": "2"}, asynchronous=False)
     assert res[0]["route"].startswith("xGMI peer stores") and res[0]["fused"]
     for t, exp in enumerate(g["rank0_reports"]):
         got = res[0]["reports"][t]

@@ -11,9 +11,13 @@ timeout -s KILL 900 python -m pytest tests -m gpu -x -q --durations=10 > $O/pyte
 tail -15 $O/pytest.log
 timeout 600 python bench.py $B > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench.json; cat $O/bench.json
 timeout 120 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-# A/B on the same box: the score kernel behind the statistics kernel on one stream instead of resident on its own
-NVRX_RESIDENT_SCORER=0 timeout 300 python bench.py $B --no-cpu-baseline --no-overhead --no-host-inputs --no-extra-legs > $O/bench_nonresident.log 2>&1
-tail -1 $O/bench_nonresident.log > $O/bench_nonresident.json; cat $O/bench_nonresident.json
+# A/B on the same box: the score kernel always resident on a stream of its own (2) / always queued behind the statistics
+# kernel (0); the default run above lets the library choose per report
+for m in 2 0; do
+  n=$([ $m = 2 ] && echo resident || echo nonresident)
+  NVRX_RESIDENT_SCORER=$m timeout 300 python bench.py $B --no-cpu-baseline --no-host-inputs > $O/bench_$n.log 2>&1
+  tail -1 $O/bench_$n.log > $O/bench_$n.json; cat $O/bench_$n.json
+done
 # the multi-rank flow with ranks SHARING this GPU (gloo group; the report's exchange through IPC peer windows)
 for n in 2 4; do
   NVRX_EXCHANGE=peer NVRX_REPORT_TIMEOUT_S=30 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n \
