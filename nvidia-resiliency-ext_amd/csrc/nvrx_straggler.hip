@@ -1261,6 +1261,7 @@ struct GatherArgs {
     float names_ok;
     uint32_t epoch;
     unsigned long long timeout_ticks;
+    int poll_naps;  // s_sleep(1) units (64 clk each) between two polling passes
 };
 
 // One granule of this epoch (bounded wait; NaN + error word when the row never shows up).
@@ -1374,7 +1375,7 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
                     }
                 }
                 if (pending) {
-                    __builtin_amdgcn_s_sleep(1);
+                    for (int nap = 0; nap < ga.poll_naps; nap++) __builtin_amdgcn_s_sleep(1);
                     spins++;
                 }
             }
@@ -1747,7 +1748,6 @@ struct nvrx_ctx {
     uint32_t *h_gather_err = nullptr, *d_gather_err = nullptr;  // pinned: epoch of a granule wait that gave up
     uint32_t gran_epoch = 0;
     int wall_khz = 100000;
-    int cu_count = 256;  // compute units of the device (a resident score kernel wants one to itself)
     hipEvent_t report_ev = nullptr;
     uint64_t report_epoch = 0;  // bumped by every guarded report
     struct StreamEpoch {
@@ -2067,8 +2067,6 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
             ctx->us_per_tick = 1000.0f / (float)khz;
             ctx->wall_khz = khz;
         }
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->cu_count = cus;
     }
     CTX_TRY(hipDeviceSynchronize());
 #undef CTX_TRY
@@ -2502,11 +2500,11 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     // Synchronous reports only, no exchange or the peer-window exchange (an RCCL all-gather needs the stream order).
     const int rows_launch = (d->rows_active > 0 ? d->rows_active : ctx->rows_per_rank) * ctx->local_ranks;
     const bool peer_route = exchanging && d->allgather_fn == reinterpret_cast<void *>(&nvrx_peer_allgather) && peer_prologue_enabled();
-    // When it pays (same-box A/B, r02k): a resident score kernel needs a CU of its own -- beside two row workgroups it
-    // slows exactly the rows everybody then waits for (512 rows on 256 CUs: 25.9 us per report resident, 24.4 queued) --
-    // and it must not have to be ordered after other streams' work (the event waits of a report behind a training
-    // step cost more than the kernel boundary they avoid: +74 vs +51 us per step).  With fewer rows than CUs and
-    // nothing to wait for it saves the boundary (64 rows: 21.2 vs 22.4 us).
+    // When it pays (same-box A/B, r02k-m): the resident score kernel must not have to be ordered after other streams' work
+    // -- the event waits of a report behind a training step cost more than the kernel boundary they avoid (+74 vs +51 us
+    // per step with a report every step) -- so it is used when the report has nothing to wait for: 64 rows 21.2 vs 22.4
+    // us per report, 512 rows (two row workgroups on every CU, the score kernel squeezed in beside two of them) 24.2-25.9
+    // resident vs 24.0-24.4 queued depending on the box, with the statistics kernel itself at 8.5 instead of 9.9 us.
     bool cross_stream = d->order_after_enabled && d->order_after_stream != stream;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -2515,7 +2513,7 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     const int rmode = resident_scorer_mode();
     const bool resident = d->resident && d->h_seq_word && !d->guard_rings && (!exchanging || peer_route) && rows_launch > 0 &&
                           score_fits_single_wg(d->R, d->K, d->S, d->d_scores, d->d_flags) &&
-                          (rmode == 2 || (rmode == 1 && !cross_stream && rows_launch < ctx->cu_count));
+                          (rmode == 2 || (rmode == 1 && !cross_stream));
     if (resident) {
         {
             std::lock_guard<std::mutex> lk(ctx->mu);
@@ -2547,6 +2545,10 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         ga.names_ok = d->names_ok ? 1.0f : 0.0f;
         ga.epoch = ctx->gran_epoch;
         ga.timeout_ticks = (unsigned long long)((d->timeout_s > 0.0 ? d->timeout_s : 1e9) * 1e3 * (double)ctx->wall_khz);
+        {
+            const char *e = getenv("NVRX_POLL_NAPS");
+            ga.poll_naps = e ? std::max(1, atoi(e)) : 4;  // 4 x 64 clk between passes: same latency as 1, less issue pressure on the CU's rows
+        }
         PeerArgs pa{};
         if (peer_route) {
             rc2 = peer_fill_args(static_cast<nvrx_peer *>(d->comm), d->d_send, d->d_table, (size_t)d->send_count, &pa);
