@@ -32,9 +32,32 @@ def get_rank(group=None) -> int:
     return dist.get_rank(group) if _dist_ready() else 0
 
 
+_C10D_WORLD = getattr(getattr(dist, "distributed_c10d", None), "_world", None) if _DIST_AVAILABLE else None
+_WR_CACHE = [None, None, (1, 0)]  # default process group object, group asked about, (world size, rank)
+
+
 def world_and_rank(group=None):
-    """(world size, rank) of ``group`` with one initialisation check: the per-report lookup."""
-    if _DIST_AVAILABLE and dist.is_initialized():
+    """(world size, rank) of ``group``: the per-report lookup.  World size and rank of a group never change while
+    the default process group lives, so the answer is remembered per (default group object, group): a report pays one
+    attribute read instead of three c10d calls (~1 us)."""
+    if not _DIST_AVAILABLE:
+        return 1, 0
+    world = _C10D_WORLD
+    if world is not None:
+        try:
+            pg = world.default_pg
+        except Exception:  # noqa: BLE001  (a torch without this private handle: the plain calls below)
+            pg = False
+        if pg is None:
+            return 1, 0
+        if pg is not False:
+            cache = _WR_CACHE
+            if cache[0] is pg and cache[1] is group:
+                return cache[2]
+            res = (dist.get_world_size(group), dist.get_rank(group))
+            _WR_CACHE[:] = [pg, group, res]
+            return res
+    if dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)
     return 1, 0
 
