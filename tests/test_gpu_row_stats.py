@@ -110,9 +110,19 @@ def test_random_rows_every_launch_shape(be, stride):
     m[4] = 42.0  # all equal
     m[5, ::7] *= 1e4  # outliers stretch the key range
     m[6] = -m[6]  # negative values order correctly
+    # rows whose keys are the raw bit patterns until a set sign bit shows up somewhere (cold re-keying path): mixed signs
+    # with -0.0, and ONE negative sample at the very end of an otherwise positive row (tile 0 sees none)
+    m[9] = rng.normal(0.5, 1.0, stride).astype(np.float32)  # (mean well away from 0: AVG is compared relatively)
+    m[9, stride // 2] = -0.0
+    m[10, -1] = -m[10, -1]
+    # ~100 / ~400 distinct values: the median's bin holds many EQUAL members (ranking by all waves; lanes holding three
+    # or more members of the bin: the key-by-key listing)
+    m[11] = 10.0 + 0.01 * rng.integers(0, 100, stride)
+    m[12] = 10.0 + 0.001 * rng.integers(0, 400, stride)
     counts = rng.integers(0, stride + 1, rows).astype(np.uint32)
     counts[:8] = [stride, max(stride - 1, 0), 1, stride, stride, stride, stride, 2]
     counts[8] = 0
+    counts[9:13] = [stride, stride, stride, max(stride - 3, 1)]
     kinds = (np.arange(rows) % 2).astype(np.uint8)
     got = _run(be, m, counts, kinds)
     _check_against_oracle(got, m, counts, kinds, f"stride{stride}")
