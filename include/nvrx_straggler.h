@@ -226,7 +226,8 @@ typedef struct nvrx_report_desc {
     int32_t resident;         /* nonzero: the library may run the score kernel RESIDENT on a stream of its own next to the
                                  statistics kernel (rows handed over as 8-byte tagged granules instead of through the
                                  stream order); used for synchronous reports without an exchange or with the peer-window
-                                 exchange.  The statistics rows then land under their own completion word d_meta[5]. */
+                                 exchange that have no other stream's work to wait for (NVRX_RESIDENT_SCORER=0|1|2: never /
+                                 that rule / always).  The statistics rows then land under their own completion word d_meta[5]. */
     int32_t reserved;
     int32_t guard_rings;      /* asynchronous reports (h_seq_word == NULL, the caller polls later): nonzero makes later
                                  device-side ring writers on other streams (nvrx_stamp_end) wait, on the device, for this
