@@ -508,6 +508,27 @@ def test_report_generator_matches_reference_on_gloo_ranks(idx):
         assert res[r]["ids"] == g["per_rank"][r]["ids"], (sc["name"], r)
 
 
+def test_world_and_rank_is_remembered_per_default_process_group():
+    """The per-report (world, rank) lookup is cached per default process group OBJECT: tearing the group down and
+    bringing a new one up (elastic restarts do) must not leave a stale answer behind."""
+    import torch.distributed as dist
+
+    from nvrx_straggler import dist_utils
+
+    assert not dist.is_initialized() and dist_utils.world_and_rank() == (1, 0)
+    for _ in range(2):
+        dist.init_process_group("gloo", rank=0, world_size=1, store=dist.HashStore())
+        try:
+            assert dist_utils.world_and_rank() == (1, 0)
+            assert dist_utils._WR_CACHE[0] is dist.distributed_c10d._world.default_pg
+            sub = dist.new_group([0])
+            assert dist_utils.world_and_rank(sub) == (1, 0) and dist_utils._WR_CACHE[1] is sub
+            assert dist_utils.world_and_rank() == (1, 0) and dist_utils._WR_CACHE[1] is None
+        finally:
+            dist.destroy_process_group()
+        assert dist_utils.world_and_rank() == (1, 0)
+
+
 def test_all_gather_object_only_when_names_change():
     counts = run_ranks(workers.gather_object_call_counts, 2, n_kernels=256)
     assert counts[0] == [2, 0, 1, 0, 1] and counts[1] == [2, 0, 1, 0, 1]
