@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import collections
 import dataclasses
+import itertools
 import os
 import threading
 import time
@@ -32,7 +33,7 @@ import numpy as np
 from . import backend as _backend_mod
 from . import dist_utils
 from .name_mapper import NameMapper
-from .statistics import STAT_COLUMNS, Statistic
+from .statistics import NUM_COLUMN, STAT_KEYS, Statistic
 
 _SummaryType = Mapping[Statistic, float]
 
@@ -50,15 +51,27 @@ class StragglerId:
 # --------------------------------------------------------------------------------------------------
 # Report: a frozen record of plain dicts, some of them built on first read
 # --------------------------------------------------------------------------------------------------
-def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray) -> Dict[str, Dict[Statistic, Any]]:
+def _row_selector(rows: Mapping[str, int]):
+    """How to cut ``rows``' statistics out of the block: a slice when the rows are consecutive (ring rows are handed
+    out in order of first use, so they nearly always are), else an index array."""
+    idx = list(rows.values())
+    if idx and idx == list(range(idx[0], idx[0] + len(idx))):
+        return slice(idx[0], idx[0] + len(idx))
+    return np.asarray(idx, dtype=np.intp)
+
+
+def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray, selector=None) -> Dict[str, Dict[Statistic, Any]]:
     """``name -> {Statistic: value}`` from device statistics rows (``_get_section_summaries``' result shape,
-    straggler.py:185-195)."""
-    out: Dict[str, Dict[Statistic, Any]] = {}
-    for name, row in rows.items():
-        vals = stats[row].tolist()
-        d: Dict[Statistic, Any] = {stat: vals[col] for stat, col in STAT_COLUMNS}
-        d[Statistic.NUM] = int(vals[5])
-        out[name] = d
+    straggler.py:185-195).  One C-level conversion of the whole block, one ``dict(zip(keys, row))`` per name (all C;
+    ``Statistic`` hashes by identity), NUM turned into an integer as in the reference (straggler.py:194)."""
+    if not rows:
+        return {}
+    block = stats[_row_selector(rows) if selector is None else selector]
+    vals = block[:, : NUM_COLUMN + 1].tolist()
+    out = dict(zip(rows, map(dict, map(zip, itertools.repeat(STAT_KEYS), vals))))
+    num = Statistic.NUM
+    for d, n in zip(out.values(), block[:, NUM_COLUMN].astype(np.int64).tolist()):
+        d[num] = n
     return out
 
 
@@ -129,7 +142,53 @@ class _View:
     """What all reports of one plan share (immutable once built): table shape, rank / name tables, which score families
     exist, where this report's rows sit in the result block, the thresholds the score kernel flagged with."""
 
-    __slots__ = ("S", "ranks", "names", "cols", "has_rel", "has_indiv", "section_rows", "kernel_rows", "layout", "thresholds")
+    __slots__ = ("S", "ranks", "names", "cols", "has_rel", "has_indiv", "section_rows", "kernel_rows", "layout", "thresholds",
+                 "_rank_list", "_col_index", "_selectors", "_ids", "_memo")
+
+    def memo(self) -> dict:
+        try:
+            return self._memo
+        except AttributeError:
+            self._memo = {}
+            return self._memo
+
+    def rank_list(self) -> list:
+        try:
+            return self._rank_list
+        except AttributeError:
+            self._rank_list = list(self.ranks)
+            return self._rank_list
+
+    def col_index(self):
+        """Score-table column of every name of ``names``, in that order (None: the identity)."""
+        try:
+            return self._col_index
+        except AttributeError:
+            idx = [self.cols[n] for n in self.names]
+            self._col_index = None if idx == list(range(self.S)) else np.asarray(idx, dtype=np.intp)
+            return self._col_index
+
+    def selector(self, which: str):
+        try:
+            sel = self._selectors
+        except AttributeError:
+            sel = self._selectors = {}
+        if which not in sel:
+            sel[which] = _row_selector(getattr(self, which))
+        return sel[which]
+
+    def straggler_ids(self, rank_to_node) -> list:
+        """``StragglerId`` of every row of this view's score table (built once per ``rank_to_node`` object: the
+        generator hands the same dict to every report of a plan)."""
+        try:
+            owner, ids = self._ids
+            if owner is rank_to_node:
+                return ids
+        except AttributeError:
+            pass
+        ids = [StragglerId(rank=r, node=rank_to_node[r]) for r in self.ranks]
+        self._ids = (rank_to_node, ids)
+        return ids
 
 
 class _ScoreSource:
@@ -190,16 +249,20 @@ class _ScoreSource:
         if field == "section_individual_perf_scores":
             return self._sections(2) if (v.has_indiv and v.names) else {}
         if field == "local_section_summaries":
-            return _summaries_from_rows(v.section_rows, self.statistics())
+            return _summaries_from_rows(v.section_rows, self.statistics(), v.selector("section_rows")) if v.section_rows else {}
         if field == "local_kernel_summaries":
-            return _summaries_from_rows(v.kernel_rows, self.statistics())
+            return _summaries_from_rows(v.kernel_rows, self.statistics(), v.selector("kernel_rows")) if v.kernel_rows else {}
         raise AttributeError(field)
 
     def _sections(self, first_col: int) -> Dict[str, Dict[int, float]]:
+        """``section -> {rank: score}``: one C-level conversion of the [S, ranks] block, one ``dict(zip(...))`` per
+        section (reporting.py:196-217 builds the same shape score by score)."""
         v = self.view
-        ranks, cols = v.ranks, v.cols
-        by_col = self.scores[:, first_col : first_col + v.S].T.tolist()  # one C-level conversion
-        return {name: dict(zip(ranks, by_col[cols[name]])) for name in v.names}
+        block = self.scores[:, first_col : first_col + v.S].T
+        idx = v.col_index()
+        if idx is not None:
+            block = block[idx]
+        return dict(zip(v.names, map(dict, map(zip, itertools.repeat(v.rank_list()), block.tolist()))))
 
 
 _LAZY_FIELDS = frozenset((
@@ -317,7 +380,12 @@ class Report:
             gpu_rel_threshold, section_rel_threshold, gpu_indiv_threshold, section_indiv_threshold
         ):
             # thresholds equal the ones the score kernel was launched with: use its flag bytes
-            gr, gi, sr, si = flags.decode()
+            src = self.__dict__.get("_src")
+            ids = src.view.straggler_ids(self.rank_to_node) if src is not None else None
+            gr, gi, sr, si = flags.decode(ids, src.view.memo() if src is not None else None)
+            if ids is not None:
+                return {"straggler_gpus_relative": gr, "straggler_gpus_individual": gi,
+                        "straggler_sections_relative": sr, "straggler_sections_individual": si}
         else:
             gr = self._below(self.gpu_relative_perf_scores, gpu_rel_threshold)
             gi = self._below(self.gpu_individual_perf_scores, gpu_indiv_threshold)
@@ -365,18 +433,47 @@ class _DeviceFlags:
     def matches(self, gpu_rel, sec_rel, gpu_indiv, sec_indiv) -> bool:
         return (float(gpu_rel), float(sec_rel), float(gpu_indiv), float(sec_indiv)) == self.thresholds
 
-    def _ranks_of(self, column: np.ndarray) -> List[int]:
-        return [self.ranks[int(i)] for i in np.nonzero(column)[0]]
-
-    def decode(self):
+    def decode(self, ids=None, memo=None):
+        """Flagged rows per score family: ``(gpu_rel, gpu_indiv, section_rel, section_indiv)``.  With ``ids`` (one
+        ``StragglerId`` per row of the table) the results are the sets ``identify_stragglers`` returns; without, lists
+        of ranks.  One ``any()`` in the common case (nothing flagged).  Otherwise per-column counts and first flagged
+        rows come from two reductions over the table and only flagged columns are visited.  ``memo`` (a dict shared by
+        the reports of one plan): a straggler usually stays one for many reports, so the result for an unchanged flag
+        table is kept and handed out as fresh copies (a set copy does not re-hash its members)."""
         f, S = self._array(), self.S
-        gi = self._ranks_of(f[:, 0]) if self.has_indiv else []
-        gr = self._ranks_of(f[:, 1]) if self.has_rel else []
-        if not f[:, 2:].any():  # the common case: no section of any rank is flagged
-            return gr, gi, {}, {}
-        cols = self.cols
-        si = {n: self._ranks_of(f[:, 2 + cols[n]]) for n in self.names} if self.has_indiv else {}
-        sr = {n: self._ranks_of(f[:, 2 + S + cols[n]]) for n in self.names} if self.has_rel else {}
+        wrap = set if ids is not None else list
+        if not np.count_nonzero(f):  # (a plain C loop: a third of the cost of the ufunc reduction behind f.any())
+            return wrap(), wrap(), {}, {}
+        key = None
+        if memo is not None and ids is not None:
+            key = f.tobytes()
+            hit = memo.get("flags")
+            if hit is not None and hit[0] == key and hit[1] is ids:
+                gr, gi, sr, si = hit[2]
+                return gr.copy(), gi.copy(), {n: v.copy() for n, v in sr.items()}, {n: v.copy() for n, v in si.items()}
+        who = ids if ids is not None else self.ranks
+        cnt = f.sum(axis=0, dtype=np.int32).tolist()
+        first = f.argmax(axis=0).tolist()
+
+        def members(c):
+            if cnt[c] == 1:
+                return wrap((who[first[c]],))
+            return wrap(who[int(r)] for r in np.flatnonzero(f[:, c]))
+
+        gi = members(0) if (self.has_indiv and cnt[0]) else wrap()
+        gr = members(1) if (self.has_rel and cnt[1]) else wrap()
+        si: Dict[str, Any] = {}
+        sr: Dict[str, Any] = {}
+        if any(cnt[2:]):
+            cols = self.cols
+            # the report's own section order, as the reference's walk over its score dicts gives it
+            if self.has_indiv:
+                si = {n: members(2 + cols[n]) for n in self.names if cnt[2 + cols[n]]}
+            if self.has_rel:
+                sr = {n: members(2 + S + cols[n]) for n in self.names if cnt[2 + S + cols[n]]}
+        if key is not None:
+            memo["flags"] = (key, ids, (gr.copy(), gi.copy(), {n: v.copy() for n, v in sr.items()},
+                                        {n: v.copy() for n, v in si.items()}))
         return gr, gi, sr, si
 
 

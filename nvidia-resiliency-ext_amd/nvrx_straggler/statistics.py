@@ -11,6 +11,11 @@ class Statistic(enum.Enum):
     STD = enum.auto()
     NUM = enum.auto()
 
+    # Members are singletons compared by identity, so the identity hash is consistent with ``==`` -- and it is a C
+    # slot: ``Enum.__hash__`` is a Python-level ``hash(self._name_)``, paid once per key of every summary dict a
+    # report builds (64 sections x 6 statistics per report).
+    __hash__ = object.__hash__
+
     def __str__(self) -> str:
         return self.name
 
@@ -27,3 +32,7 @@ STAT_COLUMNS = (
     (Statistic.STD, 4),
     (Statistic.NUM, 5),
 )
+
+#: the six keys in column order, and the column of NUM (an integer in the reference's summaries, straggler.py:194)
+STAT_KEYS = tuple(stat for stat, _ in STAT_COLUMNS)
+NUM_COLUMN = 5
