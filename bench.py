@@ -11,8 +11,14 @@ all-gather of the exchange rows (RCCL when N>1) -> score kernel -> one D2H of th
 waits.  Inputs are resident in HBM before the timed region starts.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W          (no launcher: spawns its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+`value` is the time from calling generate_report() to holding the flagged-straggler set: every timed step keeps its
+Report and calls identify_stragglers() on it (rank 0), which waits for and copies the scores / flags out of the result
+block; `report_read` adds what building the six dict mappings of that report costs on the host, and
+`us_per_report_fully_read` is the sum (the reference's generate_report returns populated dicts, reporting.py:535-545).
 
 Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
   roofline     -- the statistics kernel (k_row_stats) against the HBM roofline: algorithmic bytes =
@@ -161,6 +167,8 @@ def _per_step_overhead(world: int, rank: int, steps: int, blocks: int, asynchron
                 prev, held[0] = held[0], rep
                 if prev is not None:
                     prev.identify_stragglers()
+            elif rep is not None:
+                rep.identify_stragglers()
             return rep
 
         for _ in range(10):
@@ -198,6 +206,88 @@ def _per_step_overhead(world: int, rank: int, steps: int, blocks: int, asynchron
                     + (", asynchronous=True: report t is enqueued at step t and read (identify_stragglers) during step t+1"
                        if asynchronous else ""),
     }
+
+
+def _cadence_leg(reports: int, job=None):
+    """Reports at the cadence production uses (S/straggler.py:125 reports every ~60 s; BASELINE config #2: one report
+    per 100 training steps): between two reports the GPU runs 100 steps of 10 x matmul(4096^2, bf16), so every report
+    meets an idle detector stream and caches / TLBs / kernarg lines that the training work has evicted.  Each report
+    is timed on its own, call -> flagged set in hand, after the step's own device synchronisation (a training loop
+    that logs its loss has one; without it the figure would be the GPU's backlog, not the report).
+
+    ``job`` None: the real ``Detector`` with config #2's four sections (two of them GPU-timed), synchronous and
+    asynchronous.  ``job`` given: the headline workload (8 x 64 x 10 000 resident samples) reported at that cadence."""
+    from nvrx_straggler import Detector
+
+    x = torch.randn(4096, 4096, dtype=torch.bfloat16, device="cuda")
+
+    def work(n):
+        y = x
+        for _ in range(n):
+            y = torch.matmul(x, y)
+        return y
+
+    def summary(t):
+        a = np.asarray(t, dtype=np.float64) / 1e3
+        return {"us_median": round(float(np.median(a)), 2), "us_p95": round(float(np.percentile(a, 95)), 2),
+                "us_mean": round(float(a.mean()), 2), "us_max": round(float(a.max()), 2), "reports": len(t)}
+
+    if job is not None:
+        t = []
+        for i in range(reports + 2):
+            for _ in range(100):
+                work(10)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter_ns()
+            job.rearm(SAMPLES)
+            job.report().identify_stragglers()
+            if i >= 2:
+                t.append(time.perf_counter_ns() - t0)
+        out = summary(t)
+        out["workload"] = (f"the headline report ({TOTAL_RANKS} x {SECTIONS} x {SAMPLES} resident samples) once per 100 steps of "
+                           "10 x matmul(4096^2, bf16); each report timed alone, call -> flagged set")
+        return out
+
+    out = {}
+    for asynchronous in (False, True):
+        Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="node0", asynchronous=asynchronous)
+        try:
+            t, t_late = [], []
+            held = None
+            for i in range(reports + 2):
+                for _ in range(100):
+                    with Detector.detection_section("data", profile_cuda=False):
+                        pass
+                    with Detector.detection_section("forward", profile_cuda=True):
+                        work(4)
+                    with Detector.detection_section("backward", profile_cuda=True):
+                        work(6)
+                    with Detector.detection_section("optimizer", profile_cuda=False):
+                        pass
+                torch.cuda.synchronize()
+                t0 = time.perf_counter_ns()
+                rep = Detector.generate_report()
+                if not asynchronous:
+                    rep.identify_stragglers()
+                t1 = time.perf_counter_ns()
+                if asynchronous and held is not None:
+                    held.identify_stragglers()  # the previous report, read 100 steps after it was enqueued
+                t2 = time.perf_counter_ns()
+                held = rep
+                if i >= 2:
+                    t.append(t1 - t0)
+                    t_late.append(t2 - t1)
+            key = "asynchronous" if asynchronous else "synchronous"
+            out[key] = summary(t)
+            if asynchronous:
+                out[key]["read_one_interval_later_us_median"] = round(float(np.median(t_late)) / 1e3, 2)
+        finally:
+            Detector.shutdown()
+    out["workload"] = ("Detector with 4 sections per step (2 GPU-timed), 100 steps of 10 x matmul(4096^2, bf16) between reports "
+                       "(BASELINE config #2 cadence); each generate_report() timed alone after the step's device "
+                       "synchronisation: synchronous = call -> identify_stragglers() returned; asynchronous = the enqueue, "
+                       "the report is read at the next report")
+    return out
 
 
 def _kernel_source_sha() -> str:
@@ -255,21 +345,23 @@ def _n8_shape_leg(steps, warmup):
                     node_name="node0")
     try:
         job.load(0, synth.stress_samples(0, SECTIONS, SAMPLES))
+        gc.collect()  # before the warm-up, never between it and the timed region (see main)
         for _ in range(warmup):
             job.rearm(SAMPLES)
-            job.report()
-        gc.collect()
+            job.report().identify_stragglers()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t = []
         for _ in range(steps):
+            t0 = time.perf_counter_ns()
             job.rearm(SAMPLES)
-            job.report()
+            job.report().identify_stragglers()  # held and read, as in the headline loop
+            t.append(time.perf_counter_ns() - t0)
         torch.cuda.synchronize()
-        us = (time.perf_counter() - t0) / steps * 1e6
+        us = float(np.mean(t)) / 1e3
         kern_us, launches = _kernel_leg(job, steps, SAMPLES)
         alg = SECTIONS * SAMPLES * 4
         out = {"workload": f"1 rank x {SECTIONS} sections x {SAMPLES} samples (what ONE GPU holds at 8 GPUs), no exchange",
-               "report_us": round(us, 2), "bound": "hbm", "kernel": "k_row_stats", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "report_us": round(us, 2), "report_us_median": round(float(np.median(t)) / 1e3, 2), "bound": "hbm", "kernel": "k_row_stats", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "algorithmic_bytes_per_launch": alg, "launches_timed": launches, "traffic": _pmc_traffic(SECTIONS)}
         out.update(_roof(kern_us, alg))
         return out
@@ -302,7 +394,7 @@ def _detector_leg(steps, warmup):
         def step():
             for row in range(rings.rows_used):
                 rings.set_count(row, SAMPLES)
-            return Detector.generate_report()
+            return Detector.generate_report().identify_stragglers()
 
         for _ in range(warmup):
             step()
@@ -311,14 +403,50 @@ def _detector_leg(steps, warmup):
             for row in range(rings.rows_used):
                 rings.set_count(row, SAMPLES)
             t0 = time.perf_counter()
-            Detector.generate_report()
+            Detector.generate_report().identify_stragglers()
             t.append(time.perf_counter() - t0)
         return {"us_median": round(float(np.median(t)) * 1e6, 2), "us_p95": round(float(np.percentile(t, 95)) * 1e6, 2),
-                "workload": f"Detector.generate_report() incl. harvest / occupancy check / ring reset, 1 rank x {SECTIONS} "
+                "workload": f"Detector.generate_report() + identify_stragglers() incl. harvest / occupancy check / ring reset, 1 rank x {SECTIONS} "
                             f"sections x {SAMPLES} resident samples, relative+individual scores"}
     finally:
         Detector.shutdown()
         CustomSection.max_elapseds_len = old_cap
+
+
+def _self_launch(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N copies of this command, one rank each, with the
+    environment torch.distributed.run would give them (rendezvous on 127.0.0.1, a free port).  Rank 0 prints the JSON
+    line; the first failing rank ends the run (its exact PIDs are killed, nothing is matched by pattern)."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NVRX_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("NVRX_BENCH_TIMEOUT_S", "1500"))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if rc != 0 or time.time() > deadline:
+            for p in live:
+                p.kill()
+            for p in live:
+                p.wait()
+            return rc or 124
+        time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -335,14 +463,24 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the N=8-shape, cold-cache and Detector-level legs")
     ap.add_argument("--overhead-steps", type=int, default=100)
     ap.add_argument("--overhead-blocks", type=int, default=5)
+    ap.add_argument("--no-cadence", action="store_true", help="skip the production-cadence leg (one report per 100 training steps)")
+    ap.add_argument("--cadence-reports", type=int, default=30)
+    ap.add_argument("--dump-steps", action="store_true", help="add the per-step latencies of the timed region to the JSON line")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if TOTAL_RANKS % args.gpus:
+            raise SystemExit(f"--gpus must divide {TOTAL_RANKS}")
+        if args.backend == "nccl" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} with RCCL needs {args.gpus} visible GPUs, found {torch.cuda.device_count()} "
+                             "(RCCL refuses two ranks on one device; --backend gloo lets ranks share a GPU)")
+        raise SystemExit(_self_launch(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if TOTAL_RANKS % world:
         raise SystemExit(f"--gpus must divide {TOTAL_RANKS}")
     device_index = local_rank % max(torch.cuda.device_count(), 1)  # == local_rank on a node with one GPU per rank
@@ -363,8 +501,11 @@ def main():
     torch.cuda.synchronize()
 
     def step():
+        # the report is held and its flagged-straggler set read (rank 0 under gather_on_rank0; the others get None):
+        # identify_stragglers() waits for / copies the scores and flags out of the result block
         job.rearm(SAMPLES)
-        return job.report()
+        rep = job.report()
+        return rep, (rep.identify_stragglers() if rep is not None else None)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -372,26 +513,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    rep = None
-    for _ in range(args.warmup):
-        rep = step()
-    # correctness guard inside the bench: flagged set of the x1.5 rank at the default threshold
-    if rank == 0:
-        flagged = rep.identify_stragglers()["straggler_sections_relative"]
+    def check_flagged(found):
+        # correctness guard inside the bench: flagged set of the x1.5 rank at the default threshold
+        flagged = found["straggler_sections_relative"]
         assert len(flagged) == SECTIONS and all({s.rank for s in v} == {3} for v in flagged.values()), "wrong flagged set"
 
-    # one full collection now, so that the cyclic collector's generation-2 pass (tens of ms with torch imported) does
-    # not land inside the 200 timed steps by accident of allocation counts; the collector stays enabled
+    # One full collection BEFORE the warm-up, and what survives it is moved out of the collector's sight: a generation-2
+    # pass of Python's cyclic collector (45-70 ms with torch imported) otherwise lands inside some leg by accident of
+    # allocation counts and reads as +200 us per report.  It must not sit between the warm-up and the timed region: the
+    # collection walks every object of the process and leaves the host's caches cold, and the first report after it
+    # took 85-110 us + 50 us for the read instead of 25 + 9 (tools/outlier_probe.py, profiles/r03a_outlier_probe.txt) --
+    # that was the one ~175 us step of r02's 20-step driver run.  The collector stays enabled.
     gc.collect()
+    gc.freeze()
+    rep = found = None
+    for _ in range(max(args.warmup, 1)):
+        rep, found = step()
+    if rank == 0:
+        check_flagged(found)
     sync_all()
     per_step = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts = time.perf_counter_ns()
-        step()
+        rep, found = step()
         per_step.append(time.perf_counter_ns() - ts)
     sync_all()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        check_flagged(found)  # the last timed report
+
+    # what READING the rest of a report costs on the host (rank 0): the six dict mappings, built on first access
+    report_read = None
+    if rank == 0:
+        t_ident, t_maps = [], []
+        for _ in range(min(args.steps, 50)):
+            job.rearm(SAMPLES)
+            r = job.report()
+            ta = time.perf_counter_ns()
+            r.identify_stragglers()
+            tb = time.perf_counter_ns()
+            for f in ("gpu_relative_perf_scores", "section_relative_perf_scores", "gpu_individual_perf_scores",
+                      "section_individual_perf_scores", "local_section_summaries", "local_kernel_summaries"):
+                getattr(r, f)
+            tc = time.perf_counter_ns()
+            t_ident.append(tb - ta)
+            t_maps.append(tc - tb)
+        report_read = {"identify_stragglers_us": round(float(np.median(t_ident)) / 1e3, 2),
+                       "all_six_mappings_us": round(float(np.median(t_maps)) / 1e3, 2),
+                       "note": "host cost of reading one report: identify_stragglers() at the default thresholds (flag bytes "
+                               "of the score kernel; part of `value`) and building the six dict mappings "
+                               f"({TOTAL_RANKS} ranks x {SECTIONS} sections of scores x 2 families, {SECTIONS} x 6 local "
+                               "statistics; not part of `value`)"}
+    elif world > 1:
+        for _ in range(min(args.steps, 50)):  # collective: the other ranks take part in rank 0's reports
+            job.rearm(SAMPLES)
+            job.report()
 
     # instrumented pass: hipEvent pair around every statistics-kernel launch, on its launch stream
     job.rings.timing_enable(True)
@@ -462,6 +639,12 @@ def main():
         host_inputs = {"us_per_report": round(us, 1), "host_bytes": nbytes, "gb_per_s": round(nbytes / us / 1e3, 2),
                        "note": "samples start in pageable host memory; H2D + ring appends + report; not the headline value"}
 
+    cadence = None
+    if world == 1 and not args.no_cadence:
+        cadence = {"headline_workload": _cadence_leg(args.cadence_reports, job)}
+        job.backend.synchronize()
+        cadence.update(_cadence_leg(args.cadence_reports))
+
     overhead = overhead_async = None
     if not args.no_overhead:
         job.backend.synchronize()
@@ -531,6 +714,14 @@ def main():
                         "granules; queued behind it (or behind an RCCL exchange) the first figure is ~0 and the second "
                         "is the kernel's whole body",
             }
+        if report_read is not None:
+            fully = us_per_report + report_read["all_six_mappings_us"]
+            out["report_read"] = report_read
+            out["us_per_report_fully_read"] = round(fully, 2)
+        if args.dump_steps:
+            out["per_step_us"] = [round(v / 1e3, 2) for v in per_step]
+        if cadence is not None:
+            out["report_at_cadence"] = cadence
         if cold is not None:
             out["roofline"]["cold"] = cold
         if n8 is not None:

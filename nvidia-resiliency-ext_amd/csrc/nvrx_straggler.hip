@@ -1629,21 +1629,39 @@ int score_single_wg_enabled() {
     }
     return v;
 }
+// The fence-free publication of k_score1 (write-through stores drained per wave, a barrier, then the sequence word)
+// leans on how gfx942 / gfx950 map pinned host memory (uncached, posted PCIe writes of one requester kept in order),
+// not on the HIP memory model: it is used on exactly those two architectures, every other device gets the
+// system-scope release fence in front of the completion word.  NVRX_SCORE_FENCE=0|1 overrides the detection.
 int score_fence_enabled() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("NVRX_SCORE_FENCE");
-        v = (e && atoi(e) != 0) ? 1 : 0;
+        if (e && *e) {
+            v = atoi(e) != 0 ? 1 : 0;
+        } else {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            v = 1;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                (strncmp(prop.gcnArchName, "gfx950", 6) == 0 || strncmp(prop.gcnArchName, "gfx942", 6) == 0))
+                v = 0;
+        }
     }
     return v;
 }
 
 // NVRX_RESIDENT_SCORER: 0 = the score kernel always behind the statistics kernel on the report's stream, 2 = resident
-// whenever the shape allows it (A/B measurements), 1 / unset = the library decides (see nvrx_report).
-int resident_scorer_mode() {  // read per report (a getenv is nothing next to two launches): tests flip it
+// whenever the shape allows it (A/B measurements), 1 / unset = the library decides (see nvrx_report).  Read once per
+// context (nvrx_ctx_create), like NVRX_POLL_NAPS: a report does not call getenv.
+int resident_scorer_mode_from_env() {
     const char *e = getenv("NVRX_RESIDENT_SCORER");
     const int v = e ? atoi(e) : 1;
     return (v < 0 || v > 2) ? 1 : v;
+}
+int poll_naps_from_env() {
+    const char *e = getenv("NVRX_POLL_NAPS");
+    return e ? std::max(1, atoi(e)) : 4;  // 4 x 64 clk between passes: same latency as 1, less issue pressure on the CU's rows
 }
 
 // NVRX_PEER_PROLOGUE=0 keeps the peer-window exchange in its own kernel (A/B measurements).
@@ -1748,6 +1766,8 @@ struct nvrx_ctx {
     uint32_t *h_gather_err = nullptr, *d_gather_err = nullptr;  // pinned: epoch of a granule wait that gave up
     uint32_t gran_epoch = 0;
     int wall_khz = 100000;
+    int resident_mode = 1;  // NVRX_RESIDENT_SCORER / NVRX_POLL_NAPS as they stood when the context was created
+    int poll_naps = 4;
     hipEvent_t report_ev = nullptr;
     uint64_t report_epoch = 0;  // bumped by every guarded report
     struct StreamEpoch {
@@ -2013,6 +2033,8 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     ctx->row_stride = (ring_cap + 3) & ~3;
     ctx->stage_cap = std::min(4096, ring_cap);
     ctx->total.assign((size_t)ctx->rows, 0);
+    ctx->resident_mode = resident_scorer_mode_from_env();
+    ctx->poll_naps = poll_naps_from_env();
 
 #define CTX_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -2510,7 +2532,7 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         cross_stream = cross_stream || !ctx->stamp_streams.empty();
     }
-    const int rmode = resident_scorer_mode();
+    const int rmode = ctx->resident_mode;
     const bool resident = d->resident && d->h_seq_word && !d->guard_rings && (!exchanging || peer_route) && rows_launch > 0 &&
                           score_fits_single_wg(d->R, d->K, d->S, d->d_scores, d->d_flags) &&
                           (rmode == 2 || (rmode == 1 && !cross_stream));
@@ -2545,10 +2567,7 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         ga.names_ok = d->names_ok ? 1.0f : 0.0f;
         ga.epoch = ctx->gran_epoch;
         ga.timeout_ticks = (unsigned long long)((d->timeout_s > 0.0 ? d->timeout_s : 1e9) * 1e3 * (double)ctx->wall_khz);
-        {
-            const char *e = getenv("NVRX_POLL_NAPS");
-            ga.poll_naps = e ? std::max(1, atoi(e)) : 4;  // 4 x 64 clk between passes: same latency as 1, less issue pressure on the CU's rows
-        }
+        ga.poll_naps = ctx->poll_naps;
         PeerArgs pa{};
         if (peer_route) {
             rc2 = peer_fill_args(static_cast<nvrx_peer *>(d->comm), d->d_send, d->d_table, (size_t)d->send_count, &pa);

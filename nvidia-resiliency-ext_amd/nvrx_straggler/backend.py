@@ -77,6 +77,11 @@ def get_backend():
     return _backend
 
 
+def _nobody():
+    """A dead weak reference."""
+    return None
+
+
 def _align(n: int, a: int = 64) -> int:
     return (n + a - 1) // a * a
 
@@ -158,6 +163,12 @@ class Workspace:
         """``live`` (reporting._LiveBlock) reads this block lazily; ``settle()`` collects it before any reuse."""
         self._live = weakref.ref(live)
         self._live_seq = live.seq
+
+    def mark_live(self, seq: int) -> None:
+        """A one-call report with sequence number ``seq`` ran on this block and nobody may be holding it (a rank that
+        returns ``None``, a report abandoned for a name sync): ``settle()`` still has to see its statistics rows land."""
+        self._live = _nobody
+        self._live_seq = seq
 
     def settle(self) -> None:
         """Called before anything is enqueued that writes this workspace: the previous report's statistics rows must

@@ -33,13 +33,16 @@ def get_rank(group=None) -> int:
 
 
 _C10D_WORLD = getattr(getattr(dist, "distributed_c10d", None), "_world", None) if _DIST_AVAILABLE else None
-_WR_CACHE = [None, None, (1, 0)]  # default process group object, group asked about, (world size, rank)
+_WR_CACHE = [None]  # fallback cache of callers that bring none: ONE immutable (default group, group, (world, rank)) tuple
 
 
-def world_and_rank(group=None):
+def world_and_rank(group=None, cache=None):
     """(world size, rank) of ``group``: the per-report lookup.  World size and rank of a group never change while
     the default process group lives, so the answer is remembered per (default group object, group): a report pays one
-    attribute read instead of three c10d calls (~1 us)."""
+    attribute read instead of three c10d calls (~1 us).  ``cache`` is a one-element list owned by the caller (every
+    ``ReportGenerator`` has its own, so two generators on different groups or threads never see each other's entry);
+    the entry is ONE immutable tuple, read once and compared by identity, so a concurrent writer can only make a
+    reader miss, never hand it another group's answer."""
     if not _DIST_AVAILABLE:
         return 1, 0
     world = _C10D_WORLD
@@ -49,13 +52,17 @@ def world_and_rank(group=None):
         except Exception:  # noqa: BLE001  (a torch without this private handle: the plain calls below)
             pg = False
         if pg is None:
+            if cache is not None:
+                cache[0] = None  # nothing of a destroyed group is kept alive
             return 1, 0
         if pg is not False:
-            cache = _WR_CACHE
-            if cache[0] is pg and cache[1] is group:
-                return cache[2]
+            if cache is None:
+                cache = _WR_CACHE
+            entry = cache[0]
+            if entry is not None and entry[0] is pg and entry[1] is group:
+                return entry[2]
             res = (dist.get_world_size(group), dist.get_rank(group))
-            _WR_CACHE[:] = [pg, group, res]
+            cache[0] = (pg, group, res)
             return res
     if dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)

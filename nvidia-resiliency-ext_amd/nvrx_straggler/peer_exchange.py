@@ -10,8 +10,11 @@ data is its own flag) and polls its own window until all rows of this epoch are 
 by all ranks so that either every rank gets a :class:`PeerAllGather` or none does.  It presents the interface of
 ``rccl_direct.DirectAllGather`` (``fn_address`` / ``comm_address`` for ``nvrx_report``, ``exchange``, ``close``).
 Only ranks of ONE node can share windows; multi-node groups stay on RCCL.  ``choose()`` picks between the two routes:
-``NVRX_EXCHANGE=rccl|peer|auto`` (default auto = both are built, each is timed and checked on a dummy row, the faster
-one that delivered the right table on every rank wins).
+``NVRX_EXCHANGE=rccl|peer|auto``.  The default is ``rccl``: the window route is OPT-IN until it has a committed run across
+real GPUs behind it (so far it has only run between processes sharing one device).  ``peer`` = the windows if their
+checked trial passes on every rank, else RCCL; ``auto`` = both are built, each is timed and checked on a dummy row, the
+faster one that delivered the right table on every rank wins (a calm-state timing, so not reproducible run to run).
+The chosen route is logged once on rank 0.
 """
 from __future__ import annotations
 
@@ -54,6 +57,7 @@ class PeerAllGather:
         self.fn_address = lib.nvrx_peer_allgather_address()
         self.comm_address = peer.value
         self.max_count = MAX_FLOATS_PER_RANK
+        self._raised_epoch = 0
 
     def all_gather(self, send_ptr: int, recv_ptr: int, count: int, stream_handle: int) -> None:
         rc = self._lib.nvrx_peer_allgather(send_ptr, recv_ptr, count, _NCCL_FLOAT32, self._peer, stream_handle)
@@ -72,7 +76,10 @@ class PeerAllGather:
     def check(self) -> None:
         """Raise if an exchange kernel gave up waiting for a peer (its table rows are NaN)."""
         epoch = self.timed_out_epoch()
-        if epoch:
+        if epoch and epoch != self._raised_epoch:
+            # raised once per timed-out exchange: the error word keeps the epoch of the LAST failure, later reports that
+            # complete must not inherit it
+            self._raised_epoch = epoch
             raise _native.NativeError(
                 f"straggler report exchange: a peer did not publish its row within the timeout (exchange #{epoch}); "
                 "the report's scores are invalid")
@@ -136,6 +143,12 @@ def create(group=None, device_index: Optional[int] = None, timeout_s: float = 18
     return PeerAllGather(lib, peer, world, rank, shared_device)
 
 
+def exchange_mode() -> str:
+    """``NVRX_EXCHANGE``: ``rccl`` (default) | ``peer`` | ``auto``."""
+    mode = os.environ.get("NVRX_EXCHANGE", "") or "rccl"
+    return mode if mode in ("rccl", "peer", "auto") else "rccl"
+
+
 def _trial(route, group, backend, reps: int = 30):
     """Time ``reps`` exchanges of a recognisable dummy row on ``route`` and check what arrived.  Collective.
     Returns (median microseconds, table correct) for THIS rank.  Never raises: a rank that fails reports "not
@@ -169,7 +182,7 @@ def _trial(route, group, backend, reps: int = 30):
 
 def choose(group, backend, rccl, peer, timeout_s: float = 1800.0):
     """Pick the exchange route for ``group`` (collective; same answer on every rank).  Returns (route, info)."""
-    mode = os.environ.get("NVRX_EXCHANGE", "auto")
+    mode = exchange_mode()
     info = {"mode": mode}
     if peer is not None:
         # the trial must not be able to park a kernel on the GPU for long if a window is unreachable

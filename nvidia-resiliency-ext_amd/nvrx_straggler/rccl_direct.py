@@ -50,6 +50,8 @@ def _load_rccl() -> Optional[ctypes.CDLL]:
             lib.ncclCommDestroy.restype = ctypes.c_int
             lib.ncclGetErrorString.argtypes = [ctypes.c_int]
             lib.ncclGetErrorString.restype = ctypes.c_char_p
+            lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+            lib.ncclCommCount.restype = ctypes.c_int
         except AttributeError:
             continue
         return lib
@@ -81,6 +83,12 @@ class DirectAllGather:
         rc = self._lib.ncclAllGather(send_ptr, recv_ptr, count, _NCCL_FLOAT32, self._comm, stream_handle)
         if rc != 0:
             raise RuntimeError(f"ncclAllGather failed: {self._lib.ncclGetErrorString(rc).decode()}")
+
+    def comm_ranks(self) -> int:
+        """``ncclCommCount`` of the communicator: how many ranks RCCL itself says take part in the reports' all-gather."""
+        n = ctypes.c_int(0)
+        rc = self._lib.ncclCommCount(self._comm, ctypes.byref(n))
+        return n.value if rc == 0 else -1
 
     def exchange(self, ws, backend):
         """The report's exchange for workspace ``ws`` on the backend's stream; returns the gathered table."""
@@ -128,10 +136,10 @@ def create(group=None, device_index: Optional[int] = None) -> Optional[DirectAll
     ctypes.memmove(ctypes.byref(uid), box[0], _NCCL_UNIQUE_ID_BYTES)
     comm = ctypes.c_void_p()
     try:
-        # the communicator binds to the device that is current during init: make it the backend's
-        if device_index is not None:
-            torch.cuda.set_device(device_index)
-        rc = lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
+        # the communicator binds to the device that is current during init: make it the backend's for the duration of
+        # the call only (the caller's current device is restored)
+        with torch.cuda.device(device_index if device_index is not None else torch.cuda.current_device()):
+            rc = lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
         ok = rc == 0 and bool(comm.value)
     except Exception:  # pragma: no cover
         ok = False

@@ -23,6 +23,7 @@ from __future__ import annotations
 import collections
 import dataclasses
 import itertools
+import logging
 import os
 import threading
 import time
@@ -36,6 +37,7 @@ from .name_mapper import NameMapper
 from .statistics import NUM_COLUMN, STAT_KEYS, Statistic
 
 _SummaryType = Mapping[Statistic, float]
+_LOG = logging.getLogger(__name__)
 
 _NCCL_MARKER = "ncclDev"  # RCCL's device kernels carry the same prefix (reporting.py:336)
 
@@ -528,6 +530,7 @@ class ReportGenerator:
         self.asynchronous = bool(asynchronous)
         self._inflight: Optional[_PendingBlock] = None
         self.exchange_info: Dict[str, Any] = {}
+        self._wr_cache: list = [None]  # this generator's remembered (default group, group, (world, rank)): dist_utils.world_and_rank
 
     # ---- pieces kept from the reference's host logic ----------------------------------------------
     @staticmethod
@@ -573,7 +576,8 @@ class ReportGenerator:
         index = getattr(be.device, "index", None)
         rccl = rccl_direct.create(self.group, index)
         peer = None
-        if os.environ.get("NVRX_EXCHANGE", "auto") != "rccl" and (rccl is not None or os.environ.get("NVRX_EXCHANGE") == "peer"):
+        mode = peer_exchange.exchange_mode()
+        if mode != "rccl" and (rccl is not None or mode == "peer"):
             # windows need a group that can reach every rank's GPU: built next to the RCCL route (a gloo group whose
             # ranks share one GPU qualifies too when asked for explicitly: that is how the tests run it)
             peer = peer_exchange.create(self.group, index, _backend_mod.report_timeout_s() or 1e9)
@@ -581,6 +585,12 @@ class ReportGenerator:
                                             if (rccl or peer) else (None, {}))
         if self._direct is not None:
             self.exchange_info["route"] = getattr(self._direct, "route", "ncclAllGather on the detector's stream")
+            ranks = getattr(self._direct, "comm_ranks", None)
+            if ranks is not None:
+                self.exchange_info["rccl_comm_ranks"] = ranks()  # ncclCommCount of the communicator the reports use
+        if self.rank == 0:
+            _LOG.info("straggler report exchange route: %s %s", self.exchange_info.get("route", "torch.distributed"),
+                      {k: v for k, v in self.exchange_info.items() if k != "route"})
 
     def _exchange(self, be, ws):
         """The report's one collective: this rank's rows -> the [R, L] table, on the backend's stream."""
@@ -795,6 +805,12 @@ class ReportGenerator:
                      wait=True, stats_rows=plan.stats_needed)
         if multi:
             self._check_exchange()
+        if fused:
+            # a resident score kernel forwards the statistics rows AFTER the scores: whatever this call returns, the
+            # next user of the workspace must see them landed (meta[5]) before it enqueues anything that writes them
+            mark = getattr(ws, "mark_live", None)  # (the CPU checker backend of the tests has no deferred rows)
+            if mark is not None:
+                mark(ws.seq)
         if ws.meta[0] != 1:
             return False  # another rank met a new name: fall back to the general (name-syncing) path
         if self.gather_on_rank0 and self.rank != 0:
@@ -869,7 +885,7 @@ class ReportGenerator:
         work already enqueued there (the collectives of the training step) on the device, without a host wait.
         """
         t0 = time.perf_counter_ns()
-        self.world_size, self.rank = dist_utils.world_and_rank(self.group)
+        self.world_size, self.rank = dist_utils.world_and_rank(self.group, self._wr_cache)
         if not self._direct_tried:
             self._maybe_create_direct_exchange()
         # steady state: same name tables as last time -> run the cached plan

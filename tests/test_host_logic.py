@@ -520,13 +520,19 @@ def test_world_and_rank_is_remembered_per_default_process_group():
         dist.init_process_group("gloo", rank=0, world_size=1, store=dist.HashStore())
         try:
             assert dist_utils.world_and_rank() == (1, 0)
-            assert dist_utils._WR_CACHE[0] is dist.distributed_c10d._world.default_pg
+            assert dist_utils._WR_CACHE[0][0] is dist.distributed_c10d._world.default_pg
             sub = dist.new_group([0])
-            assert dist_utils.world_and_rank(sub) == (1, 0) and dist_utils._WR_CACHE[1] is sub
-            assert dist_utils.world_and_rank() == (1, 0) and dist_utils._WR_CACHE[1] is None
+            assert dist_utils.world_and_rank(sub) == (1, 0) and dist_utils._WR_CACHE[0][1] is sub
+            assert dist_utils.world_and_rank() == (1, 0) and dist_utils._WR_CACHE[0][1] is None
+            # a caller-owned cache (one per ReportGenerator) never sees, and never disturbs, anybody else's entry
+            mine, theirs = [None], [None]
+            assert dist_utils.world_and_rank(sub, mine) == (1, 0) and mine[0][1] is sub
+            assert dist_utils.world_and_rank(None, theirs) == (1, 0) and theirs[0][1] is None and mine[0][1] is sub
+            assert dist_utils._WR_CACHE[0][1] is None
         finally:
             dist.destroy_process_group()
         assert dist_utils.world_and_rank() == (1, 0)
+        assert dist_utils.world_and_rank(None, mine) == (1, 0) and mine[0] is None  # nothing of the dead group is kept
 
 
 def test_all_gather_object_only_when_names_change():
