@@ -15,6 +15,8 @@ no-op'd because there is no GPU here) and runs
   configs #3/#5) -> stress.json   (inputs are re-derived from the recipe in ``synth.py``)
 * ten consecutive ``Detector.generate_report`` calls on 8 gloo ranks x 4 sections x 100 samples per report
   (BASELINE config #2: history minima across reports, rank 3 slow from report 5 on) -> loop.json
+* the reference's ``StragglerDetectionCallback`` (ptl_resiliency/straggler_det_callback.py) under a scripted trainer and a
+  scripted sequence of reports (``callback_script.py``) -> callback.json
 * the reference's native ``computeStats``/``CircularBuffer``/``CuptiProfiler`` through
   ``oracle/_ref/libnvrx_ref.so`` -> native.json
 
@@ -422,9 +424,56 @@ def make_loop():
     print("loop.json:", len(got[0]), "reports")
 
 
+def make_callback():
+    """The reference's ``StragglerDetectionCallback`` (ptl_resiliency/straggler_det_callback.py:37-265) driven by the
+    scripted trainer of ``callback_script.py``.  Lightning is not in the image: ``lightning.pytorch.callbacks.Callback``
+    is a two-line stub (the callback only inherits from it), and the module is loaded from its file so that the package's
+    ``__init__`` (which imports the fault-tolerance callbacks and their dependencies) is not executed."""
+    import importlib.machinery
+    import importlib.util
+
+    straggler = _install_reference()
+    for name in ("lightning", "lightning.pytorch", "lightning.pytorch.callbacks"):
+        mod = types.ModuleType(name)
+        mod.__spec__ = importlib.machinery.ModuleSpec(name, None, is_package=True)
+        mod.__path__ = []
+        sys.modules[name] = mod
+    sys.modules["lightning.pytorch.callbacks"].Callback = type("Callback", (), {})
+    pkg_dir = os.path.join(REF_SRC, "nvidia_resiliency_ext", "ptl_resiliency")
+    pkg = types.ModuleType("nvidia_resiliency_ext.ptl_resiliency")
+    pkg.__path__ = [pkg_dir]
+    sys.modules["nvidia_resiliency_ext.ptl_resiliency"] = pkg
+    import warnings
+
+    def load(sub):
+        full = f"nvidia_resiliency_ext.ptl_resiliency.{sub}"
+        spec = importlib.util.spec_from_file_location(full, os.path.join(pkg_dir, sub + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[full] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    load("_utils")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        ref = load("straggler_det_callback")
+    import callback_script
+
+    out = {"generator": "reference StragglerDetectionCallback (ptl_resiliency/straggler_det_callback.py) driven by "
+                        "tests/golden/callback_script.py; _gather_flag_from_rank0 replaced by the identity (it needs a CUDA "
+                        "device, :231-238); 'processing time' figures and the print order of sets normalised",
+           "constructor_error": callback_script.constructor_error(ref.StragglerDetectionCallback),
+           "scenarios": [callback_script.drive(ref.StragglerDetectionCallback, ref.straggler, straggler.Report, sc, patch_gather=True)
+                         for sc in callback_script.SCENARIOS]}
+    with open(os.path.join(HERE, "callback.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("callback.json:", len(out["scenarios"]), "scenarios,",
+          sum(len(it["records"]) for sc in out["scenarios"] for it in sc["iterations"]), "log records")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF_SRC), "reference tree not found; golden vectors can only be regenerated in the build container"
-    which = sys.argv[1:] or ["section", "native", "scoring", "stress", "loop"]
+    which = sys.argv[1:] or ["section", "native", "scoring", "stress", "loop", "callback"]
     if "native" in which:
         make_native()
     if "section" in which:
@@ -435,3 +484,5 @@ if __name__ == "__main__":
         make_stress()
     if "loop" in which:
         make_loop()
+    if "callback" in which:
+        make_callback()

@@ -193,3 +193,23 @@ def test_ptl_callback_on_hip_backend_flags_the_slow_gpu():
     assert any("GPU relative performance" in m for m in r0["messages"])
     assert any("STRAGGLER DETECTION WARNING" in m and "rank=1" in m for m in r0["messages"]), r0["messages"][-6:]
     assert r0["should_stop"] and res[1]["should_stop"]
+    # every line a REAL run logs has the shape of a line the reference callback logged in the golden transcript
+    # (tests/golden/callback.json; digits, node names and the MI355X telemetry extra aside)
+    import re
+
+    import callback_script
+
+    def shape(message):
+        message = callback_script.normalise(message)
+        message = re.sub(r"Node=\S+", "Node=N", message)
+        message = re.sub(r"node='[^']*'", "node='N'", message)
+        message = re.sub(r"StragglerId\(rank=\d+, node='N'\)(, StragglerId\(rank=\d+, node='N'\))*", "IDS", message)
+        message = re.sub(r"(Rank=\d+ Node=N Score=[0-9.]+\n)+", "LINES", message.replace("  Rank=", "Rank="))
+        return re.sub(r"[0-9.]+", "#", message)
+
+    golden_shapes = {shape(text) for sc in load_golden("callback.json")["scenarios"] for it in sc["iterations"]
+                     for _, text in it["records"]}
+    for m in r0["messages"]:
+        if m.startswith("rank ") and "GPU" in m:   # ROCm SMI line about a flagged reporting rank: not in the reference
+            continue
+        assert shape(m) in golden_shapes, (m, shape(m))
