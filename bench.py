@@ -290,6 +290,51 @@ def _cadence_leg(reports: int, job=None):
     return out
 
 
+def _per_kernel_leg(reports: int = 12):
+    """Per-kernel mode at the scale of the reference's own sizing (tests/straggler/unit/test_data_shared.py:62-66): K
+    kernel keys x 100 durations per report.  The records are synthetic (tracing 400 000 real launches per report is
+    not a benchmark step) and enter where the tracer's drained records enter: ``KernelTraceProfiler.ingest`` (key ->
+    row table, ONE ``nvrx_ring_push_pairs`` scatter), then one report over the K kernel rows."""
+    from nvrx_straggler import ktrace
+    from nvrx_straggler.reporting import ReportGenerator
+
+    out = {}
+    for K in (256, 4096):
+        ktrace.KernelTraceProfiler._live = None
+        prof = ktrace.KernelTraceProfiler(statsMaxLenPerKernel=128, max_keys=K)
+        gen = ReportGenerator(["relative_perf_scores", "individual_perf_scores"], gather_on_rank0=True, node_name="node0")
+        try:
+            rng = np.random.default_rng(K)
+            recs = np.empty(K * 100, dtype=ktrace.RECORD_DTYPE)
+            recs["key"] = rng.permutation(np.repeat(np.arange(K, dtype=np.uint32), 100))
+            recs["us"] = rng.lognormal(3.0, 0.3, K * 100).astype(np.float32)
+            rings = prof._rings
+            no_sections = {}  # the same object every report: the generator's cached plan stays valid
+            t_in, t_rep = [], []
+            for i in range(reports + 2):
+                t0 = time.perf_counter_ns()
+                prof.ingest(recs)
+                t1 = time.perf_counter_ns()
+                rep = gen.generate_report_from_rings(rings, no_sections, rings.kernel_row_names)
+                score = rep.gpu_relative_perf_scores[0]
+                t2 = time.perf_counter_ns()
+                rings.reset()
+                if i >= 2:
+                    t_in.append(t1 - t0)
+                    t_rep.append(t2 - t1)
+            assert abs(score - 1.0) < 1e-6
+            out[f"K{K}"] = {"records_per_report": int(recs.size), "ingest_us_median": round(float(np.median(t_in)) / 1e3, 1),
+                            "report_us_median": round(float(np.median(t_rep)) / 1e3, 1)}
+        finally:
+            gen.close()
+            prof.close()
+            ktrace.KernelTraceProfiler._live = None
+    out["workload"] = ("K kernel keys x 100 durations per report (synthetic drained records): KernelTraceProfiler.ingest = key->row "
+                       "lookup + ONE scatter launch for all keys, then one report over the K kernel rows (statistics, GPU score) "
+                       "with its GPU score read")
+    return out
+
+
 def _kernel_source_sha() -> str:
     import hashlib
 
@@ -645,6 +690,14 @@ def main():
         job.backend.synchronize()
         cadence.update(_cadence_leg(args.cadence_reports))
 
+    per_kernel = None
+    if world == 1 and not args.no_extra_legs:
+        job.backend.synchronize()
+        try:
+            per_kernel = _per_kernel_leg()
+        except Exception as e:  # noqa: BLE001  (an optional leg must not take the headline line down)
+            per_kernel = {"error": str(e)[-300:]}
+
     overhead = overhead_async = None
     if not args.no_overhead:
         job.backend.synchronize()
@@ -722,6 +775,8 @@ def main():
             out["per_step_us"] = [round(v / 1e3, 2) for v in per_step]
         if cadence is not None:
             out["report_at_cadence"] = cadence
+        if per_kernel is not None:
+            out["per_kernel_mode"] = per_kernel
         if cold is not None:
             out["roofline"]["cold"] = cold
         if n8 is not None:

@@ -141,6 +141,11 @@ int nvrx_row_configure(nvrx_ctx *ctx, int row, int kind, int gid);
  * device ring at the next flush.  O(1), no HIP call unless the staging buffer is full. */
 int nvrx_ring_push(nvrx_ctx *ctx, int row, float value);
 int nvrx_ring_push_many(nvrx_ctx *ctx, int row, const float *values, int n);
+/* Append n (row, value) pairs in arrival order with ONE scatter launch on the context's stream, whatever the number of
+ * rows they touch (rows[i] < 0 skips pair i).  Same ring semantics as n calls of nvrx_ring_push.  This is how the
+ * per-kernel tracer's drained records reach the rings: the reference appends every CUPTI record to its key's
+ * CircularBuffer on the host (CuptiProfiler.cpp:186-207, CircularBuffer.h:53-61). */
+int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values, int n);
 /* Append n samples that already live in device memory (device-to-device, wraps as needed). */
 int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, void *stream);
 /* Declare that `row` currently holds n valid samples in its device ring (no data movement). */

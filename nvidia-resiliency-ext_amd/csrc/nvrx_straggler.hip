@@ -1769,6 +1769,13 @@ struct nvrx_ctx {
     hipEvent_t copy_done = nullptr;
     bool copy_pending = false;
 
+    // bulk appends (nvrx_ring_push_pairs): a pinned entry buffer of its own, grown on demand
+    StagedSample *h_bulk = nullptr;
+    size_t bulk_cap = 0;
+    hipEvent_t bulk_done = nullptr;
+    bool bulk_in_flight = false;
+    std::vector<uint32_t> bulk_cnt, bulk_seen;
+
     // device-side region timing (k_stamp_begin / k_stamp_end)
     static constexpr int NSTAMP = 256;
     unsigned long long *d_stamps = nullptr;  // [NSTAMP] begin timestamps, handed out round-robin
@@ -2093,6 +2100,7 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
         CTX_TRY(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
     }
     CTX_TRY(hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
+    CTX_TRY(hipEventCreateWithFlags(&ctx->bulk_done, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->stamp_ev, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->report_ev, hipEventDisableTiming));
@@ -2129,6 +2137,8 @@ int nvrx_ctx_destroy(nvrx_ctx *ctx) {
     if (ctx->d_kinds) (void)hipFree(ctx->d_kinds);
     if (ctx->d_gid) (void)hipFree(ctx->d_gid);
     if (ctx->d_hist_min) (void)hipFree(ctx->d_hist_min);
+    if (ctx->h_bulk) (void)hipHostFree(ctx->h_bulk);
+    if (ctx->bulk_done) (void)hipEventDestroy(ctx->bulk_done);
     if (ctx->h_kinds) (void)hipHostFree(ctx->h_kinds);
     if (ctx->h_gid) (void)hipHostFree(ctx->h_gid);
     for (StageBuf &b : ctx->buf) {
@@ -2208,6 +2218,80 @@ int nvrx_ring_push_many(nvrx_ctx *ctx, int row, const float *values, int n) {
     for (int i = 0; i < n; i++) {
         rc = push_locked(ctx, row, values[i]);
         if (rc) return rc;
+    }
+    return NVRX_OK;
+}
+
+// Bulk append of (row, value) pairs in arrival order: ONE scatter launch however many rows the pairs touch.  This is how
+// the per-kernel tracer's drained records reach the rings (hundreds to thousands of kernel keys per report,
+// CuptiProfiler.cpp:186-207 appends the same records to one CircularBuffer per key on the host).  Ring semantics are
+// those of nvrx_ring_push applied pair by pair: slot = pushes % ring_cap, and a pair that a LATER pair of the same call
+// would overwrite is not written at all (the scatter has no order inside one launch).  rows[i] < 0 skips the pair.
+int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values, int n) {
+    if (!ctx || (n > 0 && (!rows || !values)) || n < 0) return fail(NVRX_ERR_INVALID, "bad arguments");
+    if (n == 0) return NVRX_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx_set_device(ctx);
+    if (rc) return rc;
+    hipStream_t st = ctx->default_stream;
+    rc = flush_locked(ctx, st);  // samples staged before this call keep their place in the order
+    if (rc) return rc;
+    ctx->bulk_cnt.assign((size_t)ctx->rows, 0u);
+    for (int i = 0; i < n; i++) {
+        const int32_t r = rows[i];
+        if (r < 0) continue;
+        if (r >= ctx->rows) return fail(NVRX_ERR_RANGE, "row %d out of range (%d rows)", (int)r, ctx->rows);
+        ctx->bulk_cnt[(size_t)r]++;
+    }
+    if (ctx->bulk_in_flight) {  // the previous call's scatter still reads the entry buffer
+        HIP_TRY(hipEventSynchronize(ctx->bulk_done));
+        ctx->bulk_in_flight = false;
+    }
+    if (ctx->bulk_cap < (size_t)n) {
+        if (ctx->h_bulk) HIP_TRY(hipHostFree(ctx->h_bulk));
+        ctx->h_bulk = nullptr;
+        ctx->bulk_cap = 0;
+        const size_t cap = std::max<size_t>((size_t)n + (size_t)n / 2, 1u << 16);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_bulk), cap * sizeof(StagedSample), hipHostMallocDefault));
+        ctx->bulk_cap = cap;
+    }
+    ctx->bulk_seen.assign((size_t)ctx->rows, 0u);
+    const uint64_t cap = (uint64_t)ctx->ring_cap;
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const int32_t r = rows[i];
+        if (r < 0) continue;
+        const uint32_t k = ctx->bulk_seen[(size_t)r]++;
+        if ((uint64_t)(ctx->bulk_cnt[(size_t)r] - k) > cap) continue;  // overwritten later in this very call
+        StagedSample &e = ctx->h_bulk[m++];
+        e.row_slot = ((uint32_t)r << 16) | (uint32_t)((ctx->total[(size_t)r] + k) % cap);
+        e.value = values[i];
+    }
+    for (int r = 0; r < ctx->rows; r++) ctx->total[(size_t)r] += ctx->bulk_cnt[(size_t)r];
+    // the launch of flush_locked with this call's entries: counts (and pending row metadata) travel with it
+    StageBuf &b = ctx->buf[ctx->cur];
+    for (int r = 0; r < ctx->rows; r++)
+        b.h_counts[r] = (uint32_t)std::min<uint64_t>(ctx->total[(size_t)r], cap);
+    const int work = std::max(m, ctx->rows);
+    hipLaunchKernelGGL(k_scatter, dim3((work + 255) / 256), dim3(256), 0, st, b.h_counts, ctx->h_bulk, m, ctx->d_samples,
+                       ctx->row_stride, ctx->d_counts, ctx->rows, ctx->meta_dirty ? ctx->h_kinds : nullptr, ctx->d_kinds,
+                       ctx->meta_dirty ? ctx->h_gid : nullptr, ctx->d_gid);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b.done, st));
+    HIP_TRY(hipEventRecord(ctx->bulk_done, st));
+    b.in_flight = true;
+    ctx->bulk_in_flight = true;
+    if (ctx->meta_dirty) {
+        HIP_TRY(hipEventSynchronize(b.done));
+        b.in_flight = false;
+    }
+    ctx->meta_dirty = false;
+    ctx->counts_dirty = false;
+    ctx->cur = (ctx->cur + 1) % nvrx_ctx::NBUF;
+    StageBuf &nb = ctx->buf[ctx->cur];
+    if (nb.in_flight) {
+        HIP_TRY(hipEventSynchronize(nb.done));
+        nb.in_flight = false;
     }
     return NVRX_OK;
 }

@@ -13,7 +13,9 @@ import threading
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint32, c_void_p
 
 _LIB_NAME = "libnvrx_straggler_hip.so"
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
+# NVRX_LIB_DIR: load the native libraries from another directory (the sanitizer build of `make -C csrc asan` lives in
+# lib_asan/; tools/run_sanitized.sh points here)
+_LIB_PATH = os.path.join(os.environ.get("NVRX_LIB_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib"), _LIB_NAME)
 
 NVRX_ABI_VERSION = 2
 STATS_STRIDE = 8
@@ -55,6 +57,7 @@ SYMBOLS = [
     ("nvrx_row_configure", c_int, [c_void_p, c_int, c_int, c_int]),
     ("nvrx_ring_push", c_int, [c_void_p, c_int, c_float]),
     ("nvrx_ring_push_many", c_int, [c_void_p, c_int, c_void_p, c_int]),
+    ("nvrx_ring_push_pairs", c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     ("nvrx_ring_push_device", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     ("nvrx_ring_set_count", c_int, [c_void_p, c_int, c_int]),
     ("nvrx_ring_set_count_all", c_int, [c_void_p, c_int]),

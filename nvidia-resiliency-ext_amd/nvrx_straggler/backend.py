@@ -382,6 +382,15 @@ class HipRings:
         a = np.ascontiguousarray(values, dtype=np.float32)
         _native.check(self.lib.nvrx_ring_push_many(self.ctx, lr * self.rows_per_rank + row, a.ctypes.data, a.size))
 
+    def push_pairs(self, rows: np.ndarray, values: np.ndarray) -> None:
+        """Append ``values[i]`` to ring row ``rows[i]`` (global row index; negative = skip) for all i, in order, with
+        ONE scatter launch (``nvrx_ring_push_pairs``)."""
+        r = np.ascontiguousarray(rows, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=np.float32)
+        if r.size != v.size:
+            raise ValueError("rows and values differ in length")
+        _native.check(self.lib.nvrx_ring_push_pairs(self.ctx, r.ctypes.data, v.ctypes.data, r.size))
+
     def push_device(self, row: int, values: torch.Tensor, lr: int = 0) -> None:
         assert values.dtype == torch.float32 and values.is_contiguous() and values.is_cuda
         _native.check(self.lib.nvrx_ring_push_device(self.ctx, lr * self.rows_per_rank + row, values.data_ptr(),

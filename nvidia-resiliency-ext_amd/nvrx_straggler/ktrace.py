@@ -35,7 +35,9 @@ from . import backend as _backend_mod
 from .hip_profiler import KernelStats
 
 _LIB_NAME = "libnvrx_ktrace.so"
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
+# NVRX_LIB_DIR: load the native libraries from another directory (the sanitizer build of `make -C csrc asan` lives in
+# lib_asan/; tools/run_sanitized.sh points here)
+_LIB_PATH = os.path.join(os.environ.get("NVRX_LIB_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib"), _LIB_NAME)
 
 
 class Record(Structure):
@@ -43,6 +45,7 @@ class Record(Structure):
 
 
 RECORD_DTYPE = np.dtype([("key", np.uint32), ("us", np.float32)])
+_ROW_UNKNOWN = -2  # key id without an entry in the key -> row table yet (-1: the rings had no row left for it)
 
 # every symbol include/nvrx_ktrace.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -174,6 +177,7 @@ class KernelTraceProfiler:
         self._started = False
         self._closed = False
         self._key_rows: Dict[int, int] = {}  # tracer key id -> ring row (-1: no row left)
+        self._row_table = np.full(1024, _ROW_UNKNOWN, dtype=np.int32)  # the same as an array indexed by key id
         self.keys_without_row = 0
         KernelTraceProfiler._live = weakref.ref(self)
 
@@ -235,20 +239,26 @@ class KernelTraceProfiler:
             import torch
 
             torch.cuda.synchronize()
-        recs = drain_all()
+        return self.ingest(drain_all())
+
+    def ingest(self, recs: np.ndarray) -> int:
+        """Append drained ``(key, us)`` records (``RECORD_DTYPE``, arrival order) to the device rings: every key id is
+        looked up in a key -> ring-row table (rows are handed out the first time a key shows up: cold) and ALL records
+        go to the device with one ``nvrx_ring_push_pairs`` call = one scatter launch, whether they belong to two
+        kernel keys or to four thousand (data_shared test sizes of the reference: tests/straggler/unit/test_data_shared.py:62-66)."""
         if recs.size == 0:
             return 0
-        order = np.argsort(recs["key"], kind="stable")  # stable: samples stay in launch order inside a key
-        keys = recs["key"][order]
-        us = np.ascontiguousarray(recs["us"][order])
-        bounds = np.flatnonzero(np.diff(keys)) + 1
-        starts = np.concatenate(([0], bounds))
-        ends = np.concatenate((bounds, [keys.size]))
-        rings = self._rings
-        for a, b in zip(starts.tolist(), ends.tolist()):
-            k = int(keys[a])
-            row = self._key_rows.get(k)
-            if row is None:
+        keys = recs["key"]
+        table = self._row_table
+        top = int(keys.max())
+        if top >= table.size:
+            grown = np.full(max(top + 1, 2 * table.size), _ROW_UNKNOWN, dtype=np.int32)
+            grown[: table.size] = table
+            table = self._row_table = grown
+        rows = table[keys]
+        if (rows == _ROW_UNKNOWN).any():
+            rings = self._rings
+            for k in np.unique(keys[rows == _ROW_UNKNOWN]).tolist():
                 try:
                     row = rings.row_for(_native.KIND_KERNEL, key_name(k))
                 except RuntimeError:
@@ -257,10 +267,11 @@ class KernelTraceProfiler:
                     if self.keys_without_row == 1:
                         warnings.warn("straggler rings are full: further kernel names are not recorded "
                                       "(raise max_rows in Detector.initialize)")
+                table[k] = row
                 self._key_rows[k] = row
-            if row >= 0:
-                rings.push_many(row, us[a:b])
-        return 0
+            rows = table[keys]
+        self._rings.push_pairs(rows, recs["us"])
+        return int(recs.size)
 
     def active_rows(self) -> Dict[str, int]:
         r = self._rings

@@ -199,6 +199,11 @@ class OracleRings:
         for v in values:
             self.push(row, float(v), lr)
 
+    def push_pairs(self, rows, values):
+        for r, v in zip(np.asarray(rows).tolist(), np.asarray(values).tolist()):
+            if r >= 0:
+                self.push(r, float(v))
+
     def set_count(self, row, n, lr=0):
         self.total[lr * self.rows_per_rank + row] = n
 

@@ -198,3 +198,67 @@ def test_ring_overwrite_oldest_matches_reference(be, cap, n):
         assert np.isnan(rings.peek_stats()[row][2])
     finally:
         rings.close()
+
+
+@pytest.mark.parametrize("cap,rows,n", [(16, 40, 3000), (64, 300, 20000), (100, 4096, 409600)])
+def test_bulk_append_of_row_value_pairs_matches_the_ring_of_the_reference(be, cap, rows, n):
+    """nvrx_ring_push_pairs (the per-kernel tracer's route into the rings: one scatter launch for all keys) == the
+    reference's CircularBuffer fed pair by pair (CuptiProfiler.cpp:186-207, CircularBuffer.h:53-61): rows that receive
+    more than a ring's worth in ONE call, rows continued by a second call and by single pushes, skipped (negative) rows.
+    The largest case is the reference's own data_shared sizing: 4096 kernel keys x 100 samples (test_data_shared.py:62-66)."""
+    rng = np.random.default_rng(cap)
+    rings = be.make_rings(1, rows, cap)
+    try:
+        for r in range(rows):
+            rings.row_for(1, f"k{r}")
+        # skewed: a few rows take most of the pairs (they wrap inside one call), many rows take a handful
+        hot = rng.integers(0, min(rows, 8), n // 2)
+        cold = rng.integers(0, rows, n - n // 2)
+        row_of = rng.permutation(np.concatenate([hot, cold])).astype(np.int32)
+        row_of[rng.integers(0, n, n // 50)] = -1
+        vals = rng.normal(100.0, 5.0, n).astype(np.float32)
+        a = n * 2 // 3
+        rings.push_pairs(row_of[:a], vals[:a])
+        for i in range(a, min(a + 50, n)):           # single pushes in between keep their place in the order
+            if row_of[i] >= 0:
+                rings.push(int(row_of[i]), float(vals[i]))
+        rings.push_pairs(row_of[min(a + 50, n):], vals[min(a + 50, n):])
+        stats = rings.peek_stats()
+        check = range(rows) if rows <= 300 else list(range(8)) + rng.integers(0, rows, 120).tolist()
+        for r in check:
+            mine = vals[row_of == r]
+            exp = oracle.ring_run(mine, cap)
+            assert rings.count(r) == exp.size, r
+            stored = rings.read_row(r)[: exp.size]
+            assert sorted(stored.tolist()) == sorted(exp.tolist()), r
+            if exp.size:
+                e = oracle.kernel_stats(exp)
+                assert stats[r][0] == e[0] and stats[r][1] == e[1] and stats[r][5] == exp.size, r
+    finally:
+        rings.close()
+
+
+def test_tracer_records_reach_their_rows_in_one_launch(be):
+    """KernelTraceProfiler.ingest (what harvest() does with the drained records) on synthetic records: 4096 kernel
+    keys x 100 durations; every key's statistics row equals the oracle's computeStats of its own durations."""
+    from nvrx_straggler import ktrace
+
+    K, per = 4096, 100
+    rng = np.random.default_rng(7)
+    recs = np.empty(K * per, dtype=ktrace.RECORD_DTYPE)
+    recs["key"] = rng.permutation(np.repeat(np.arange(K, dtype=np.uint32), per))
+    recs["us"] = rng.lognormal(3.0, 0.4, K * per).astype(np.float32)
+    prof = ktrace.KernelTraceProfiler(statsMaxLenPerKernel=128, max_keys=K)
+    try:
+        assert prof.ingest(recs[: K * per // 2]) == K * per // 2
+        assert prof.ingest(recs[K * per // 2:]) == K * per - K * per // 2
+        stats = prof._rings.peek_stats()
+        assert len(prof._key_rows) == K and prof.keys_without_row == 0
+        for k in rng.integers(0, K, 200).tolist():
+            mine = recs["us"][recs["key"] == k]
+            e = oracle.kernel_stats(mine)
+            row = prof._key_rows[k]
+            assert stats[row][5] == per and stats[row][0] == e[0] and stats[row][1] == e[1] and stats[row][2] == e[2], k
+    finally:
+        prof.close()
+        ktrace.KernelTraceProfiler._live = None

@@ -714,3 +714,104 @@ def test_poll_fails_fast_when_the_word_has_moved_past():
     assert lib.nvrx_poll_u32(addr, 9, 0.01) == -62 and b"not seen after" in lib.nvrx_last_error()
     word.value = 0
     assert lib.nvrx_poll_u32(addr, 1, 0.01) == -62  # a fresh block (0) is simply not there yet
+
+
+def test_a_report_read_on_another_thread_while_the_next_ones_are_generated():
+    """Two-thread stress of the lazily read result block (reporting._LiveBlock.head / stats vs Workspace.settle ->
+    detach): a reader thread builds the mappings of the most recent report while the main thread already generates the
+    next ones on the same workspace.  Every report carries values only it can have (medians scale with the report
+    number), so a block copied after it was overwritten, or half of each, shows up as a wrong number."""
+    import threading
+
+    from nvrx_straggler import Statistic, backend
+    from nvrx_straggler.reporting import ReportGenerator
+    from oracle_backend import OracleBackend
+
+    be = OracleBackend(emulate_fused=True)
+    backend.set_backend(be)
+    try:
+        S, N = 12, 33
+        rings = be.make_rings(1, S, 64)
+        rows = {f"s{i}": rings.row_for(0, f"s{i}") for i in range(S)}
+        none = {}
+        gen = ReportGenerator(["relative_perf_scores", "individual_perf_scores"], gather_on_rank0=True, node_name="n")
+        base = np.linspace(1.0, 2.0, N, dtype=np.float32)
+
+        def arm(t):
+            for i in range(S):
+                rings.samples[i, :N] = base * np.float32(1 + (t % 13)) * np.float32(1 + i)
+            rings.total[:] = N
+
+        latest = [None]
+        errors = []
+        stop = threading.Event()
+        reads = [0]
+
+        def reader():
+            while not stop.is_set():
+                item = latest[0]
+                if item is None:
+                    continue
+                t, rep = item
+                try:
+                    summ = rep.local_section_summaries
+                    flagged = rep.identify_stragglers()
+                    for i in (0, S // 2, S - 1):
+                        want = np.float32(np.median(base)) * np.float32(1 + (t % 13)) * np.float32(1 + i)
+                        got = summ[f"s{i}"][Statistic.MED]
+                        if abs(got - want) > 1e-4 * want:
+                            errors.append((t, i, got, want))
+                    if flagged["straggler_gpus_relative"]:
+                        errors.append((t, "flagged", flagged))
+                    reads[0] += 1
+                except Exception as e:  # noqa: BLE001
+                    errors.append((t, repr(e)))
+                    return
+
+        th = threading.Thread(target=reader, daemon=True)
+        th.start()
+        for t in range(3000):
+            arm(t)
+            rep = gen.generate_report_from_rings(rings, rows, none)
+            latest[0] = (t, rep)
+            rings.reset()
+        stop.set()
+        th.join(10)
+        assert not errors, errors[:5]
+        assert reads[0] > 50, reads[0]   # the reader really ran beside the generator
+        assert gen._ring_plan is not None and gen._ring_plan.fused  # the lazily read block was the path under test
+    finally:
+        backend.set_backend(None)
+
+
+def test_region_timing_flattens_gpu_scores_when_the_region_holds_a_collective():
+    """How far the default GPU timing (one device-stamped row per profiled REGION, key ``hipevent::<section>``) moves
+    the relative GPU score away from the reference's per-kernel score when the region contains a collective
+    (INTEGRATION.md quotes these numbers).  Four ranks, rank 2 computes 25 % slower; the step ends in an all-reduce,
+    so every rank's region lasts as long as the slowest rank's compute plus the wire time.
+
+    * per-kernel rows (``NVRX_GPU_TIMING=kernels``, the reference's data model): the collective kernel ``ncclDev*`` is
+      dropped (reporting.py:330-336), the score is min(compute) / compute = 0.8 for the slow rank -> flagged at 0.85;
+    * one row per region: all four regions last the same, every score is 1.0 -> the slow GPU is invisible.
+    """
+    compute = [10.0, 10.0, 12.5, 10.0]   # ms of GPU compute per step
+    wire = 1.0
+    region = max(compute) + wire         # what a device stamp around the whole step measures on every rank
+
+    def stat(v, n=100):
+        return {"MIN": v, "MAX": v, "MED": v, "AVG": v, "STD": 0.0, "NUM": n}
+
+    per_kernel = [({}, {"gemm_blk_256_1_1_grid_512_1_1": stat(c), "ncclDevKernel_AllReduce_blk_1_1_1_grid_1_1_1": stat(region - c)})
+                  for c in compute]
+    per_region = [({}, {"hipevent::train_step": stat(region)}) for _ in compute]
+    out = {}
+    for name, step in (("kernels", per_kernel), ("regions", per_region)):
+        sc = {"world_size": 4, "scores_to_compute": ["relative_perf_scores"], "gather_on_rank0": True, "steps": [step],
+              "thresholds": [0.85]}
+        res = run_ranks(workers.scoring_scenario, 4, scenario=sc)
+        out[name] = res[0]["reports"][0]
+    k, r = out["kernels"], out["regions"]
+    assert [round(k["gpu_relative_perf_scores"][i], 4) for i in range(4)] == [1.0, 1.0, 0.8, 1.0]
+    assert k["stragglers"]["0.85"]["straggler_gpus_relative"] == [2]
+    assert [round(r["gpu_relative_perf_scores"][i], 4) for i in range(4)] == [1.0, 1.0, 1.0, 1.0]
+    assert r["stragglers"]["0.85"]["straggler_gpus_relative"] == []

@@ -1,0 +1,22 @@
+"""The native libraries' HOST code under AddressSanitizer + UndefinedBehaviorSanitizer (`make -C csrc asan`,
+tools/run_sanitized.sh): the device-free paths -- loader, every exported symbol, argument checks and error strings,
+the tracer library's queue / key table behind the fake tracer.  On a GPU box `SAN=ubsan tools/run_sanitized.sh -m gpu`
+covers the paths that need a device (the ASan runtime cannot be preloaded next to HSA: tools/run_sanitized.sh)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_host_code_is_clean_under_asan_and_ubsan():
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "NVRX_LIB_DIR")}
+    r = subprocess.run(["bash", os.path.join(REPO, "tools", "run_sanitized.sh")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "lib_asan" in r.stdout and " passed" in r.stdout, tail
+    assert "runtime error" not in tail and "AddressSanitizer" not in tail, tail
