@@ -571,11 +571,14 @@ def main():
     # that was the one ~175 us step of r02's 20-step driver run.  The collector stays enabled.
     gc.collect()
     gc.freeze()
+    # correctness guard (not timed, not part of the warm-up count): 25 reports, the flagged set of EVERY one checked
     rep = found = None
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(25):
         rep, found = step()
-    if rank == 0:
-        check_flagged(found)
+        if rank == 0:
+            check_flagged(found)
+    for _ in range(args.warmup):
+        rep, found = step()
     sync_all()
     per_step = []
     t0 = time.perf_counter()

@@ -198,6 +198,15 @@ def _choose(mode, info, group, backend, rccl, peer):
     if mode == "rccl" or peer is None:
         if peer is not None:
             peer.close()
+        if rccl is not None:
+            # the same checked trial the other modes run: a communicator that does not deliver the right table on every
+            # rank is dropped (the reports then stay on torch.distributed), and the figure says what the route costs here
+            us, good = _trial(rccl, group, backend)
+            info["rccl_us"] = round(us, 2) if np.isfinite(us) else None
+            if not _all_ok(good, group):
+                rccl.close()
+                info["rccl_rejected"] = True
+                return None, info
         return rccl, info
     if mode == "peer" or rccl is None:
         us, good = _trial(peer, group, backend)

@@ -37,6 +37,7 @@ def test_single_rank_communicator_all_gather_on_our_stream():
         ex.all_gather(send.data_ptr(), table.data_ptr(), 3 * L, be.stream_handle)
         be.synchronize()
         assert np.array_equal(table.cpu().numpy(), rows)
+        assert ex.comm_ranks() == 1   # ncclCommCount: what bench.py reports as exchange.selection.rccl_comm_ranks
     finally:
         ex.close()
 
