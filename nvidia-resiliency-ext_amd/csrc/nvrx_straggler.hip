@@ -199,6 +199,10 @@ __device__ unsigned long long g_sub[4096][2][16];
 #ifndef NVRX_HIST_BITS_WIDE
 #define NVRX_HIST_BITS_WIDE 12
 #endif
+// the score kernel loads one dword of every 64-byte line of its argument segment up front (A/B switch for experiments)
+#ifndef NVRX_TOUCH_KERNARGS
+#define NVRX_TOUCH_KERNARGS 1
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Cross-rank scoring on the exchanged table (layout in nvrx_straggler.h).  (Fusing this into the tail
@@ -574,6 +578,8 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                         kmx = max(kmx, kk);
                     }
                     if (NVRX_ABLATE == 0) atomicAdd(&s_hist[min(__builtin_elementwise_sub_sat(kk, lo0) >> sh, (uint32_t)(HIST_BINS - 1))], 1u);
+                    if (NVRX_ABLATE == 3)  // timing probe only (wrong counts): the same atomics without bank conflicts
+                        atomicAdd(&s_hist[(min(__builtin_elementwise_sub_sat(kk, lo0) >> sh, (uint32_t)(HIST_BINS - 1)) & ~63u) | (uint32_t)lane], 1u);
                 }
                 // moments of the tile as two packed pairs (v_pk_add_f32 / v_pk_fma_f32)
                 const f32x2 d01 = f32x2{xs[0], xs[1]} - pivot2, d23 = f32x2{xs[2], xs[3]} - pivot2;
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
 
         uint32_t k = k_rank, pop = 0u, bin = 0u;
         bool rebuild = conv;
-        if (NVRX_ABLATE == 0 && !conv) {
+        if ((NVRX_ABLATE == 0 || NVRX_ABLATE == 3) && !conv) {
             bin = locate_first(k, pop);
             rebuild = speculative && (bin == 0u || bin == (uint32_t)(HIST_BINS - 1));
         } else {
@@ -771,7 +777,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         auto key_value = [&](uint32_t kk) -> float { return conv ? key2f(kk) : __uint_as_float(kk); };
 
         uint32_t med_key;
-        if (NVRX_ABLATE != 0 || kmn == kmx) {
+        if ((NVRX_ABLATE != 0 && NVRX_ABLATE != 3) || kmn == kmx) {
             med_key = kmn;  // all samples equal (or selection ablated)
         } else {
             path = 1;
@@ -1325,6 +1331,20 @@ __global__ __launch_bounds__(NTHR) void k_score1(ScoreArgs a, int fence, PeerArg
     const int tid = threadIdx.x;
     const float NaN = __builtin_nanf("");
     const unsigned long long t_begin = wall_clock64();
+#if NVRX_TOUCH_KERNARGS
+    {   // The ~300-byte argument segment is read lazily by scalar loads, a 64-byte line at a time where the code first
+        // needs it -- one of them inside the scoring pass, i.e. behind the last row.  One dword of every line is loaded
+        // here instead, while the kernel has nothing to do but wait for the rows (r02: with the arguments in host memory
+        // the resident tail was 5.8 us instead of 2.8).
+        constexpr int KARG_DWORDS = (int)((sizeof(ScoreArgs) + sizeof(int) + sizeof(PeerArgs) + sizeof(GatherArgs)) / 4);
+        const uint32_t __attribute__((address_space(4))) *ka =
+            (const uint32_t __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+        uint32_t touched = 0u;
+#pragma unroll
+        for (int d = 0; d < KARG_DWORDS; d += 16) touched ^= ka[d];
+        asm volatile("" ::"s"(touched));
+    }
+#endif
     // (rank, section) of this thread's first pair in the flat scoring pass, and the step to its next one: the integer
     // divisions happen here, before the wait for the rows, not behind it
     const int pair_r0 = tid / max(S, 1), pair_s0 = tid - pair_r0 * S;
