@@ -556,7 +556,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def check_flagged(found):
         # correctness guard inside the bench: flagged set of the x1.5 rank at the default threshold

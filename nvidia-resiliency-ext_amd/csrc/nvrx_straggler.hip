@@ -409,14 +409,6 @@ __device__ __forceinline__ double recip_count(uint32_t c) {
     return c ? r : __builtin_inf();
 }
 
-// what a lane knows about its own keys when the streaming pass ends (24 bytes in LDS, reduced by ONE wave)
-struct LanePart {
-    uint32_t kmn, kmx;  // smallest / largest key
-    float psum, psq;    // sum(x - pivot), sum((x - pivot)^2) over the lane's samples
-    float pivot;        // the lane's first sample
-    uint32_t cnt;       // samples held
-};
-
 template <int THREADS, int VPT>
 __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__ samples,
                                                        const uint32_t *__restrict__ counts,
@@ -437,12 +429,9 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
     __shared__ __attribute__((aligned(16))) uint32_t s_sum[THREADS];
     __shared__ __attribute__((aligned(16))) uint32_t s_cand[CAND_MAX];  // compact candidate list (unused slots: 0xFFFFFFFF)
     __shared__ __attribute__((aligned(16))) uint32_t s_lt[CAND_MAX];    // per slot: how many candidates are smaller
-    __shared__ __attribute__((aligned(16))) LanePart s_part[THREADS];  // every lane's min / max / moment partials
-    __shared__ __attribute__((aligned(16))) double s_d[2];          // {row mean, sum of squared deviations}
+    __shared__ __attribute__((aligned(16))) double s_d[2 * WAVES];  // [0,W) partial sums, [W,2W) squared deviations
     __shared__ __attribute__((aligned(16))) uint32_t s_mm[4];       // {tile-0 min, tile-0 max, row min, row max}
-    __shared__ __attribute__((aligned(16))) uint32_t s_loc[4];      // first locate, done by wave 0: {bin, rank inside it, population}
     __shared__ uint32_t s_cur[1];                                   // append cursor of the candidate list
-    __shared__ uint32_t s_flag[1];                                  // a sample with a set sign bit was seen
 
     const int row = ep.rows_active ? (int)(blockIdx.x / ep.rows_active) * ep.rows_per_rank + (int)(blockIdx.x % ep.rows_active)
                                    : (int)blockIdx.x;
@@ -492,10 +481,7 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             s_lt[tid] = 0u;
         }
         if (tid < 4) s_mm[tid] = (tid & 1) ? 0u : 0xFFFFFFFFu;
-        if (tid == 0) {
-            s_cur[0] = 0u;
-            s_flag[0] = 0u;
-        }
+        if (tid == 0) s_cur[0] = 0u;
         __syncthreads();  // (0)
 
         // Tiles that are valid for every lane (i < full_tiles, block-uniform) skip the tail masking;
@@ -506,7 +492,6 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         // variance's denominator (n-1 for sections, n for kernel rows: CuptiProfiler.cpp:66-72)
         const double inv_n = recip_count(n);
         const double inv_den = kind == NVRX_KIND_KERNEL ? inv_n : recip_count(n - 1u);
-        const bool speculative = VPT > 1 && n > (uint32_t)(THREADS * 4);  // the histogram starts before the row's range is known
 
         // ---- tile 0: keys, and the range estimate the histogram is laid over ---------------------------
         uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
@@ -521,27 +506,15 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                 kmn = min(kmn, key[c]);
                 kmx = max(kmx, valid ? kk : 0u);
             }
-            // Rows longer than one tile only need an ESTIMATE here: wave 0's share of tile 0 (the row's first 256
-            // samples) gives it, the other waves go straight to the barrier.  A row that fits in one tile gets its exact
-            // range from every wave (its histogram is laid over exactly that range and never rebuilt).
             uint32_t a = kmn, b = kmx;
-            if (speculative) {
-                if (wave == 0) {
-                    wave_minmax_u32(a, b);
-                    if (lane == 0) {
-                        s_mm[0] = a;
-                        s_mm[1] = b;
-                    }
-                }
-            } else {
-                wave_minmax_u32(a, b);
-                if (lane == 0) {
-                    atomicMin(&s_mm[0], a);
-                    atomicMax(&s_mm[1], b);
-                }
+            wave_minmax_u32(a, b);
+            if (lane == 0) {
+                atomicMin(&s_mm[0], a);
+                atomicMax(&s_mm[1], b);
             }
         }
         __syncthreads();  // (1) tile-0 range
+        const bool speculative = VPT > 1 && n > (uint32_t)(THREADS * 4);
         uint32_t lo0, sh;  // histogram origin (a key) and log2 of the bin width
         {
             const uint32_t mn0 = uni(s_mm[0]), mx0 = uni(s_mm[1]);
@@ -578,8 +551,6 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                         kmx = max(kmx, kk);
                     }
                     if (NVRX_ABLATE == 0) atomicAdd(&s_hist[min(__builtin_elementwise_sub_sat(kk, lo0) >> sh, (uint32_t)(HIST_BINS - 1))], 1u);
-                    if (NVRX_ABLATE == 3)  // timing probe only (wrong counts): the same atomics without bank conflicts
-                        atomicAdd(&s_hist[(min(__builtin_elementwise_sub_sat(kk, lo0) >> sh, (uint32_t)(HIST_BINS - 1)) & ~63u) | (uint32_t)lane], 1u);
                 }
                 // moments of the tile as two packed pairs (v_pk_add_f32 / v_pk_fma_f32)
                 const f32x2 d01 = f32x2{xs[0], xs[1]} - pivot2, d23 = f32x2{xs[2], xs[3]} - pivot2;
@@ -613,83 +584,48 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         }
         psum += psum2.x + psum2.y;
         psq += psq2.x + psq2.y;
-        // The lane's partial results go to LDS as they stand: row min / max / mean / deviation are needed by the
-        // epilogue only, not by the selection, so no wave reduces anything here.  ONE wave (the last) turns the THREADS
-        // lane records into the row's values while wave 0 locates the median's bin (see locate_first).
-        {
-            LanePart rec;
-            rec.kmn = kmn;
-            rec.kmx = kmx;
-            rec.psum = psum;
-            rec.psq = psq;
-            rec.pivot = pivot;
-            rec.cnt = cnt;
-            s_part[tid] = rec;
+        wave_minmax_u32(kmn, kmx);
+        double sum = wave_sum_f64((double)psum + (double)cnt * (double)pivot);
+        if (lane == 0) {
+            atomicMin(&s_mm[2], kmn);
+            atomicMax(&s_mm[3], kmx);
+            s_d[wave] = sum;
         }
-        // Keys.  Up to here a sample's key is its raw bit pattern: for non-negative floats -- every timing row there
-        // is -- the bits order like the values, so the hot loop spends nothing on a key transform.  A set sign bit
-        // anywhere (a negative sample, -0.0, a signed NaN) shows up as a lane maximum >= 0x80000000 and raises a flag:
-        // such a row is re-keyed in its registers with the order-preserving map f2key, its range taken again, and it
-        // continues through the exact-range rebuild below (block-uniform; costs that row a few extra exchanges).
-        if (__ballot(kmx >= 0x80000000u) != 0ull && lane == 0) s_flag[0] = 1u;
         NVRX_PHASE(2);
-        __syncthreads();  // (2) histogram complete, lane records and the sign flag published
-        const bool conv = uni(s_flag[0]) != 0u;
+        __syncthreads();  // (2) histogram complete, row min / max / partial sums published
+        kmn = uni(s_mm[2]);
+        kmx = uni(s_mm[3]);
         NVRX_PHASE(3);
 
-        // The last wave's side job: THREADS lane records -> {row min, row max} in s_mm[2..3], {mean, sum of squared
-        // deviations} in s_d.  Per lane around its own pivot p: s = sum(x-p), q = sum((x-p)^2); with the row mean m the
-        // lane's exact share of sum((x-m)^2) is q - 2(m-p)s + cnt(m-p)^2; everything across lanes is f64.  The records
-        // are read twice (16 LDS reads) rather than held in registers.
-        auto reduce_records = [&]() {
-            constexpr int E = THREADS / 64;
-            uint32_t a = 0xFFFFFFFFu, b = 0u;
-            double sum = 0.0;
+        // Locate rank k in the finished histogram: every thread sums its PER consecutive bins, ONE
+        // exchange, then every wave scans all THREADS sums on its own (lane L holds sums [L*G, L*G+G)).
+        // Returns the bin; k becomes the rank inside it, pop its population (all wave-uniform).
+        auto locate = [&](uint32_t &k, uint32_t &pop) -> uint32_t {
+            {
+                uint32_t local = 0u;
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-                const LanePart r = s_part[lane + 64 * e];
-                a = min(a, r.kmn);
-                b = max(b, r.kmx);
-                sum += (double)r.psum + (double)r.cnt * (double)r.pivot;
+                for (int j = 0; j < PER; j++) local += s_hist[tid * PER + j];
+                s_sum[tid] = local;
             }
-            wave_minmax_u32(a, b);
-            const double mean = wave_sum_f64(sum) * inv_n;
-            double ss = 0.0;
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const LanePart r = s_part[lane + 64 * e];
-                const double dm = mean - (double)r.pivot;
-                ss += (double)r.psq - 2.0 * dm * (double)r.psum + (double)r.cnt * dm * dm;
-            }
-            ss = wave_sum_f64(ss);
-            if (lane == 0) {
-                s_mm[2] = a;
-                s_mm[3] = b;
-                s_d[0] = mean;
-                s_d[1] = ss;
-            }
-        };
-
-        // Locate rank k in the finished histogram.  Every thread sums its PER consecutive bins into s_sum (ONE exchange);
-        // scan_pick then walks the THREADS sums inside one wave: lane L holds sums [L*G, L*G+G), a DPP prefix scan finds the
-        // lane that owns rank k, and two more levels -- which of that lane's G thread sums, which of that thread's PER
-        // bins -- are each resolved by the lanes of the first DPP row in parallel (one value per lane, a prefix scan
-        // inside the row, a ballot).  Returns the bin; k becomes the rank inside it, pop its population (wave-uniform).
-        auto thread_sums = [&]() {
+            NVRX_SUB(0);
+            __syncthreads();  // thread sums published
+            NVRX_SUB(1);
+            uint32_t ts[G];
             uint32_t local = 0u;
 #pragma unroll
-            for (int j = 0; j < PER; j++) local += s_hist[tid * PER + j];
-            s_sum[tid] = local;
-        };
-        auto scan_pick = [&](uint32_t &k, uint32_t &pop) -> uint32_t {
-            uint32_t local = 0u;
-#pragma unroll
-            for (int g = 0; g < G; g++) local += s_sum[lane * G + g];
+            for (int g = 0; g < G; g++) {
+                ts[g] = s_sum[lane * G + g];
+                local += ts[g];
+            }
             const uint32_t incl = wave_scan_u32(local);
             const uint32_t excl = incl - local;
+            NVRX_SUB(2);
             const int L = __builtin_ctzll(__ballot(k >= excl && k < incl));  // exactly one lane owns rank k
             uint32_t krem = k - (uint32_t)__builtin_amdgcn_readlane((int)excl, L);
-            // `cnt` <= 16 values at `src`; returns the index, leaves the rank inside it in krem and the value in `picked`
+            // Two more levels, each resolved by the lanes of the first DPP row in parallel (one value per lane, a prefix
+            // scan inside the row, a ballot): which of that lane's G thread sums holds the rank, then which of that
+            // thread's PER bins.  `cnt` <= 16 values at `src`; returns the index, leaves the rank inside it in krem
+            // and the value itself in `picked`.
             auto row_pick = [&](const uint32_t *src, int cnt, uint32_t &picked) -> uint32_t {
                 const uint32_t val = lane < cnt ? src[lane & 15] : 0u;
                 uint32_t inc2 = val;
@@ -708,47 +644,37 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             const uint32_t tsel = (uint32_t)L * G + row_pick(s_sum + L * G, G, tsum);  // thread whose PER bins hold rank k
             const uint32_t bsel = row_pick(s_hist + tsel * PER, PER, pop);
             k = krem;
+            NVRX_SUB(3);
             return tsel * PER + bsel;
         };
-        // the first locate of a row (hot): wave 0 alone walks the sums and publishes {bin, k, pop}, the last wave
-        // reduces the lane records meanwhile, the others have nothing to do until the bin is known
-        auto locate_first = [&](uint32_t &k, uint32_t &pop) -> uint32_t {
-            thread_sums();
-            __syncthreads();  // (2b) thread sums published
-            if (wave == 0) {
-                uint32_t kk = k, pp = 0u;
-                const uint32_t b = scan_pick(kk, pp);
-                if (lane == 0) {
-                    s_loc[0] = b;
-                    s_loc[1] = kk;
-                    s_loc[2] = pp;
-                }
-            } else if (wave == WAVES - 1) {
-                reduce_records();
-            }
-            __syncthreads();  // (2c) the bin and the row's min / max / moments are known to everybody
-            k = uni(s_loc[1]);
-            pop = uni(s_loc[2]);
-            return uni(s_loc[0]);
+
+        // pairwise sum of WAVES per-wave partials (a 2- or 3-level tree instead of a chain of dependent f64 adds)
+        auto sum_partials = [&](const double *q) -> double {
+            double t[WAVES];
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) t[w] = q[w];
+#pragma unroll
+            for (int step = 1; step < WAVES; step *= 2)
+#pragma unroll
+                for (int w = 0; w + step < WAVES; w += 2 * step) t[w] += t[w + step];
+            return t[0];
         };
-        // any later locate (rebuilt or refined histograms: cold): every wave walks the sums on its own
-        auto locate = [&](uint32_t &k, uint32_t &pop) -> uint32_t {
-            thread_sums();
-            __syncthreads();
-            return scan_pick(k, pop);
+        // mean and this wave's share of the squared deviations (needs the partial sums of barrier (2))
+        double mean = 0.0;
+        auto finish_moments = [&]() {
+            mean = sum_partials(s_d) * inv_n;  // row sum: the same fixed pairing in every thread
+            const double dm = mean - (double)pivot;
+            const double lane_ss = (double)psq - 2.0 * dm * (double)psum + (double)cnt * dm * dm;
+            const double wss = wave_sum_f64(lane_ss);
+            if (lane == 0) s_d[WAVES + wave] = wss;
         };
 
-        uint32_t k = k_rank, pop = 0u, bin = 0u;
-        bool rebuild = conv;
-        if ((NVRX_ABLATE == 0 || NVRX_ABLATE == 3) && !conv) {
-            bin = locate_first(k, pop);
-            rebuild = speculative && (bin == 0u || bin == (uint32_t)(HIST_BINS - 1));
-        } else {
-            if (wave == WAVES - 1) reduce_records();
-            __syncthreads();
-        }
-        kmn = uni(s_mm[2]);  // the row's exact range (raw bit patterns)
-        kmx = uni(s_mm[3]);
+        // Keys.  Up to here a sample's key is its raw bit pattern: for non-negative floats -- every timing row there
+        // is -- the bits order like the values, so the hot loop spends nothing on a key transform.  A set sign bit
+        // anywhere (a negative sample, -0.0, a signed NaN) shows up as a row maximum >= 0x80000000: such a row is
+        // re-keyed in its registers with the order-preserving map f2key, its range taken again, and it continues
+        // through the exact-range rebuild below (block-uniform; costs that row a few extra exchanges).
+        const bool conv = kmx >= 0x80000000u;
         if (conv) {
             uint32_t a = 0xFFFFFFFFu, b = 0u;
 #pragma unroll
@@ -777,10 +703,18 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
         auto key_value = [&](uint32_t kk) -> float { return conv ? key2f(kk) : __uint_as_float(kk); };
 
         uint32_t med_key;
-        if ((NVRX_ABLATE != 0 && NVRX_ABLATE != 3) || kmn == kmx) {
+        if (NVRX_ABLATE != 0 || kmn == kmx) {
             med_key = kmn;  // all samples equal (or selection ablated)
+            finish_moments();
+            __syncthreads();
         } else {
+            uint32_t k = k_rank, pop = 0u, bin = 0u;
             path = 1;
+            bool rebuild = conv;
+            if (!conv) {
+                bin = locate(k, pop);
+                rebuild = speculative && (bin == 0u || bin == (uint32_t)(HIST_BINS - 1));
+            }
             if (rebuild) {
                 // The estimate missed (the edge bins also hold everything that was clamped), or the row was re-keyed:
                 // rebuild the histogram over the exact range (nothing is clamped any more) and locate again.
@@ -788,7 +722,6 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                 lo0 = kmn;
                 const int top = 32 - __clz((int)(kmx - kmn));
                 sh = (uint32_t)(top > HIST_BITS ? top - HIST_BITS : 0);
-                __syncthreads();  // every wave is done reading s_hist / s_sum
 #pragma unroll
                 for (int j = 0; j < PER; j++) s_hist[tid * PER + j] = 0u;
                 __syncthreads();
@@ -801,52 +734,81 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
             }
             uint32_t base = lo0 + (bin << sh);  // first key of the bin that holds the median
             NVRX_PHASE(4);
+            bool moments_done = false;
             const bool all_waves_finish = kind == NVRX_KIND_KERNEL && (n & 1u) == 0u;
             while (sh > 0u) {
                 if (pop <= (uint32_t)CAND_MAX) {
                     // ---- finish by ranking the bin's few members directly ----------------------------------
-                    // Collect the 20-40 members into a compact list.  Pass 1 over the keys costs two instructions each (the
-                    // distance to the bin's first key, a compare): the wave's member count comes from the compare masks
-                    // on the scalar unit, together with one bit per key slot that holds a member in SOME lane (about
-                    // four of the twenty slots).  One returning LDS add reserves the wave's stretch of the list (issued
-                    // by hand: the compiler's uniform-atomic rewrite would wait for the result on the spot); pass 2 then
-                    // revisits only the marked slots and places their members by mask prefix counts.
+                    // One branch-free stream over the keys: membership compare, the wave's member count from the
+                    // compare masks on the scalar unit, and per lane its own member count, its last member and the XOR
+                    // of its members.  One returning LDS add reserves the wave's stretch of the compact candidate list
+                    // (issued by hand: the compiler's uniform-atomic rewrite would wait for the result on the spot); its
+                    // latency hides under the moments.  Lanes holding one or two members -- all of them, bar one
+                    // workgroup in thirty -- place them from a prefix scan of the counts (two members: last, and
+                    // XOR ^ last); a wave in which some lane holds three or more revisits its keys one by one instead.
                     uint32_t wcnt = 0u, wbase = 0u;
-                    if constexpr (NKEY <= 32) {
-                        const uint32_t width = 1u << sh;  // sh <= 32 - HIST_BITS
-                        uint32_t slots = 0u;
+                    if constexpr (NKEY <= 24) {
+                        uint32_t mcnt = 0u, mcnt_hi = 0u, last = 0u, last_hi = 0u, mxor = 0u, mxor_hi = 0u;
 #pragma unroll
                         for (int j = 0; j < NKEY; j++) {
-                            const uint32_t c = (uint32_t)__popcll(__ballot(key[j] - base < width));  // wraps to a huge value below the bin
-                            wcnt += c;
-                            slots |= c ? (1u << j) : 0u;
+                            const uint32_t r = key[j] - base;  // wraps to a huge value below the bin
+                            const bool member = (r >> sh) == 0u;
+                            wcnt += (uint32_t)__popcll(__ballot(member));
+                            if (j < NKEY / 2) {  // two half-length chains per quantity
+                                mcnt += member ? 1u : 0u;
+                                last = member ? r : last;
+                                mxor ^= member ? r : 0u;
+                            } else {
+                                mcnt_hi += member ? 1u : 0u;
+                                last_hi = member ? r : last_hi;
+                                mxor_hi ^= member ? r : 0u;
+                            }
                         }
+                        last = mcnt_hi ? last_hi : last;
+                        mcnt += mcnt_hi;
+                        mxor ^= mxor_hi;
+                        NVRX_SUB(4);
                         if (lane == 0 && wcnt) {
                             const uint32_t cur_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)s_cur;
                             asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(wbase) : "v"(cur_addr), "v"(wcnt) : "memory");
                         }
+                        if (!moments_done) {
+                            finish_moments();
+                            moments_done = true;
+                        }
+                        NVRX_SUB(5);
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wbase) : : "memory");
                         wbase = uni(wbase);
                         if (wcnt) {  // wave-uniform
-                            uint32_t run = wbase;
+                            if (__ballot(mcnt > 2u) == 0ull) {
+                                const uint32_t pos = wbase + wave_scan_u32(mcnt) - mcnt;
+                                if (mcnt >= 1u && pos < (uint32_t)CAND_MAX) s_cand[pos] = last;
+                                if (mcnt >= 2u && pos + 1u < (uint32_t)CAND_MAX) s_cand[pos + 1u] = mxor ^ last;
+                            } else {
+                                uint32_t run = wbase;
 #pragma unroll
-                            for (int j = 0; j < NKEY; j++) {
-                                if (slots & (1u << j)) {  // wave-uniform
+                                for (int j = 0; j < NKEY; j++) {
                                     const uint32_t r = key[j] - base;
-                                    const bool member = r < width;
+                                    const bool member = (r >> sh) == 0u;
                                     const unsigned long long b = __ballot(member);
-                                    const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-                                    if (member && pos < (uint32_t)CAND_MAX) s_cand[pos] = r;
-                                    run += (uint32_t)__popcll(b);
+                                    if (b) {  // wave-uniform
+                                        const uint32_t pos = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                                        if (member && pos < (uint32_t)CAND_MAX) s_cand[pos] = r;
+                                        run += (uint32_t)__popcll(b);
+                                    }
                                 }
                             }
                         }
                     } else {
-                        // long register tiles: count first, then revisit mask by mask
+                        // long register tiles (more masks than SGPRs): count first, then revisit mask by mask
 #pragma unroll
                         for (int j = 0; j < NKEY; j++) wcnt += (uint32_t)__popcll(__ballot(((key[j] - base) >> sh) == 0u));
                         if (lane == 0 && wcnt) wbase = atomicAdd(&s_cur[0], wcnt);
                         wbase = uni(wbase);
+                        if (!moments_done) {
+                            finish_moments();
+                            moments_done = true;
+                        }
                         if (wcnt) {  // wave-uniform
                             uint32_t run = wbase;
 #pragma unroll
@@ -862,33 +824,39 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                             }
                         }
                     }
-                    __syncthreads();  // (3) candidates listed (unused slots hold 0xFFFFFFFF)
+                    NVRX_SUB(6);
+                    __syncthreads();  // candidates listed (unused slots hold 0xFFFFFFFF), deviation partials published
+                    NVRX_SUB(7);
                     NVRX_PHASE(5);
                     if (pop <= (uint32_t)CAND_ONE) {
-                        // Few enough for one wave: lane L owns candidate L and the wave walks the bits of the bin's key
-                        // range from the top -- a radix select whose every step is one compare per lane plus scalar mask
-                        // arithmetic: `live` = the candidates still in the race, k = the rank wanted among them; a step
-                        // keeps the zeros if there are more than k of them, else the ones.  It ends when one candidate
-                        // is left (or all that are left are equal).  Nothing is exchanged any more: section rows are
-                        // finished by wave 0 alone (only thread 0 stores results; the other waves are done and leave the
-                        // SIMDs to it), kernel rows with an even count need the median in every wave for their second
-                        // middle element, so every wave selects.
+                        // Few enough for one wave: lane L owns candidate L and counts the candidates below it (the list is
+                        // read as LDS broadcasts, 32 slots per batch of loads); the value at rank k is the largest
+                        // candidate with lt <= k (empty slots compare as +inf: lt = pop > k).  Nothing is exchanged
+                        // any more: section rows are finished by wave 0 alone (only thread 0 stores results; the other
+                        // waves are done and leave the SIMDs to it), kernel rows with an even count need the median in
+                        // every wave for their second middle element, so every wave ranks.
                         if (wave != 0 && !all_waves_finish) {
                             sh = 0u;
                             break;
                         }
                         const uint32_t own = s_cand[lane];
-                        unsigned long long live = pop >= 64u ? ~0ull : ((1ull << pop) - 1ull);
-                        uint32_t kk = k;
-                        for (uint32_t bit = 1u << (sh - 1u); bit != 0u && (live & (live - 1ull)) != 0ull; bit >>= 1) {
-                            const unsigned long long ones = __ballot((own & bit) != 0u) & live;
-                            const unsigned long long zeros = live & ~ones;
-                            const uint32_t c0 = (uint32_t)__popcll(zeros);
-                            const bool low = kk < c0;
-                            live = low ? zeros : ones;
-                            kk -= low ? 0u : c0;
+                        uint32_t lt0 = 0u, lt1 = 0u, lt2 = 0u, lt3 = 0u;  // four short add chains instead of one long one
+#pragma unroll
+                        for (int half = 0; half < CAND_ONE / 32; half++) {
+                            if (half == 0 || pop > (uint32_t)(half * 32)) {  // wave-uniform
+                                uint4 v[8];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) v[q] = reinterpret_cast<const uint4 *>(s_cand)[half * 8 + q];
+#pragma unroll
+                                for (int q = 0; q < 8; q++) {
+                                    lt0 += (v[q].x < own) ? 1u : 0u;
+                                    lt1 += (v[q].y < own) ? 1u : 0u;
+                                    lt2 += (v[q].z < own) ? 1u : 0u;
+                                    lt3 += (v[q].w < own) ? 1u : 0u;
+                                }
+                            }
                         }
-                        base += (uint32_t)__builtin_amdgcn_readlane((int)own, __builtin_ctzll(live));
+                        base += wave_max_u32((lt0 + lt1) + (lt2 + lt3) <= k ? own : 0u);
                     } else {
                         // All-pairs ranking split over the waves: every lane owns 4 of the CAND_MAX slots, each
                         // wave compares all owners with ITS OWN members only and adds its partial "smaller than"
@@ -935,7 +903,12 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                 base += bin << sh2;
                 sh = sh2;
             }
+            if (!moments_done) {
+                finish_moments();
+                __syncthreads();
+            }
             med_key = base;
+            NVRX_SUB(8);
             NVRX_PHASE(6);
         }
         const uint32_t dsel = med_key - kmn;
@@ -972,13 +945,14 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
 
         if (wave != 0) return;  // thread 0 stores the row's results: the other waves are done
         NVRX_PHASE(7);
-        // mean and squared deviations were published by the last wave before barrier (2c)
-        const double mean = s_d[0], ss = s_d[1];
+        // squared-deviation partials were published before the last barrier each path went through
+        const double ss = sum_partials(s_d + WAVES);
         r_min = key_value(kmn);
         r_max = key_value(kmx);
         r_med = med;
         r_avg = (float)mean;
         r_std = (kind == NVRX_KIND_KERNEL || n > 1u) ? sqrtf((float)(ss * inv_den)) : __builtin_nanf("");
+        NVRX_SUB(9);
     }
 
     if (tid == 0) {
