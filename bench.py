@@ -586,8 +586,10 @@ def main():
         ts = time.perf_counter_ns()
         rep, found = step()
         per_step.append(time.perf_counter_ns() - ts)
+    t_loop = time.perf_counter()
     sync_all()
     elapsed = time.perf_counter() - t0
+    closing_sync_us = (time.perf_counter() - t_loop) * 1e6
     if rank == 0:
         check_flagged(found)  # the last timed report
 
@@ -743,6 +745,11 @@ def main():
             "reports_per_s": round(1e6 / us_per_report, 1),
             "us_per_report_median": round(float(np.median(per_step)) / 1e3, 2),
             "us_per_report_p95": round(float(np.percentile(per_step, 95)) / 1e3, 2),
+            # what separates `value` (the whole bracketed region / K) from the median step: the first step after the opening
+            # device synchronize, and the closing synchronize itself (a marker on every queue the reports used: ~12 us per
+            # stream even when its work is long done), both divided by K
+            "timed_region": {"first_step_us": round(per_step[0] / 1e3, 2), "closing_synchronize_us": round(closing_sync_us, 2),
+                             "sum_of_steps_us": round(sum(per_step) / 1e3, 2), "region_us": round(elapsed * 1e6, 2)},
             "instrumented_ms_per_step": round(elapsed_instr / args.steps * 1e3, 5),
             "roofline": {
                 "bound": "hbm",

@@ -191,6 +191,10 @@ class Workspace:
         """A private copy of meta | scores | flags (valid once meta[4] shows the report's sequence number)."""
         return self._host[: self._off_stats].copy()
 
+    def host_head_bytes(self) -> bytes:
+        """The same as ``bytes``: one memcpy out of the pinned block, no numpy object involved."""
+        return ctypes.string_at(self.h_ptr, self._off_stats)
+
     def host_stats(self, rows: int) -> np.ndarray:
         """A private copy of the first ``rows`` statistics rows (valid once meta[5] shows the sequence number)."""
         return self.stats[:rows].copy()

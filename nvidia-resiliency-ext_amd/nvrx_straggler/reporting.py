@@ -107,19 +107,28 @@ class _LiveBlock:
     calls ``detach()`` before anything reuses the block -- which copies only if somebody still holds the report.  The
     statistics rows have a completion word of their own (a resident score kernel forwards them after the scores)."""
 
-    __slots__ = ("backend", "ws", "seq", "rows", "_head", "_stats", "__weakref__")
+    __slots__ = ("backend", "ws", "seq", "rows", "_head", "_head_bytes", "_stats", "__weakref__")
 
     def __init__(self, backend, ws, seq: int, rows: int):
         self.backend, self.ws, self.seq, self.rows = backend, ws, seq, rows
         self._head: Optional[np.ndarray] = None
+        self._head_bytes: Optional[bytes] = None
         self._stats: Optional[np.ndarray] = None
+
+    def head_bytes(self) -> bytes:
+        """meta | scores | flags as ONE ``bytes`` copy of the block (a single memcpy; the flag path of
+        ``identify_stragglers`` needs nothing else of the block and nothing of numpy)."""
+        if self._head_bytes is None:
+            with _LIVE_LOCK:
+                if self._head_bytes is None:
+                    grab = getattr(self.ws, "host_head_bytes", None)
+                    self._head_bytes = grab() if grab is not None else self.ws.host_head().tobytes()
+                    self._release()
+        return self._head_bytes
 
     def head(self) -> np.ndarray:
         if self._head is None:
-            with _LIVE_LOCK:
-                if self._head is None:
-                    self._head = self.ws.host_head()
-                    self._release()
+            self._head = np.frombuffer(self.head_bytes(), dtype=np.uint8)  # read-only view of the private copy
         return self._head
 
     def stats(self) -> np.ndarray:
@@ -136,7 +145,7 @@ class _LiveBlock:
         self.stats()
 
     def _release(self) -> None:
-        if self._head is not None and self._stats is not None:
+        if self._head_bytes is not None and self._stats is not None:
             self.backend = self.ws = None  # nothing of the live workspace is referenced any more
 
 
@@ -233,6 +242,13 @@ class _ScoreSource:
                     self.cut(pend if t is np.ndarray else pend.wait())
                 self.pending = None
         return self
+
+    def flag_bytes(self) -> bytes:
+        """This report's flag rows ([ranks, 2+2S] u8, row-major) as ``bytes``."""
+        if self.scores is None and type(self.pending) is _LiveBlock:
+            _, off_f, _, _, W, lo, hi, _ = self.view.layout
+            return self.pending.head_bytes()[off_f + lo * W : off_f + hi * W]
+        return self.ensure().flags.tobytes()
 
     def device_flags(self) -> "_DeviceFlags":
         v = self.view
@@ -442,17 +458,20 @@ class _DeviceFlags:
         rows come from two reductions over the table and only flagged columns are visited.  ``memo`` (a dict shared by
         the reports of one plan): a straggler usually stays one for many reports, so the result for an unchanged flag
         table is kept and handed out as fresh copies (a set copy does not re-hash its members)."""
-        f, S = self._array(), self.S
+        S = self.S
         wrap = set if ids is not None else list
-        if not np.count_nonzero(f):  # (a plain C loop: a third of the cost of the ufunc reduction behind f.any())
+        src = self.flags
+        fb = src.flag_bytes() if isinstance(src, _ScoreSource) else src.tobytes()
+        if fb.count(0) == len(fb):  # (bytes.count: one C loop, no numpy call on the common path)
             return wrap(), wrap(), {}, {}
         key = None
         if memo is not None and ids is not None:
-            key = f.tobytes()
+            key = fb
             hit = memo.get("flags")
             if hit is not None and hit[0] == key and hit[1] is ids:
                 gr, gi, sr, si = hit[2]
                 return gr.copy(), gi.copy(), {n: v.copy() for n, v in sr.items()}, {n: v.copy() for n, v in si.items()}
+        f = self._array()
         who = ids if ids is not None else self.ranks
         cnt = f.sum(axis=0, dtype=np.int32).tolist()
         first = f.argmax(axis=0).tolist()
