@@ -1,0 +1,59 @@
+"""The driver's contract with bench.py, on the GPU box: `python bench.py --gpus N ...` WITHOUT a launcher must start its own
+ranks and print ONE JSON line from rank 0 (the old bench exited with "launch with torch.distributed.run").
+Ranks share the one GPU here over gloo; on a multi-GPU node the same path runs one rank per GPU over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAST = ["--no-cpu-baseline", "--no-overhead", "--no-host-inputs", "--no-extra-legs", "--no-cadence"]
+
+
+def _run(args, env=None, timeout=240):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=e,
+                       cwd=REPO)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    return r, lines
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_has_the_contract_fields_and_the_round3_legs():
+    r, lines = _run(["--gpus", "1", "--steps", "6", "--warmup", "2", "--dump-steps"] + FAST)
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is False and d["unit"] == "us"
+    assert abs(d["value"] - d["ms_per_step"] * 1e3) < 0.02 and len(d["per_step_us"]) == 6
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    # the timed steps are held and read: the read shows up as a leg of its own, and value covers the whole bracketed region
+    assert d["report_read"]["identify_stragglers_us"] > 0 and d["us_per_report_fully_read"] > d["value"]
+    tr = d["timed_region"]
+    assert tr["region_us"] >= tr["sum_of_steps_us"] and abs(tr["region_us"] / 6 - d["value"]) < 0.5
+
+
+@pytest.mark.gpu
+def test_gpus_2_without_a_launcher_spawns_its_own_ranks():
+    r, lines = _run(["--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2"] + FAST)
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["logical_ranks_per_gpu"] == 4 and d["config"]["rows_per_gpu"] == 256
+    assert d["exchange"]["bytes_per_rank"] == 4 * 129 * 4 and d["exchange"]["us_median"] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_needs_one_gpu_per_rank_and_says_so():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU node: the RCCL path itself would run")
+    r, lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"] + FAST, timeout=120)
+    assert r.returncode != 0 and not lines
+    assert "RCCL" in (r.stderr + r.stdout) and "--backend gloo" in (r.stderr + r.stdout)
