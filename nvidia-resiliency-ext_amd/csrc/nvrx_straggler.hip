@@ -1793,6 +1793,15 @@ struct nvrx_ctx {
     int wall_khz = 100000;
     int resident_mode = 1;  // NVRX_RESIDENT_SCORER / NVRX_POLL_NAPS as they stood when the context was created
     int poll_naps = 4;
+    int rehome_mode = 1;    // NVRX_REPORT_REHOME: synchronous reports may run ON the one stream they must follow
+    // work of ours that may still be running on a stream a re-homed report would not be ordered after (a staging flush
+    // forced by a full buffer, device-side appends, bulk appends, history resets, asynchronous reports); cleared when
+    // a synchronous report on the context's own stream has completed
+    bool side_work = true;
+    // a re-homed synchronous report does not record the staging buffer's "scatter done" event either: its own
+    // completion word says so (the scatter runs in front of it on the same stream)
+    bool defer_flush_event = false;
+    int deferred_buf = -1;
     hipEvent_t report_ev = nullptr;
     uint64_t report_epoch = 0;  // bumped by every guarded report
     struct StreamEpoch {
@@ -1864,7 +1873,10 @@ int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, in
                        ctx->meta_dirty ? ctx->h_kinds : nullptr, ctx->d_kinds,
                        ctx->meta_dirty ? ctx->h_gid : nullptr, ctx->d_gid);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b.done, stream));
+    if (ctx->defer_flush_event && !ctx->meta_dirty)
+        ctx->deferred_buf = ctx->cur;
+    else
+        HIP_TRY(hipEventRecord(b.done, stream));
     b.in_flight = true;
     if (ctx->meta_dirty) {
         // h_kinds/h_gid are read by the kernel just launched: do not let the host modify them until
@@ -1888,6 +1900,7 @@ inline int push_locked(nvrx_ctx *ctx, int row, float value) {
     if (ctx->n_staged == ctx->stage_cap) {
         int rc = flush_locked(ctx, ctx->default_stream);
         if (rc) return rc;
+        ctx->side_work = true;
     }
     const uint32_t slot = (uint32_t)(ctx->total[row] % (uint64_t)ctx->ring_cap);
     StagedSample &e = ctx->buf[ctx->cur].h_entries[ctx->n_staged++];
@@ -2060,6 +2073,10 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     ctx->total.assign((size_t)ctx->rows, 0);
     ctx->resident_mode = resident_scorer_mode_from_env();
     ctx->poll_naps = poll_naps_from_env();
+    {
+        const char *e = getenv("NVRX_REPORT_REHOME");
+        ctx->rehome_mode = (e && atoi(e) == 0) ? 0 : 1;
+    }
 
 #define CTX_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -2225,6 +2242,7 @@ int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values
     if (!ctx || (n > 0 && (!rows || !values)) || n < 0) return fail(NVRX_ERR_INVALID, "bad arguments");
     if (n == 0) return NVRX_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->side_work = true;  // (a later report is only re-homed onto another stream once this is known to be done)
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
     hipStream_t st = ctx->default_stream;
@@ -2296,6 +2314,7 @@ int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, 
     if (n < 0 || (n > 0 && !d_values)) return fail(NVRX_ERR_INVALID, "bad d_values/n");
     if (n == 0) return NVRX_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->side_work = true;  // (a later report is only re-homed onto another stream once this is known to be done)
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
@@ -2375,6 +2394,7 @@ int nvrx_ring_reset(nvrx_ctx *ctx) {
 int nvrx_history_reset(nvrx_ctx *ctx, void *stream) {
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->side_work = true;  // (a later report is only re-homed onto another stream once this is known to be done)
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
     hipLaunchKernelGGL(k_fill_f32, dim3((ctx->rows + 255) / 256), dim3(256), 0, as_stream(stream), ctx->d_hist_min,
@@ -2386,6 +2406,7 @@ int nvrx_history_reset(nvrx_ctx *ctx, void *stream) {
 int nvrx_ring_flush(nvrx_ctx *ctx, void *stream) {
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->side_work = true;  // (a later report is only re-homed onto another stream once this is known to be done)
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
     return flush_locked(ctx, as_stream(stream));
@@ -2614,7 +2635,35 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     const bool exchanging = d->allgather_fn != nullptr;
     if (exchanging && (!d->d_table || d->d_table == d->d_send || d->send_count <= 0))
         return fail(NVRX_ERR_INVALID, "an exchange needs a separate table buffer and a positive send_count");
-    if (d->order_after_enabled && d->order_after_stream != stream) {
+    // Re-homing.  A synchronous report that has to follow the work of exactly ONE other stream -- the stream the
+    // region stamps of this window were launched on and / or the caller's current stream -- is enqueued ON that stream:
+    // the stream order is the dependency, and the report issues nothing but kernel launches.  The event record +
+    // stream-wait pairs it replaces are cheap between two reports a millisecond apart, but a report at production
+    // cadence (one per ~60 s, S/straggler.py:125) meets them cold: 75 us of the 98 us the call took went into them
+    // (tools/cadence_detector_breakdown.py), against 3 us for each of the launches, whose code the training loop keeps
+    // warm.  Not for asynchronous reports (they are meant to run BESIDE the next step; re-homed they measured 2.7 % per
+    // step instead of 2.0-2.4 % and no gain at cadence), not while work of ours may still be running on the context's
+    // own stream (side_work), NVRX_REPORT_REHOME=0 turns it off.
+    bool rehomed = false;
+    if (d->h_seq_word && !d->guard_rings && ctx->rehome_mode) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        hipStream_t only = nullptr;
+        int distinct = 0;
+        auto see = [&](hipStream_t s) {
+            if (distinct == 0 || s != only) {
+                only = s;
+                distinct++;
+            }
+        };
+        for (hipStream_t s : ctx->stamp_streams) see(s);
+        if (d->order_after_enabled) see(as_stream(d->order_after_stream));
+        if (distinct == 1 && only != as_stream(stream) && !ctx->side_work && !ctx->timing) {
+            stream = only;
+            rehomed = true;
+            ctx->stamp_streams.clear();
+        }
+    }
+    if (!rehomed && d->order_after_enabled && d->order_after_stream != stream) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         HIP_TRY(hipEventRecord(ctx->order_ev, as_stream(d->order_after_stream)));
         HIP_TRY(hipStreamWaitEvent(as_stream(stream), ctx->order_ev, 0));
@@ -2629,7 +2678,7 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     // per step with a report every step) -- so it is used when the report has nothing to wait for: 64 rows 21.2 vs 22.4
     // us per report, 512 rows (two row workgroups on every CU, the score kernel squeezed in beside two of them) 24.2-25.9
     // resident vs 24.0-24.4 queued depending on the box, with the statistics kernel itself at 8.5 instead of 9.9 us.
-    bool cross_stream = d->order_after_enabled && d->order_after_stream != stream;
+    bool cross_stream = rehomed || (d->order_after_enabled && d->order_after_stream != stream);
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         cross_stream = cross_stream || !ctx->stamp_streams.empty();
@@ -2684,10 +2733,33 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         if (rc2) return rc2;
         if (*static_cast<volatile uint32_t *>(ctx->h_gather_err) == ctx->gran_epoch)
             return fail(NVRX_ERR_TIMEOUT, "the score kernel gave up waiting for the statistics kernel's rows (epoch %u)", ctx->gran_epoch);
+        if (as_stream(stream) == ctx->default_stream) {
+            // every row's granules were consumed: the statistics kernel, last on the context's in-order stream, is done
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            ctx->side_work = false;
+        }
         return NVRX_OK;
     }
+    ctx->defer_flush_event = rehomed;
+    ctx->deferred_buf = -1;
     int rc = nvrx_report_local(ctx, d->d_stats, d->d_send, d->K, d->S, d->names_ok, d->rows_active, stream);
-    if (rc) return rc;
+    ctx->defer_flush_event = false;
+    // the staging buffer whose "scatter done" event was not recorded: released by the completion word, or -- on any
+    // failure below -- given its event after all
+    auto settle_deferred = [&](bool done) {
+        if (ctx->deferred_buf < 0) return;
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        StageBuf &db = ctx->buf[ctx->deferred_buf];
+        if (done)
+            db.in_flight = false;
+        else
+            (void)hipEventRecord(db.done, as_stream(stream));
+        ctx->deferred_buf = -1;
+    };
+    if (rc) {
+        settle_deferred(false);
+        return rc;
+    }
     if (d->guard_rings) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         HIP_TRY(hipEventRecord(ctx->report_ev, as_stream(stream)));
@@ -2699,7 +2771,10 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         score_fits_single_wg(d->R, d->K, d->S, d->d_scores, d->d_flags) && peer_prologue_enabled()) {
         // peer windows + a table the single-workgroup score kernel takes: the exchange runs as that kernel's prologue
         rc = peer_fill_args(static_cast<nvrx_peer *>(d->comm), d->d_send, d->d_table, (size_t)d->send_count, &pa);
-        if (rc) return rc;
+        if (rc) {
+            settle_deferred(false);
+            return rc;
+        }
         prologue = true;
     } else if (exchanging) {
         // ncclAllGather(sendbuff, recvbuff, sendcount, ncclFloat32 = 7, comm, stream), enqueued between the two
@@ -2707,14 +2782,34 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         using AllGatherFn = int (*)(const void *, void *, size_t, int, void *, void *);
         const int nrc = reinterpret_cast<AllGatherFn>(d->allgather_fn)(d->d_send, d->d_table, (size_t)d->send_count, 7,
                                                                        d->comm, stream);
-        if (nrc != 0) return fail(NVRX_ERR_HIP, "all-gather of the exchange rows failed (ncclResult %d)", nrc);
+        if (nrc != 0) {
+            settle_deferred(false);
+            return fail(NVRX_ERR_HIP, "all-gather of the exchange rows failed (ncclResult %d)", nrc);
+        }
     }
     d->seq = (d->seq % 0x7FFFFFFFu) + 1u;
     rc = score_launch(exchanging ? d->d_table : d->d_send, d->R, d->K, d->S, d->do_indiv, d->do_rel, d->thresholds,
                       d->d_scores, d->d_flags, d->d_meta, d->d_done_counter, d->seq, d->d_stats, d->d_stats_dst,
                       d->stats_rows, stream, prologue ? &pa : nullptr);
-    if (rc) return rc;
-    if (d->h_seq_word) return nvrx_poll_u32(d->h_seq_word, d->seq, d->timeout_s > 0.0 ? d->timeout_s : 1e30);
+    if (rc) {
+        settle_deferred(false);
+        return rc;
+    }
+    if (d->h_seq_word) {
+        rc = nvrx_poll_u32(d->h_seq_word, d->seq, d->timeout_s > 0.0 ? d->timeout_s : 1e30);
+        settle_deferred(rc == NVRX_OK);
+        if (rc == NVRX_OK && !rehomed && as_stream(stream) == ctx->default_stream) {
+            // the completion word was stored by the last kernel of this report on the context's own in-order stream:
+            // everything of ours enqueued there before it has finished
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            ctx->side_work = false;
+        }
+        return rc;
+    }
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->side_work = true;  // an asynchronous report is in flight on this stream
+    }
     return NVRX_OK;
 }
 

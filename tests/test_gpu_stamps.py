@@ -92,3 +92,34 @@ def test_nested_regions_and_unmatched_end():
             rings.stamp_end(a, st)
     finally:
         rings.close()
+
+
+@pytest.mark.parametrize("rehome", ["1", "0"])
+def test_synchronous_report_follows_the_regions_it_reads_without_a_host_wait(monkeypatch, rehome):
+    """A synchronous ``Detector.generate_report()`` issued while the GPU is still busy with the very region it has to
+    report: the report must contain THIS window's device-stamped sample (count and magnitude), for the re-homed route
+    (the report's kernels enqueued on the stamps' own stream, no events: ``NVRX_REPORT_REHOME=1``, the default once the
+    context's own stream is known to be idle) and for the event-ordered route (``=0``).  Alternating regions of very
+    different length make a report that ran ahead of its stamp read the PREVIOUS window's value or none at all."""
+    from nvrx_straggler import Detector, Statistic
+
+    monkeypatch.setenv("NVRX_REPORT_REHOME", rehome)
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n")
+    try:
+        _spin(0.1)
+        torch.cuda.synchronize()
+        for i in range(12):
+            ms = 3.0 if i % 2 else 0.6
+            with Detector.detection_section("cpu_only", profile_cuda=False):
+                pass
+            with Detector.detection_section("region", profile_cuda=True):
+                _spin(ms)
+            rep = Detector.generate_report()          # the host is ~ms ahead of the GPU here
+            got = rep.local_kernel_summaries["hipevent::region"]
+            assert got[Statistic.NUM] == 1, (i, got)
+            assert 0.5 * ms * 1e3 < got[Statistic.MED] < 3.0 * ms * 1e3, (i, ms, got)   # microseconds
+            assert rep.local_section_summaries["cpu_only"][Statistic.NUM] == 1
+            assert rep.local_section_summaries["region"][Statistic.NUM] == 1
+            assert abs(rep.gpu_relative_perf_scores[0] - 1.0) < 1e-6
+    finally:
+        Detector.shutdown()

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Detector.generate_report() at production cadence (config #2: 4 sections per step, 2 GPU-timed, one report per 100
+steps), cold: which stage costs what.  Stages are timed by wrapping the callables the method goes through."""
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "nvidia-resiliency-ext_amd"), os.path.join(REPO, "tests", "golden")):
+    sys.path.insert(0, p)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from nvrx_straggler import Detector  # noqa: E402
+
+marks = {}
+
+
+def wrap(obj, name, label):
+    fn = getattr(obj, name)
+
+    def timed(*a, **k):
+        t0 = time.perf_counter_ns()
+        try:
+            return fn(*a, **k)
+        finally:
+            marks[label] = marks.get(label, 0) + time.perf_counter_ns() - t0
+
+    setattr(obj, name, timed)
+
+
+x = torch.randn(4096, 4096, dtype=torch.bfloat16, device="cuda")
+
+
+def work(n):
+    y = x
+    for _ in range(n):
+        y = torch.matmul(x, y)
+
+
+Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n")
+wrap(Detector.cupti_manager, "harvest", "harvest")
+wrap(Detector.rings, "counts", "rings.counts")
+wrap(Detector.rings, "report_fused", "rings.report_fused (Python + C call)")
+wrap(Detector.rings.lib, "nvrx_report", "  nvrx_report (C)")
+wrap(Detector.rings, "reset", "rings.reset")
+wrap(Detector.reporter, "generate_report_from_rings", "reporter.generate_report_from_rings")
+import ctypes  # noqa: E402
+
+dbg = getattr(ctypes.CDLL(os.path.join(os.environ["NVRX_LIB_DIR"], "libnvrx_straggler_hip.so")), "nvrx_debug_clocks", None) \
+    if os.environ.get("NVRX_LIB_DIR") else None
+clk = (ctypes.c_double * 8)()
+rows = []
+for cadence in (True, False):
+    acc = []
+    for i in range(24 if cadence else 60):
+        n_steps = 100 if cadence else 1
+        for _ in range(n_steps):
+            with Detector.detection_section("data", profile_cuda=False):
+                pass
+            with Detector.detection_section("forward", profile_cuda=True):
+                work(4 if cadence else 1)
+            with Detector.detection_section("backward", profile_cuda=True):
+                work(6 if cadence else 1)
+            with Detector.detection_section("optimizer", profile_cuda=False):
+                pass
+        torch.cuda.synchronize()
+        marks.clear()
+        t0 = time.perf_counter_ns()
+        rep = Detector.generate_report()
+        t1 = time.perf_counter_ns()
+        rep.identify_stragglers()
+        t2 = time.perf_counter_ns()
+        if dbg is not None:
+            dbg(clk)
+            marks["C: enter -> after event waits (order_after_stamps) + flush"] = int((clk[5] - clk[0]) * 1e3)
+            marks["C: launch of k_row_stats"] = int((clk[2] - clk[5]) * 1e3)
+            marks["C: launch of k_score1"] = int((clk[3] - clk[2]) * 1e3)
+            marks["C: poll for the completion word"] = int((clk[4] - clk[3]) * 1e3)
+        if i >= 4:
+            d = dict(marks)
+            d["TOTAL generate_report"] = t1 - t0
+            d["identify_stragglers"] = t2 - t1
+            acc.append(d)
+    print("=== one report per 100 training steps (cold)" if cadence else "=== a report every step, tiny steps (warm)")
+    for k in ("TOTAL generate_report", "harvest", "rings.counts", "reporter.generate_report_from_rings", "rings.report_fused (Python + C call)",
+              "  nvrx_report (C)", "C: enter -> after event waits (order_after_stamps) + flush", "C: launch of k_row_stats",
+              "C: launch of k_score1", "C: poll for the completion word", "rings.reset", "identify_stragglers"):
+        v = [a.get(k, 0) for a in acc]
+        print(f"  {k:44s} median {np.median(v)/1e3:7.1f} us   p95 {np.percentile(v,95)/1e3:7.1f}")
+Detector.shutdown()
