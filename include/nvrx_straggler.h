@@ -200,6 +200,10 @@ int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S
 /* A whole report in ONE call: flush -> row statistics -> [all-gather of the exchange rows] -> scoring of the
  * table -> (optionally) wait for the completion word.  The descriptor is filled once per report shape and reused;
  * the library advances `seq` itself, so a steady-state report is a single FFI crossing.
+ * `stream` is where the report runs unless it is RE-HOMED: a synchronous report (h_seq_word given, guard_rings 0) that
+ * must follow the work of exactly one other stream -- the stream the window's region stamps (nvrx_stamp_end) were
+ * launched on and / or order_after_stream -- is enqueued on THAT stream instead, so that the stream order is the
+ * dependency and no event is recorded or waited for (NVRX_REPORT_REHOME=0 keeps it on `stream` behind event waits).
  * Replaces Detector.generate_report's body (straggler.py:236-239) + ReportGenerator.generate_report
  * (reporting.py:421-554) for the case where the summaries never leave the device. */
 typedef struct nvrx_report_desc {
