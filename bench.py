@@ -458,6 +458,14 @@ def _detector_leg(steps, warmup):
         CustomSection.max_elapseds_len = old_cap
 
 
+def _side_leg(fn, *a, **k):
+    """A side leg must never take the headline line down with it: its failure becomes its value."""
+    try:
+        return fn(*a, **k)
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
+
+
 def _self_launch(n: int) -> int:
     """``python bench.py --gpus N`` without a launcher: start N copies of this command, one rank each, with the
     environment torch.distributed.run would give them (rendezvous on 127.0.0.1, a free port).  Rank 0 prints the JSON
@@ -673,46 +681,49 @@ def main():
         cold = _roof(cold_us, job.local_ranks * SECTIONS * SAMPLES * 4)
         cold["launches_timed"] = cold_n
         cold["note"] = "1 GiB device sweep between reports: rows fetched from HBM, not from L2 / Infinity Cache"
-        n8 = _n8_shape_leg(args.steps, args.warmup)
-        detector_leg = _detector_leg(args.steps, args.warmup)
+        n8 = _side_leg(_n8_shape_leg, args.steps, args.warmup)
+        detector_leg = _side_leg(_detector_leg, args.steps, args.warmup)
 
     host_inputs = None
     if world == 1 and not args.no_host_inputs:
-        host = [synth.stress_samples(r, SECTIONS, SAMPLES, slow_rank=3, slow_factor=1.5) for r in job.logical_ranks()]
-        t_host = []
-        for _ in range(6):
-            job.rings.reset()
-            sync_all()
-            t0 = time.perf_counter()
-            for lr in range(job.local_ranks):
-                job.load(lr, host[lr])
-            job.report()
-            t_host.append(time.perf_counter() - t0)
-        nbytes = job.local_ranks * SECTIONS * SAMPLES * 4
-        us = float(np.median(t_host[1:])) * 1e6
-        host_inputs = {"us_per_report": round(us, 1), "host_bytes": nbytes, "gb_per_s": round(nbytes / us / 1e3, 2),
-                       "note": "samples start in pageable host memory; H2D + ring appends + report; not the headline value"}
+        try:
+            host = [synth.stress_samples(r, SECTIONS, SAMPLES, slow_rank=3, slow_factor=1.5) for r in job.logical_ranks()]
+            t_host = []
+            for _ in range(6):
+                job.rings.reset()
+                sync_all()
+                t0 = time.perf_counter()
+                for lr in range(job.local_ranks):
+                    job.load(lr, host[lr])
+                job.report()
+                t_host.append(time.perf_counter() - t0)
+            nbytes = job.local_ranks * SECTIONS * SAMPLES * 4
+            us = float(np.median(t_host[1:])) * 1e6
+            host_inputs = {"us_per_report": round(us, 1), "host_bytes": nbytes, "gb_per_s": round(nbytes / us / 1e3, 2),
+                           "note": "samples start in pageable host memory; H2D + ring appends + report; not the headline value"}
+        except Exception as e:  # noqa: BLE001  (a side leg: see _side_leg)
+            host_inputs = {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
 
     cadence = None
     if world == 1 and not args.no_cadence:
-        cadence = {"headline_workload": _cadence_leg(args.cadence_reports, job)}
+        cadence = {"headline_workload": _side_leg(_cadence_leg, args.cadence_reports, job)}
         job.backend.synchronize()
-        cadence.update(_cadence_leg(args.cadence_reports))
+        cadence.update(_side_leg(_cadence_leg, args.cadence_reports))
 
     per_kernel = None
     if world == 1 and not args.no_extra_legs:
         job.backend.synchronize()
-        try:
-            per_kernel = _per_kernel_leg()
-        except Exception as e:  # noqa: BLE001  (an optional leg must not take the headline line down)
-            per_kernel = {"error": str(e)[-300:]}
+        per_kernel = _side_leg(_per_kernel_leg)
 
     overhead = overhead_async = None
     if not args.no_overhead:
         job.backend.synchronize()
-        overhead = _per_step_overhead(world, rank, args.overhead_steps, args.overhead_blocks)
+        # (collective at N > 1: every rank runs it and a failure is a failure of the job; at N = 1 it is a side leg)
         if world == 1:
-            overhead_async = _per_step_overhead(world, rank, args.overhead_steps, args.overhead_blocks, asynchronous=True)
+            overhead = _side_leg(_per_step_overhead, world, rank, args.overhead_steps, args.overhead_blocks)
+            overhead_async = _side_leg(_per_step_overhead, world, rank, args.overhead_steps, args.overhead_blocks, asynchronous=True)
+        else:
+            overhead = _per_step_overhead(world, rank, args.overhead_steps, args.overhead_blocks)
 
     ex_us = exchange.get("us_median", 0.0) if exchange else 0.0
     times = torch.tensor([elapsed, elapsed_instr, ex_us], dtype=torch.float64, device="cuda")
@@ -810,7 +821,7 @@ def main():
             exchange["note"] = "enqueue + stream wait of one all-gather of the exchange rows, max over ranks; latency-bound"
             out["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = _cpu_baseline(args.cpu_reps)
+            out["cpu_baseline"] = _side_leg(_cpu_baseline, args.cpu_reps)
         print(json.dumps(out), flush=True)
 
     job.close()
