@@ -86,81 +86,65 @@ def _align(n: int, a: int = 64) -> int:
     return (n + a - 1) // a * a
 
 
-class Workspace:
-    """Buffers of one report shape (R ranks, K kernel ids, S section ids)."""
+class ResultBlock:
+    """One result block in PINNED, device-mapped host memory: ``meta | scores | flags | stats``.  The kernels store their
+    results straight into it and the score kernel publishes a sequence word last (``meta[4]``; ``meta[5]`` for the
+    statistics rows, which a resident score kernel forwards after the scores), so a report needs no D2H copy and no
+    stream synchronisation.  A workspace owns TWO of them and alternates: the block of report n is not written again
+    before report n+2, so a caller that still holds report n while it asks for n+1 (``report = generate_report()`` in
+    a loop does exactly that) costs the next report nothing -- with one block the next report first had to wait for
+    the previous one's statistics rows and copy 16 KB out of the way."""
 
-    def __init__(self, backend: "HipBackend", R: int, K: int, S: int, local_ranks: int, stats_rows: int):
-        self.R, self.K, self.S = R, K, S
-        self.local_ranks = local_ranks
-        self.stats_rows = stats_rows
-        self.L = _native.table_len(K, S)
-        self.W = _native.score_len(S)
-        dev = backend.device
-        self.send = torch.empty((local_ranks, self.L), dtype=torch.float32, device=dev)
-        self.table = torch.empty((R, self.L), dtype=torch.float32, device=dev) if R != local_ranks else self.send
-        self.send_initialised = False
-        # one result block in PINNED, device-mapped host memory: meta | scores | flags | stats.
-        # The kernels store their results straight into it and the score kernel publishes a
-        # sequence word last, so a report needs no D2H copy and no stream synchronisation.
+    def __init__(self, ws: "Workspace", backend: "HipBackend"):
+        R, W, stats_rows = ws.R, ws.W, ws.stats_rows
         self._off_meta = 0
         self._off_scores = self._off_meta + _align(_native.META_WORDS * 4)
-        self._off_flags = self._off_scores + _align(R * self.W * 4)
-        self._off_stats = self._off_flags + _align(R * self.W)
+        self._off_flags = self._off_scores + _align(R * W * 4)
+        self._off_stats = self._off_flags + _align(R * W)
         self.nbytes = self._off_stats + _align(max(stats_rows, 1) * _native.STATS_STRIDE * 4)
         h_ptr, d_ptr = ctypes.c_void_p(), ctypes.c_void_p()
         _native.check(backend.lib.nvrx_host_alloc(ctypes.byref(h_ptr), ctypes.byref(d_ptr), self.nbytes))
         self._lib = backend.lib
+        self._backend = backend
         self.h_ptr, self.d_ptr = h_ptr.value, d_ptr.value
         host = np.frombuffer((ctypes.c_uint8 * self.nbytes).from_address(self.h_ptr), dtype=np.uint8)
         self._host = host
         self.stats = host[self._off_stats : self._off_stats + stats_rows * 32].view(np.float32).reshape(stats_rows, _native.STATS_STRIDE)
         self.meta = host[self._off_meta : self._off_meta + _native.META_WORDS * 4].view(np.uint32)
-        self.scores = host[self._off_scores : self._off_scores + R * self.W * 4].view(np.float32).reshape(R, self.W)
-        self.flags = host[self._off_flags : self._off_flags + R * self.W].reshape(R, self.W)
-        # statistics are produced in device memory and forwarded to the host block by the score kernel
-        self.stats_dev = torch.zeros((max(stats_rows, 1), _native.STATS_STRIDE), dtype=torch.float32, device=dev)
-        self.d_stats = self.stats_dev.data_ptr()
+        self.scores = host[self._off_scores : self._off_scores + R * W * 4].view(np.float32).reshape(R, W)
+        self.flags = host[self._off_flags : self._off_flags + R * W].reshape(R, W)
         self.h_stats_dst = self.d_ptr + self._off_stats
         self.d_meta = self.d_ptr + self._off_meta
         self.d_scores = self.d_ptr + self._off_scores
         self.d_flags = self.d_ptr + self._off_flags
         self.h_seq = self.h_ptr + self._off_meta + 16  # meta[4]: scores / flags / meta have landed
         self.h_seq2 = self.h_ptr + self._off_meta + 20  # meta[5]: the statistics rows have landed
-        self.done_counter = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.d_counter = self.done_counter.data_ptr()
-        self.seq = 0
-        self.send_ptr = self.send.data_ptr()
-        self.table_ptr = self.table.data_ptr()
-        # descriptor of the one-call report (nvrx_report); the library advances desc.seq itself
+        # descriptor of the one-call report (nvrx_report) into THIS block; the library advances desc.seq itself
         d = self.desc = _native.ReportDesc()
-        d.R, d.K, d.S = R, K, S
+        d.R, d.K, d.S = ws.R, ws.K, ws.S
         d.names_ok, d.rows_active, d.do_indiv, d.do_rel, d.stats_rows = 1, 0, 1, 1, 0
         for i, t in enumerate(DEFAULT_THRESHOLDS):
             d.thresholds[i] = t
-        d.d_stats, d.d_send, d.d_table = self.d_stats, self.send_ptr, self.table_ptr
+        d.d_stats, d.d_send, d.d_table = ws.d_stats, ws.send_ptr, ws.table_ptr
         d.d_scores, d.d_flags, d.d_meta, d.d_stats_dst = self.d_scores, self.d_flags, self.d_meta, self.h_stats_dst
-        d.d_done_counter = self.d_counter
-        d.allgather_fn, d.comm, d.send_count = None, None, local_ranks * self.L
+        d.d_done_counter = ws.d_counter
+        d.allgather_fn, d.comm, d.send_count = None, None, ws.local_ranks * ws.L
         d.seq = 0
         d.h_seq_word = self.h_seq
         d.timeout_s = report_timeout_s()
         self.desc_ref = ctypes.byref(d)
         self.desc_key = None
-        # the last report's result block may still be "live" (read lazily by a Report): see attach() / settle()
+        # this block's last report may still be "live" (read lazily by a Report): see attach() / settle()
         self._live = None
         self._live_seq = 0
-        self._backend = backend
 
-    def __del__(self):  # pragma: no cover
-        try:
-            if self.h_ptr:
-                self._lib.nvrx_host_free(self.h_ptr)
-                self.h_ptr = None
-        except Exception:
-            pass
+    def free(self) -> None:
+        if self.h_ptr:
+            self._lib.nvrx_host_free(self.h_ptr)
+            self.h_ptr = None
 
     def attach(self, live) -> None:
-        """``live`` (reporting._LiveBlock) reads this block lazily; ``settle()`` collects it before any reuse."""
+        """``live`` (reporting._LiveBlock) reads this block lazily; ``settle()`` collects it before the block is reused."""
         self._live = weakref.ref(live)
         self._live_seq = live.seq
 
@@ -171,9 +155,9 @@ class Workspace:
         self._live_seq = seq
 
     def settle(self) -> None:
-        """Called before anything is enqueued that writes this workspace: the previous report's statistics rows must
-        have landed (a resident score kernel forwards them after the scores), and if somebody still holds that report
-        its data is copied out now."""
+        """Called before anything is enqueued that writes this block again: its last report's statistics rows must have
+        landed (a resident score kernel forwards them after the scores), and if somebody still holds that report its data
+        is copied out now."""
         ref = self._live
         if ref is not None:
             self._live = None
@@ -181,10 +165,10 @@ class Workspace:
             if live is not None:
                 live.detach()
             elif self.meta[5] != self._live_seq:
-                self._backend.wait_seq(self, self._live_seq, stats=True)
+                self._backend.wait_seq(None, self._live_seq, stats=True, block=self)
 
     def host_block(self) -> np.ndarray:
-        """A private copy of the pinned result block (the block itself is overwritten by the next report)."""
+        """A private copy of the whole block (the block itself is overwritten two reports later)."""
         return self._host.copy()
 
     def host_head(self) -> np.ndarray:
@@ -198,6 +182,91 @@ class Workspace:
     def host_stats(self, rows: int) -> np.ndarray:
         """A private copy of the first ``rows`` statistics rows (valid once meta[5] shows the sequence number)."""
         return self.stats[:rows].copy()
+
+
+class Workspace:
+    """Buffers of one report shape (R ranks, K kernel ids, S section ids): the exchange rows and the gathered table in
+    device memory, and two result blocks (``ResultBlock``) that successive reports alternate between.  ``ws.meta /
+    scores / flags / stats`` are those of the CURRENT block, i.e. of the report that ran last."""
+
+    def __init__(self, backend: "HipBackend", R: int, K: int, S: int, local_ranks: int, stats_rows: int):
+        self.R, self.K, self.S = R, K, S
+        self.local_ranks = local_ranks
+        self.stats_rows = stats_rows
+        self.L = _native.table_len(K, S)
+        self.W = _native.score_len(S)
+        dev = backend.device
+        self.send = torch.empty((local_ranks, self.L), dtype=torch.float32, device=dev)
+        self.table = torch.empty((R, self.L), dtype=torch.float32, device=dev) if R != local_ranks else self.send
+        self.send_initialised = False
+        # statistics are produced in device memory and forwarded to the host block by the score kernel
+        self.stats_dev = torch.zeros((max(stats_rows, 1), _native.STATS_STRIDE), dtype=torch.float32, device=dev)
+        self.d_stats = self.stats_dev.data_ptr()
+        self.done_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_counter = self.done_counter.data_ptr()
+        self.seq = 0  # the one sequence every report on this workspace draws from, whichever block and route it takes
+        self.send_ptr = self.send.data_ptr()
+        self.table_ptr = self.table.data_ptr()
+        self._backend = backend
+        self.blocks = (ResultBlock(self, backend), ResultBlock(self, backend))
+        self.block = self.blocks[0]
+        self._cur = 0
+        b = self.block
+        self._off_scores, self._off_flags, self._off_stats, self.nbytes = b._off_scores, b._off_flags, b._off_stats, b.nbytes
+
+    def __del__(self):  # pragma: no cover
+        try:
+            for b in self.blocks:
+                b.free()
+        except Exception:
+            pass
+
+    # ---- the current block's views / addresses ----------------------------------------------------------------
+    meta = property(lambda self: self.block.meta)
+    scores = property(lambda self: self.block.scores)
+    flags = property(lambda self: self.block.flags)
+    stats = property(lambda self: self.block.stats)
+    desc = property(lambda self: self.block.desc)
+    h_seq = property(lambda self: self.block.h_seq)
+    h_seq2 = property(lambda self: self.block.h_seq2)
+    d_meta = property(lambda self: self.block.d_meta)
+    d_scores = property(lambda self: self.block.d_scores)
+    d_flags = property(lambda self: self.block.d_flags)
+    h_stats_dst = property(lambda self: self.block.h_stats_dst)
+
+    def flip(self) -> ResultBlock:
+        """Make the OTHER block the current one for the report about to be enqueued (settling whatever its previous
+        report -- two reports ago -- left behind) and return it."""
+        nxt = self.blocks[1 - self._cur]
+        if nxt._live is not None:
+            nxt.settle()
+        self._cur = 1 - self._cur
+        self.block = nxt
+        return nxt
+
+    def attach(self, live) -> None:
+        self.block.attach(live)
+
+    def mark_live(self, seq: int) -> None:
+        self.block.mark_live(seq)
+
+    def settle(self) -> None:
+        """Both blocks: nothing of this workspace is in flight or lazily referenced afterwards."""
+        for b in self.blocks:
+            if b._live is not None:
+                b.settle()
+
+    def host_block(self) -> np.ndarray:
+        return self.block.host_block()
+
+    def host_head(self) -> np.ndarray:
+        return self.block.host_head()
+
+    def host_head_bytes(self) -> bytes:
+        return self.block.host_head_bytes()
+
+    def host_stats(self, rows: int) -> np.ndarray:
+        return self.block.host_stats(rows)
 
     def set_send_row(self, lr: int, row: np.ndarray) -> None:
         """Host-packed exchange row (dict-input path)."""
@@ -269,30 +338,34 @@ class HipBackend:
                 self._thr[i] = float(thresholds[i])
             self._thr_src = thresholds
         lib = self.lib
-        if ws._live is not None:
-            ws.settle()
+        blk = ws.flip()  # this report's result block; the previous report's block stays readable for one more report
         nrows = ws.stats_rows if stats_rows is None else min(stats_rows, ws.stats_rows)
         table_ptr = ws.table_ptr if table is ws.table else (ws.send_ptr if table is ws.send else table.data_ptr())
-        ws.seq = ws.desc.seq = (max(ws.seq, ws.desc.seq) % 0x7FFFFFFF) + 1  # one sequence for both report routes
+        ws.seq = (ws.seq % 0x7FFFFFFF) + 1  # one sequence for both report routes and both blocks
         rc = lib.nvrx_score(table_ptr, ws.R, ws.K, ws.S, int(do_indiv), int(do_rel), self._thr,
-                            ws.d_scores, ws.d_flags, ws.d_meta, ws.d_counter, ws.seq,
-                            ws.d_stats, ws.h_stats_dst, nrows, self._stream_handle)
+                            blk.d_scores, blk.d_flags, blk.d_meta, ws.d_counter, ws.seq,
+                            ws.d_stats, blk.h_stats_dst, nrows, self._stream_handle)
         if rc < 0:
             _native.check(rc)
         if wait:
             timeout = report_timeout_s()
-            rc = lib.nvrx_poll_u32(ws.h_seq, ws.seq, timeout if timeout > 0 else 1e30)
+            rc = lib.nvrx_poll_u32(blk.h_seq, ws.seq, timeout if timeout > 0 else 1e30)
             if rc < 0:
                 self.retire_workspace(ws)
                 _native.check(rc)
 
-    def wait_seq(self, ws: Workspace, seq: int, stats: bool = False) -> None:
-        """Block until the report that was enqueued with sequence number ``seq`` has published its results
-        (``stats=True``: its statistics rows, which a resident score kernel forwards after the scores)."""
+    def wait_seq(self, ws: Optional[Workspace], seq: int, stats: bool = False, block: Optional[ResultBlock] = None) -> None:
+        """Block until the report that was enqueued with sequence number ``seq`` has published its results into
+        ``block`` (default: the workspace's current one); ``stats=True``: its statistics rows, which a resident score
+        kernel forwards after the scores."""
+        blk = block if block is not None else ws.block
         timeout = report_timeout_s()
-        rc = self.lib.nvrx_poll_u32(ws.h_seq2 if stats else ws.h_seq, seq, timeout if timeout > 0 else 1e30)
+        rc = self.lib.nvrx_poll_u32(blk.h_seq2 if stats else blk.h_seq, seq, timeout if timeout > 0 else 1e30)
         if rc < 0:
-            self.retire_workspace(ws)
+            if ws is None:
+                ws = next((w for w in self._workspaces.values() if blk in w.blocks), None)
+            if ws is not None:
+                self.retire_workspace(ws)
             _native.check(rc)
 
     def retire_workspace(self, ws: Workspace) -> None:
@@ -457,9 +530,7 @@ class HipRings:
 
     # ---- report ----------------------------------------------------------------------------------
     def report_local(self, ws: Workspace, names_ok: bool, rows_active: int = 0) -> None:
-        """flush -> statistics kernel -> exchange rows, all on the backend's stream."""
-        if ws._live is not None:
-            ws.settle()
+        """flush -> statistics kernel -> exchange rows, all on the backend's stream (nothing here writes a result block)."""
         if not ws.send_initialised:
             self.backend.send_init(ws)
         rc = self.lib.nvrx_report_local(self.ctx, ws.d_stats, ws.send_ptr, ws.K, ws.S, int(names_ok),
@@ -475,11 +546,10 @@ class HipRings:
         ``ws.scores / flags / meta / stats`` hold this report's values.  ``wait=False`` only enqueues (asynchronous
         report): the caller waits for the returned sequence number with ``backend.wait_seq`` later, and ring writers on
         other streams are ordered after the statistics kernel on the device."""
-        if ws._live is not None:
-            ws.settle()
-        d = ws.desc
+        blk = ws.flip()  # this report's result block; the previous report's block stays readable for one more report
+        d = blk.desc
         key = (rows_active, stats_rows, do_indiv, do_rel, thresholds, direct, names_ok, wait, resident)
-        if ws.desc_key != key:  # cold: the switches of this shape changed
+        if blk.desc_key != key:  # cold: the switches of this shape changed
             d.rows_active, d.stats_rows = rows_active, min(stats_rows, ws.stats_rows)
             d.do_indiv, d.do_rel = int(do_indiv), int(do_rel)
             d.names_ok = int(names_ok)
@@ -490,12 +560,12 @@ class HipRings:
             else:
                 d.allgather_fn, d.comm = None, None
             d.timeout_s = report_timeout_s()
-            d.h_seq_word = ws.h_seq if wait else None
+            d.h_seq_word = blk.h_seq if wait else None
             d.guard_rings = 0 if wait else 1
             # resident score kernel on a stream of its own: the library decides among the eligible shapes (no exchange or
             # peer windows, table fits one workgroup); off when ranks share a device
             d.resident = 1 if (wait and resident) else 0
-            ws.desc_key = key
+            blk.desc_key = key
         if order_after is not None:  # the caller's current stream: the report follows what is enqueued there
             d.order_after_stream, d.order_after_enabled = order_after, 1
         elif d.order_after_enabled:
@@ -503,8 +573,8 @@ class HipRings:
         if not ws.send_initialised:
             self.backend.send_init(ws)
             self.backend.synchronize()  # cold: a resident score kernel touches the exchange rows from its own stream
-        d.seq = max(d.seq, ws.seq)
-        rc = self.lib.nvrx_report(self.ctx, ws.desc_ref, self.backend._stream_handle)
+        d.seq = ws.seq
+        rc = self.lib.nvrx_report(self.ctx, blk.desc_ref, self.backend._stream_handle)
         ws.seq = d.seq
         if rc < 0:
             if rc == _native.ERR_TIMEOUT:

@@ -82,19 +82,24 @@ class _PendingBlock:
     pinned block fills in when they run.  ``wait()`` polls the completion word and takes the private copy; the
     generator settles the block before the workspace is used again, a ``Report`` settles it on first read."""
 
-    __slots__ = ("backend", "ws", "seq", "blob", "lock")
+    __slots__ = ("backend", "ws", "blk", "seq", "blob", "lock")
 
     def __init__(self, backend, ws, seq: int):
         self.backend, self.ws, self.seq = backend, ws, seq
+        self.blk = getattr(ws, "block", None)  # the one of the workspace's result blocks this report was enqueued into
         self.blob: Optional[np.ndarray] = None
         self.lock = threading.Lock()
 
     def wait(self) -> np.ndarray:
         with self.lock:
             if self.blob is None:
-                self.backend.wait_seq(self.ws, self.seq)
-                self.blob = self.ws.host_block()
-                self.backend = self.ws = None  # nothing of the live workspace is referenced any more
+                if self.blk is not None:
+                    self.backend.wait_seq(self.ws, self.seq, block=self.blk)
+                    self.blob = self.blk.host_block()
+                else:  # (the CPU checker backend of the tests: one block, computed at enqueue time)
+                    self.backend.wait_seq(self.ws, self.seq)
+                    self.blob = self.ws.host_block()
+                self.backend = self.ws = self.blk = None  # nothing of the live workspace is referenced any more
         return self.blob
 
 
@@ -102,15 +107,17 @@ _LIVE_LOCK = threading.Lock()  # a report may be read on another thread while th
 
 
 class _LiveBlock:
-    """The result block of the LAST synchronous one-call report on a workspace, still in place.  Nothing is copied when
-    the report returns: ``head()`` / ``stats()`` take private copies when the report is first read, and the workspace
-    calls ``detach()`` before anything reuses the block -- which copies only if somebody still holds the report.  The
-    statistics rows have a completion word of their own (a resident score kernel forwards them after the scores)."""
+    """The result block of a synchronous one-call report, still in place.  Nothing is copied when the report returns:
+    ``head()`` / ``stats()`` take private copies when the report is first read, and the block calls ``detach()`` before
+    anything writes it again -- two reports later (a workspace alternates between two blocks), and it copies only if
+    somebody still holds the report by then.  The statistics rows have a completion word of their own (a resident
+    score kernel forwards them after the scores)."""
 
-    __slots__ = ("backend", "ws", "seq", "rows", "_head", "_head_bytes", "_stats", "__weakref__")
+    __slots__ = ("backend", "ws", "blk", "seq", "rows", "_head", "_head_bytes", "_stats", "__weakref__")
 
     def __init__(self, backend, ws, seq: int, rows: int):
         self.backend, self.ws, self.seq, self.rows = backend, ws, seq, rows
+        self.blk = getattr(ws, "block", ws)  # (the CPU checker backend's workspace is its own single block)
         self._head: Optional[np.ndarray] = None
         self._head_bytes: Optional[bytes] = None
         self._stats: Optional[np.ndarray] = None
@@ -121,8 +128,8 @@ class _LiveBlock:
         if self._head_bytes is None:
             with _LIVE_LOCK:
                 if self._head_bytes is None:
-                    grab = getattr(self.ws, "host_head_bytes", None)
-                    self._head_bytes = grab() if grab is not None else self.ws.host_head().tobytes()
+                    grab = getattr(self.blk, "host_head_bytes", None)
+                    self._head_bytes = grab() if grab is not None else self.blk.host_head().tobytes()
                     self._release()
         return self._head_bytes
 
@@ -135,18 +142,21 @@ class _LiveBlock:
         if self._stats is None:
             with _LIVE_LOCK:
                 if self._stats is None:
-                    self.backend.wait_seq(self.ws, self.seq, stats=True)
-                    self._stats = self.ws.host_stats(self.rows)
+                    if self.blk is self.ws:
+                        self.backend.wait_seq(self.ws, self.seq, stats=True)
+                    else:
+                        self.backend.wait_seq(self.ws, self.seq, stats=True, block=self.blk)
+                    self._stats = self.blk.host_stats(self.rows)
                     self._release()
         return self._stats
 
     def detach(self) -> None:
-        self.head()
+        self.head_bytes()
         self.stats()
 
     def _release(self) -> None:
         if self._head_bytes is not None and self._stats is not None:
-            self.backend = self.ws = None  # nothing of the live workspace is referenced any more
+            self.backend = self.ws = self.blk = None  # nothing of the live workspace is referenced any more
 
 
 class _View:
