@@ -34,7 +34,7 @@ def test_single_gpu_line_has_the_contract_fields_and_the_round3_legs():
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
     # the timed steps are held and read: the read shows up as a leg of its own, and value covers the whole bracketed region
-    assert d["report_read"]["identify_stragglers_us"] > 0 and d["us_per_report_fully_read"] > d["value"]
+    assert d["report_read"]["identify_stragglers_us"] > 0 and d["us_per_report_fully_read"] > d["value"] and 0 < d["us_per_call_median"] < d["us_per_report_median"]
     tr = d["timed_region"]
     assert tr["region_us"] >= tr["sum_of_steps_us"] and abs(tr["region_us"] / 6 - d["value"]) < 0.5
 
