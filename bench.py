@@ -600,10 +600,10 @@ def main():
         rep, found = step()
         per_step.append(time.perf_counter_ns() - ts)
     t_loop = time.perf_counter()
-    call_us_median = float(np.median(call_ns[: args.steps])) / 1e3
     sync_all()
     elapsed = time.perf_counter() - t0
     closing_sync_us = (time.perf_counter() - t_loop) * 1e6
+    call_us_median = float(np.median(call_ns[: args.steps])) / 1e3
     if rank == 0:
         check_flagged(found)  # the last timed report
 
