@@ -39,6 +39,11 @@ from .statistics import NUM_COLUMN, STAT_KEYS, Statistic
 _SummaryType = Mapping[Statistic, float]
 _LOG = logging.getLogger(__name__)
 
+try:  # csrc/nvrx_pyread.c: the same dicts without numpy's intermediate lists (host-side formatting only; same results)
+    from . import _nvrx_pyread as _pyread
+except ImportError:  # not built: the Python builders below
+    _pyread = None
+
 _NCCL_MARKER = "ncclDev"  # RCCL's device kernels carry the same prefix (reporting.py:336)
 
 
@@ -64,10 +69,13 @@ def _row_selector(rows: Mapping[str, int]):
 
 def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray, selector=None) -> Dict[str, Dict[Statistic, Any]]:
     """``name -> {Statistic: value}`` from device statistics rows (``_get_section_summaries``' result shape,
-    straggler.py:185-195).  One C-level conversion of the whole block, one ``dict(zip(keys, row))`` per name (all C;
-    ``Statistic`` hashes by identity), NUM turned into an integer as in the reference (straggler.py:194)."""
+    straggler.py:185-195), NUM as an integer as in the reference (straggler.py:194).  Built by ``_nvrx_pyread`` when it
+    is there; else one C-level conversion of the whole block and one ``dict(zip(keys, row))`` per name (``Statistic``
+    hashes by identity)."""
     if not rows:
         return {}
+    if _pyread is not None and stats.dtype == np.float32 and stats.flags.c_contiguous and stats.shape[1] == 8:
+        return _pyread.summaries(tuple(rows), STAT_KEYS, stats, tuple(rows.values()))
     block = stats[_row_selector(rows) if selector is None else selector]
     vals = block[:, : NUM_COLUMN + 1].tolist()
     out = dict(zip(rows, map(dict, map(zip, itertools.repeat(STAT_KEYS), vals))))
@@ -164,7 +172,7 @@ class _View:
     exist, where this report's rows sit in the result block, the thresholds the score kernel flagged with."""
 
     __slots__ = ("S", "ranks", "names", "cols", "has_rel", "has_indiv", "section_rows", "kernel_rows", "layout", "thresholds",
-                 "_rank_list", "_col_index", "_selectors", "_ids", "_memo")
+                 "_rank_list", "_col_index", "_selectors", "_ids", "_memo", "_tuples")
 
     def memo(self) -> dict:
         try:
@@ -179,6 +187,22 @@ class _View:
         except AttributeError:
             self._rank_list = list(self.ranks)
             return self._rank_list
+
+    def rank_tuple(self) -> tuple:
+        try:
+            return self._tuples[0]
+        except AttributeError:
+            idx = self.col_index()
+            self._tuples = (tuple(self.ranks), tuple(self.names), None if idx is None else tuple(int(i) for i in idx))
+            return self._tuples[0]
+
+    def names_tuple(self) -> tuple:
+        self.rank_tuple()
+        return self._tuples[1]
+
+    def col_tuple(self):
+        self.rank_tuple()
+        return self._tuples[2]
 
     def col_index(self):
         """Score-table column of every name of ``names``, in that order (None: the identity)."""
@@ -283,11 +307,16 @@ class _ScoreSource:
         raise AttributeError(field)
 
     def _sections(self, first_col: int) -> Dict[str, Dict[int, float]]:
-        """``section -> {rank: score}``: one C-level conversion of the [S, ranks] block, one ``dict(zip(...))`` per
-        section (reporting.py:196-217 builds the same shape score by score)."""
+        """``section -> {rank: score}`` (reporting.py:196-217 builds the same shape score by score): ``_nvrx_pyread``
+        walks the [ranks, 2+2S] block directly; without it, one C-level conversion of the [S, ranks] block and one
+        ``dict(zip(...))`` per section."""
         v = self.view
-        block = self.scores[:, first_col : first_col + v.S].T
+        sc = self.scores
         idx = v.col_index()
+        if _pyread is not None and sc.dtype == np.float32 and sc.flags.c_contiguous:
+            return _pyread.sections(v.names_tuple(), v.rank_tuple(), sc, sc.shape[0], sc.shape[1], first_col,
+                                    None if idx is None else v.col_tuple())
+        block = sc[:, first_col : first_col + v.S].T
         if idx is not None:
             block = block[idx]
         return dict(zip(v.names, map(dict, map(zip, itertools.repeat(v.rank_list()), block.tolist()))))

@@ -815,3 +815,62 @@ def test_region_timing_flattens_gpu_scores_when_the_region_holds_a_collective():
     assert k["stragglers"]["0.85"]["straggler_gpus_relative"] == [2]
     assert [round(r["gpu_relative_perf_scores"][i], 4) for i in range(4)] == [1.0, 1.0, 1.0, 1.0]
     assert r["stragglers"]["0.85"]["straggler_gpus_relative"] == []
+
+
+def test_c_dict_builders_equal_the_python_builders(monkeypatch):
+    """``_nvrx_pyread`` (csrc/nvrx_pyread.c) builds a Report's nested dicts straight from the f32 blocks; the Python builders
+    (numpy ``tolist`` + ``dict(zip)``) are what runs when the module was not built.  Same keys in the same order, same
+    values (NaN and inf included), NUM an ``int`` -- for the identity column order of a gathered report and for a
+    rank's own section order."""
+    import math
+
+    from nvrx_straggler import Statistic, reporting
+
+    assert reporting._pyread is not None, "csrc/nvrx_pyread.c was not built (make -C nvidia-resiliency-ext_amd/csrc)"
+    rng = np.random.default_rng(3)
+    R, S = 8, 37
+    W = 2 + 2 * S
+    scores = rng.uniform(0.1, 1.0, (R, W)).astype(np.float32)
+    scores[2, 5] = np.nan
+    scores[7, 2 + S + 3] = np.inf
+    stats = rng.uniform(1.0, 9.0, (S + 5, 8)).astype(np.float32)
+    stats[:, 5] = rng.integers(0, 70000, S + 5)
+    stats[3, 4] = np.nan
+
+    def same(a, b):
+        assert list(a) == list(b)                      # key order
+        for k in a:
+            assert list(a[k]) == list(b[k]), k
+            for kk in a[k]:
+                x, y = a[k][kk], b[k][kk]
+                assert type(x) is type(y), (k, kk, type(x), type(y))
+                assert (x == y) or (math.isnan(x) and math.isnan(y)), (k, kk, x, y)
+
+    for order in ("identity", "permuted"):
+        v = reporting._View()
+        v.S, v.ranks = S, range(3, 3 + R)
+        names = [f"section_{i:02d}" for i in range(S)]
+        if order == "permuted":
+            names = [names[i] for i in rng.permutation(S)]
+        v.names = names
+        v.cols = {n: int(n.split("_")[1]) for n in names}
+        v.has_rel = v.has_indiv = True
+        v.section_rows = {n: 2 + v.cols[n] for n in names}
+        v.kernel_rows = {"k_a": 0, "k_b": S + 4}
+        v.layout, v.thresholds = None, None
+        got, want = {}, {}
+        for use_c, out in ((True, got), (False, want)):
+            with monkeypatch.context() as m:
+                if not use_c:
+                    m.setattr(reporting, "_pyread", None)
+                src = reporting._ScoreSource(v)
+                src.scores, src.flags, src.stats = scores, np.zeros((R, W), np.uint8), stats
+                for f in sorted(reporting._LAZY_FIELDS):
+                    out[f] = src.build(f)
+        for f in got:
+            if f.startswith("gpu_"):
+                assert got[f] == want[f] or all(math.isnan(got[f][k]) == math.isnan(want[f][k]) for k in got[f])
+            else:
+                same(got[f], want[f])
+        assert all(type(d[Statistic.NUM]) is int for d in got["local_section_summaries"].values())
+        assert list(got["section_relative_perf_scores"]) == names
