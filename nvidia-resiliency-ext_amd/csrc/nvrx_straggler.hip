@@ -1798,10 +1798,6 @@ struct nvrx_ctx {
     // forced by a full buffer, device-side appends, bulk appends, history resets, asynchronous reports); cleared when
     // a synchronous report on the context's own stream has completed
     bool side_work = true;
-    // a re-homed synchronous report does not record the staging buffer's "scatter done" event either: its own
-    // completion word says so (the scatter runs in front of it on the same stream)
-    bool defer_flush_event = false;
-    int deferred_buf = -1;
     hipEvent_t report_ev = nullptr;
     uint64_t report_epoch = 0;  // bumped by every guarded report
     struct StreamEpoch {
@@ -1840,7 +1836,10 @@ int order_after_stamps(nvrx_ctx *ctx, hipStream_t stream, hipStream_t also = nul
 // `rows_active` rows per rank about to be launched holds the same number of samples, that number is
 // returned through it and NOTHING is launched -- k_row_stats takes it as a kernel argument instead of
 // reading d_counts (which stays marked dirty until a later flush uploads it).
-int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, int rows_active = 0) {
+// `deferred_buf` (optional, re-homed synchronous reports only): the staging buffer's "scatter done" event is NOT recorded;
+// the buffer's index is returned instead and the caller releases it when the report's own completion word has arrived
+// (the scatter runs in front of it on the same stream).
+int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, int rows_active = 0, int *deferred_buf = nullptr) {
     if (uniform_n) *uniform_n = -1;
     if (!ctx->stamp_streams.empty()) {
         int rc = order_after_stamps(ctx, stream);
@@ -1873,8 +1872,8 @@ int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, in
                        ctx->meta_dirty ? ctx->h_kinds : nullptr, ctx->d_kinds,
                        ctx->meta_dirty ? ctx->h_gid : nullptr, ctx->d_gid);
     HIP_TRY(hipGetLastError());
-    if (ctx->defer_flush_event && !ctx->meta_dirty)
-        ctx->deferred_buf = ctx->cur;
+    if (deferred_buf && !ctx->meta_dirty)
+        *deferred_buf = ctx->cur;
     else
         HIP_TRY(hipEventRecord(b.done, stream));
     b.in_flight = true;
@@ -2543,7 +2542,7 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
 // report (local half)
 // ------------------------------------------------------------------------------------------------
 static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
-                             void *stream, unsigned long long *rowg, uint32_t epoch);
+                             void *stream, unsigned long long *rowg, uint32_t epoch, int *deferred_buf = nullptr);
 
 int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
                       void *stream) {
@@ -2551,7 +2550,7 @@ int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S
 }
 
 static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
-                             void *stream, unsigned long long *rowg, uint32_t epoch) {
+                             void *stream, unsigned long long *rowg, uint32_t epoch, int *deferred_buf) {
     hipStream_t st = as_stream(stream);
     if (!ctx || !d_stats) return fail(NVRX_ERR_INVALID, "null argument");
     if (K < 0 || S < 0) return fail(NVRX_ERR_INVALID, "bad K/S");
@@ -2561,7 +2560,7 @@ static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
     int uniform_n = -1;
-    rc = flush_locked(ctx, st, &uniform_n, rows_active);
+    rc = flush_locked(ctx, st, &uniform_n, rows_active, deferred_buf);
     if (rc) return rc;
     Epilogue ep{};
     ep.gid = ctx->d_gid;
@@ -2740,21 +2739,20 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         }
         return NVRX_OK;
     }
-    ctx->defer_flush_event = rehomed;
-    ctx->deferred_buf = -1;
-    int rc = nvrx_report_local(ctx, d->d_stats, d->d_send, d->K, d->S, d->names_ok, d->rows_active, stream);
-    ctx->defer_flush_event = false;
+    int deferred_buf = -1;
+    int rc = report_local_impl(ctx, d->d_stats, d->d_send, d->K, d->S, d->names_ok, d->rows_active, stream, nullptr, 0,
+                               rehomed ? &deferred_buf : nullptr);
     // the staging buffer whose "scatter done" event was not recorded: released by the completion word, or -- on any
     // failure below -- given its event after all
     auto settle_deferred = [&](bool done) {
-        if (ctx->deferred_buf < 0) return;
+        if (deferred_buf < 0) return;
         std::lock_guard<std::mutex> lk(ctx->mu);
-        StageBuf &db = ctx->buf[ctx->deferred_buf];
+        StageBuf &db = ctx->buf[deferred_buf];
         if (done)
             db.in_flight = false;
         else
             (void)hipEventRecord(db.done, as_stream(stream));
-        ctx->deferred_buf = -1;
+        deferred_buf = -1;
     };
     if (rc) {
         settle_deferred(false);
