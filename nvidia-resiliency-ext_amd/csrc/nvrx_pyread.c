@@ -11,6 +11,7 @@
  *
  *   sections(names, ranks, scores, n_rows, width, first_col, cols) -> {name: {rank: float}}
  *   summaries(names, stat_keys, stats, rows) -> {name: {stat_key: float, ..., stat_keys[5]: int}}
+ *   copy_sets(d) -> {key: set(value) for key, value in d.items()}      (fresh sets for every caller of identify_stragglers)
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
@@ -115,9 +116,31 @@ done:
     return out;
 }
 
+static PyObject *pyread_copy_sets(PyObject *self, PyObject *arg) {
+    if (!PyDict_Check(arg)) {
+        PyErr_SetString(PyExc_TypeError, "nvrx_pyread.copy_sets: a dict of sets expected");
+        return NULL;
+    }
+    PyObject *out = PyDict_New();
+    if (!out) return NULL;
+    PyObject *key, *value;
+    Py_ssize_t pos = 0;
+    while (PyDict_Next(arg, &pos, &key, &value)) {
+        PyObject *c = PySet_New(value);  /* a set built from a set keeps the stored hashes: nothing is re-hashed */
+        if (!c || PyDict_SetItem(out, key, c) < 0) {
+            Py_XDECREF(c);
+            Py_DECREF(out);
+            return NULL;
+        }
+        Py_DECREF(c);
+    }
+    return out;
+}
+
 static PyMethodDef pyread_methods[] = {
     {"sections", pyread_sections, METH_VARARGS, "section -> {rank -> score} from an f32 score block"},
     {"summaries", pyread_summaries, METH_VARARGS, "name -> {Statistic -> value} from f32 statistics rows"},
+    {"copy_sets", pyread_copy_sets, METH_O, "a dict of sets, copied one level deep"},
     {NULL, NULL, 0, NULL},
 };
 

@@ -44,6 +44,13 @@ try:  # csrc/nvrx_pyread.c: the same dicts without numpy's intermediate lists (h
 except ImportError:  # not built: the Python builders below
     _pyread = None
 
+
+def _copy_sets(d: Dict[str, set]) -> Dict[str, set]:
+    """``{name: set}`` copied one level deep (callers of ``identify_stragglers`` may do what they like with their sets)."""
+    if _pyread is not None:
+        return _pyread.copy_sets(d)
+    return {n: v.copy() for n, v in d.items()}
+
 _NCCL_MARKER = "ncclDev"  # RCCL's device kernels carry the same prefix (reporting.py:336)
 
 
@@ -509,7 +516,7 @@ class _DeviceFlags:
             hit = memo.get("flags")
             if hit is not None and hit[0] == key and hit[1] is ids:
                 gr, gi, sr, si = hit[2]
-                return gr.copy(), gi.copy(), {n: v.copy() for n, v in sr.items()}, {n: v.copy() for n, v in si.items()}
+                return gr.copy(), gi.copy(), _copy_sets(sr), _copy_sets(si)
         f = self._array()
         who = ids if ids is not None else self.ranks
         cnt = f.sum(axis=0, dtype=np.int32).tolist()
@@ -532,8 +539,7 @@ class _DeviceFlags:
             if self.has_rel:
                 sr = {n: members(2 + S + cols[n]) for n in self.names if cnt[2 + S + cols[n]]}
         if key is not None:
-            memo["flags"] = (key, ids, (gr.copy(), gi.copy(), {n: v.copy() for n, v in sr.items()},
-                                        {n: v.copy() for n, v in si.items()}))
+            memo["flags"] = (key, ids, (gr.copy(), gi.copy(), _copy_sets(sr), _copy_sets(si)))
         return gr, gi, sr, si
 
 

@@ -874,3 +874,11 @@ def test_c_dict_builders_equal_the_python_builders(monkeypatch):
                 same(got[f], want[f])
         assert all(type(d[Statistic.NUM]) is int for d in got["local_section_summaries"].values())
         assert list(got["section_relative_perf_scores"]) == names
+    flagged = {f"s{i}": {reporting.StragglerId(rank=i % 3, node="n"), reporting.StragglerId(rank=7, node="m")} for i in range(9)}
+    for use_c in (True, False):
+        with monkeypatch.context() as m:
+            if not use_c:
+                m.setattr(reporting, "_pyread", None)
+            copy = reporting._copy_sets(flagged)
+        assert copy == flagged and list(copy) == list(flagged) and all(type(v) is set for v in copy.values())
+        assert all(copy[k] is not flagged[k] for k in flagged)
