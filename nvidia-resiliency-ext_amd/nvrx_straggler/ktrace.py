@@ -123,11 +123,71 @@ def setup(max_pending: int = 0) -> None:
     _setup_error = None
 
 
+_prefetch_thread: Optional[threading.Thread] = None
+prefetch_stats: Dict[str, float] = {}
+
+
+def _prefetch_gpu_libraries() -> Optional[threading.Thread]:
+    """Read the large GPU libraries PyTorch links into the page cache, sequentially, on a background thread.
+
+    With a tool attached that asks for code-object callbacks, the first HIP call loads EVERY GPU code object of every
+    loaded library instead of deferring them: 10.7 GB of ``read()`` calls on this image (libmagma 1.3 GB, MIOpen 0.95,
+    rocsolver 0.76, libtorch_hip 0.42, rocsparse 0.39 ...), against 0.00 GB without a tool.  From a warm page cache
+    that takes 3 s; on a box whose storage is cold the loader's access pattern pulls the files in at 10-14 MB/s
+    (process in D state, ``submit_bio_wait``) and the call takes 130-165 s -- the "rocprofiler-sdk start-up stall" of
+    rounds 1-2 (tools/debug/ktrace_stall_io.sh, ktrace_eager_load.py).  The same storage delivers the same files at
+    ~900 MB/s when they are read front to back, so that is what this thread does, before HIP starts.
+    ``NVRX_KTRACE_PREFETCH=0`` turns it off."""
+    if os.environ.get("NVRX_KTRACE_PREFETCH", "1") in ("0", ""):
+        return None
+
+    def run() -> None:
+        import glob
+        import importlib.util
+        import time
+
+        t0 = time.monotonic()
+        total = 0
+        try:
+            spec = importlib.util.find_spec("torch")
+            if spec is None or not spec.origin:
+                return
+            libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+            files = sorted(((os.path.getsize(f), f) for f in glob.glob(os.path.join(libdir, "*.so*")) if os.path.isfile(f)),
+                           reverse=True)
+            chunk = memoryview(bytearray(16 << 20))
+            for size, path in files:
+                if size < (32 << 20):
+                    break
+                with open(path, "rb", buffering=0) as f:
+                    try:
+                        os.posix_fadvise(f.fileno(), 0, 0, os.POSIX_FADV_SEQUENTIAL)
+                    except (AttributeError, OSError):
+                        pass
+                    while True:
+                        n = f.readinto(chunk)  # releases the GIL
+                        if not n:
+                            break
+                        total += n
+        except Exception:  # noqa: BLE001  (an optimisation: never in the way)
+            pass
+        finally:
+            prefetch_stats["seconds"] = time.monotonic() - t0
+            prefetch_stats["gigabytes"] = total / 1e9
+
+    t = threading.Thread(target=run, name="nvrx-ktrace-prefetch", daemon=True)
+    t.start()
+    return t
+
+
 def setup_from_env() -> None:
     """Import-time hook: register early when ``NVRX_GPU_TIMING=kernels`` (errors surface at first use)."""
     if os.environ.get("NVRX_GPU_TIMING", "") == "kernels":
+        global _prefetch_thread
         try:
             setup()
+            if _prefetch_thread is None:
+                _prefetch_thread = _prefetch_gpu_libraries()
         except Exception:  # noqa: BLE001  (reported by KernelTraceProfiler.__init__)
             pass
 
@@ -186,6 +246,8 @@ class KernelTraceProfiler:
         if not self._lib.nvrx_ktrace_ready():
             import torch
 
+            if _prefetch_thread is not None:
+                _prefetch_thread.join(timeout=180.0)  # let the read-ahead finish before HIP starts reading page by page
             torch.cuda.init()  # the SDK calls the tool's initialiser when the runtime comes up
             if not self._lib.nvrx_ktrace_ready():
                 raise RuntimeError(
