@@ -128,17 +128,19 @@ prefetch_stats: Dict[str, float] = {}
 
 
 def _prefetch_gpu_libraries() -> Optional[threading.Thread]:
-    """Read the large GPU libraries PyTorch links into the page cache, sequentially, on a background thread.
+    """OPT-IN (``NVRX_KTRACE_PREFETCH=1``): read the large GPU libraries PyTorch links into the page cache, sequentially,
+    on a background thread, before HIP starts.
 
     With a tool attached that asks for code-object callbacks, the first HIP call loads EVERY GPU code object of every
     loaded library instead of deferring them: 10.7 GB of ``read()`` calls on this image (libmagma 1.3 GB, MIOpen 0.95,
     rocsolver 0.76, libtorch_hip 0.42, rocsparse 0.39 ...), against 0.00 GB without a tool.  From a warm page cache
-    that takes 3 s; on a box whose storage is cold the loader's access pattern pulls the files in at 10-14 MB/s
-    (process in D state, ``submit_bio_wait``) and the call takes 130-165 s -- the "rocprofiler-sdk start-up stall" of
-    rounds 1-2 (tools/debug/ktrace_stall_io.sh, ktrace_eager_load.py).  The same storage delivers the same files at
-    ~900 MB/s when they are read front to back, so that is what this thread does, before HIP starts.
-    ``NVRX_KTRACE_PREFETCH=0`` turns it off."""
-    if os.environ.get("NVRX_KTRACE_PREFETCH", "1") in ("0", ""):
+    that takes 3 s; on a box whose storage is cold 1.5-1.8 GB of it come from storage at 10-14 MB/s (process in D
+    state, ``submit_bio_wait``) and the call takes 130-165 s -- the "rocprofiler-sdk start-up stall" of rounds 1-2
+    (tools/debug/ktrace_stall_io.sh, ktrace_eager_load.py).  Reading the files front to back was measured at ~900 MB/s on
+    one box (there the read-ahead turns minutes into seconds) but a box that is slow for sequential reads as well
+    gains nothing and reads 5.3 GB instead of 1.8: a cold box still ran into the 150 s limit of the GPU test with the
+    read-ahead on.  Hence opt-in, for deployments that know their storage."""
+    if os.environ.get("NVRX_KTRACE_PREFETCH", "0") in ("0", ""):
         return None
 
     def run() -> None:
@@ -247,7 +249,7 @@ class KernelTraceProfiler:
             import torch
 
             if _prefetch_thread is not None:
-                _prefetch_thread.join(timeout=180.0)  # let the read-ahead finish before HIP starts reading page by page
+                _prefetch_thread.join(timeout=60.0)  # (opt-in read-ahead: let it finish before HIP starts reading page by page)
             torch.cuda.init()  # the SDK calls the tool's initialiser when the runtime comes up
             if not self._lib.nvrx_ktrace_ready():
                 raise RuntimeError(

@@ -10,8 +10,9 @@ The first HIP call of a process with this tool attached is slow where storage is
 object of every loaded library eagerly (10.7 GB of read() calls on this image, 0.00 GB without a tool) and the
 loader's access pattern pulls them in at 10-14 MB/s -- 130-165 s on such a box, 3 s from a warm page cache
 (tools/debug/ktrace_stall_io.sh, ktrace_eager_load.py; rounds 1-2 knew it as "rocprofiler-sdk's start-up stall").
-``ktrace`` now reads the libraries ahead sequentially (~900 MB/s on the same storage) before HIP starts; the scenario
-still gets 150 s and is reported as XFAIL with the measured wait if a box is slower than that."""
+An opt-in sequential read-ahead exists (``NVRX_KTRACE_PREFETCH=1``: ~900 MB/s on one box, no help on a box whose
+storage is slow either way); the scenario gets 150 s and is reported as XFAIL with the measured wait if a box is
+slower than that."""
 import json
 import os
 import subprocess
