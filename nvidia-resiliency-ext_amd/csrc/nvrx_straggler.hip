@@ -2546,6 +2546,10 @@ static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K
 
 int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
                       void *stream) {
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->side_work = true;  // the caller decides when this stream is waited for: no re-homing until that is known
+    }
     return report_local_impl(ctx, d_stats, d_send, K, S, names_ok, rows_active, stream, nullptr, 0);
 }
 
