@@ -336,10 +336,14 @@ def _per_kernel_leg(reports: int = 12):
 
 
 def _kernel_source_sha() -> str:
+    """sha256 (16 hex digits) of the text of ``k_row_stats`` -- everything between its header comment and the next kernel's
+    -- in csrc/nvrx_straggler.hip: the traffic figure belongs to that kernel, host-side edits of the file do not touch it."""
     import hashlib
 
     with open(os.path.join(REPO, "nvidia-resiliency-ext_amd", "csrc", "nvrx_straggler.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+        text = f.read()
+    a, b = text.find(b"// k_row_stats: one workgroup per timing row."), text.find(b"// k_scatter:")
+    return hashlib.sha256(text[a:b] if 0 <= a < b else text).hexdigest()[:16]
 
 
 def _pmc_traffic(rows: int):

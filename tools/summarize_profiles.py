@@ -34,10 +34,13 @@ def short(name):
 
 
 def kernel_source_sha():
+    """The same hash bench.py computes: the text of k_row_stats only (its header comment up to the next kernel's)."""
     import hashlib
 
     with open(os.path.join(REPO, "nvidia-resiliency-ext_amd", "csrc", "nvrx_straggler.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+        text = f.read()
+    a, b = text.find(b"// k_row_stats: one workgroup per timing row."), text.find(b"// k_scatter:")
+    return hashlib.sha256(text[a:b] if 0 <= a < b else text).hexdigest()[:16]
 
 
 def pmc(dirname, counter):
