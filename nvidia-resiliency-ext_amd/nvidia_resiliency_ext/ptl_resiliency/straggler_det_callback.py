@@ -86,12 +86,6 @@ class StragglerDetectionCallback(Callback):
         self.interval_est_was_reset = False
 
     # ---- Lightning hooks -----------------------------------------------------------------------
-    def _wrap_ptl_callables(self, trainer):
-        assert getattr(trainer.strategy, "training_step", None), (
-            f"{type(trainer.strategy)} does not have 'training_step' method."
-        )
-        straggler.Detector.wrap_callables(callable_ids=[straggler.CallableId(trainer.strategy, "training_step")])
-
     def setup(self, trainer, pl_module, stage):
         if self.initialized:
             return
@@ -101,7 +95,10 @@ class StragglerDetectionCallback(Callback):
             profiling_interval=self.profiling_interval,
             report_time_interval=self.report_time_interval,
         )
-        self._wrap_ptl_callables(trainer)
+        step_owner = trainer.strategy
+        assert getattr(step_owner, "training_step", None), f"{type(step_owner)} does not have 'training_step' method."
+        # every training step becomes a profiled section named "<Strategy class>.training_step"
+        straggler.Detector.wrap_callables(callable_ids=[straggler.CallableId(step_owner, "training_step")])
         self.initialized = True
 
     def teardown(self, trainer, pl_module, stage):
@@ -110,108 +107,103 @@ class StragglerDetectionCallback(Callback):
             self.initialized = False
 
     def on_train_batch_end(self, trainer, pl_module, outputs, batch, batch_idx):
-        t0 = time.monotonic()
-        report = straggler.Detector.generate_report_if_interval_elapsed()
-        found = False
-        if trainer.global_rank == 0 and report:
-            found = self._handle_straggler_report(pl_module, report)
-        if straggler.Detector.is_interval_elapsed():  # a report was produced this iteration
-            if self.stop_if_detected and self._gather_flag_from_rank0(found):
-                self._stop_training(trainer)
-            self.logger.info(f"Straggler report processing time: {time.monotonic() - t0:.3f} sec.")
+        started = time.monotonic()
+        detector = straggler.Detector
+        report = detector.generate_report_if_interval_elapsed()
+        # gather_on_rank0: rank 0 alone holds the report and decides; the decision reaches the others below
+        found = bool(report) and trainer.global_rank == 0 and self._digest(pl_module, report)
+        if not detector.is_interval_elapsed():
+            return  # no report was due this iteration
+        if self.stop_if_detected and self._decision_of_rank0(found):
+            self._halt(trainer)
+        self.logger.info(f"Straggler report processing time: {time.monotonic() - started:.3f} sec.")
 
-    # ---- report handling -------------------------------------------------------------------------
-    def _print_stragglers(self, stragglers):
-        rel = stragglers["straggler_gpus_relative"]
-        if rel:
-            self.logger.warning(
-                f"STRAGGLER DETECTION WARNING: Some GPUs have worse relative performance. Affected ranks: {rel}"
-            )
-        indiv = stragglers["straggler_gpus_individual"]
-        if indiv:
-            self.logger.warning(
-                f"STRAGGLER DETECTION WARNING: Some GPUs performance dropped. Affected ranks: {indiv}"
-            )
-        # MI355X extra: when the reporting rank itself is flagged, say what ROCm SMI sees on its GPU
-        # (clock below peak, hot junction, power) -- the first things to rule out for a slow GPU
-        me = getattr(straggler.Detector.reporter, "rank", None) if straggler.Detector.initialized else None
-        if me is not None and any(getattr(s, "rank", None) == me for s in list(rel) + list(indiv)):
-            self.logger.warning(f"rank {me}: {straggler.Detector.gpu_telemetry_line()}")
+    # ---- what happens with a report (rank 0) -----------------------------------------------------------
+    #: (constructor switch, Report field, identify_stragglers key, heading, logging prefix, warning text)
+    _FAMILIES = (
+        ("calc_relative_gpu_perf", "gpu_relative_perf_scores", "straggler_gpus_relative", "GPU relative performance",
+         "gpu_relative_perf", "Some GPUs have worse relative performance."),
+        ("calc_individual_gpu_perf", "gpu_individual_perf_scores", "straggler_gpus_individual", "GPU individual performance",
+         "gpu_individual_perf", "Some GPUs performance dropped."),
+    )
 
-    @staticmethod
-    def _format_gpu_scores(rank_to_score, rank_to_node, num_best=3, num_worst=3) -> str:
-        ordered = sorted(((s, r) for r, s in rank_to_score.items()), reverse=True)  # best first
-        n = len(ordered)
-
-        def line(s, r):
-            return f"  Rank={r} Node={rank_to_node[r]} Score={s:.2f}\n"
-
-        if n <= num_best + num_worst:
-            return "".join(line(s, r) for s, r in reversed(ordered))
-        out = f" Worst performing {num_worst}/{n} ranks:\n"
-        out += "".join(line(s, r) for s, r in reversed(ordered[-num_worst:]))
-        out += f" Best performing {num_best}/{n} ranks:\n"
-        out += "".join(line(s, r) for s, r in ordered[:num_best])
-        return out
-
-    def _print_gpu_scores(self, report):
-        assert self.num_gpu_perf_scores_to_print > 0
-        n = self.num_gpu_perf_scores_to_print
-        if self.calc_relative_gpu_perf:
-            text = self._format_gpu_scores(report.gpu_relative_perf_scores, report.rank_to_node, n, n)
-            self.logger.info(f"\nGPU relative performance:\n{text}")
-        if self.calc_individual_gpu_perf:
-            text = self._format_gpu_scores(report.gpu_individual_perf_scores, report.rank_to_node, n, n)
-            self.logger.info(f"\nGPU individual performance:\n{text}")
-
-    def _log_gpu_perf_scores(self, pl_module, rank_to_score, rank_to_node, score_prefix):
-        lo = med = hi = float("nan")
-        values = list(rank_to_score.values())
-        if values:
-            t = torch.tensor(values, dtype=torch.float32)
-            lo, med, hi = torch.min(t).item(), torch.median(t).item(), torch.max(t).item()
-        payload = {f"{score_prefix}/min": lo, f"{score_prefix}/median": med, f"{score_prefix}/max": hi}
-        try:
-            pl_module.log_dict(payload, logger=True, batch_size=1, rank_zero_only=True)
-        except Exception as e:  # logging must never take training down
-            self.logger.error(f"Failed to log GPU performance scores: {e}")
-
-    def _log_gpu_scores(self, pl_module, report):
-        assert self.enable_ptl_logging is True
-        if self.calc_relative_gpu_perf:
-            self._log_gpu_perf_scores(pl_module, report.gpu_relative_perf_scores, report.rank_to_node, "gpu_relative_perf")
-        if self.calc_individual_gpu_perf:
-            self._log_gpu_perf_scores(pl_module, report.gpu_individual_perf_scores, report.rank_to_node, "gpu_individual_perf")
-
-    def _handle_straggler_report(self, pl_module, report) -> bool:
-        stragglers = report.identify_stragglers(
+    def _digest(self, pl_module, report) -> bool:
+        """Warn about flagged GPUs, print the best / worst ranks, feed the PTL loggers; True if anything was flagged."""
+        flagged = report.identify_stragglers(
             gpu_rel_threshold=self.gpu_relative_perf_threshold,
             gpu_indiv_threshold=self.gpu_individual_perf_threshold,
         )
-        found = bool(stragglers["straggler_gpus_relative"] or stragglers["straggler_gpus_individual"])
-        if found:
-            self._print_stragglers(stragglers)
-        if self.num_gpu_perf_scores_to_print > 0:
-            self._print_gpu_scores(report)
+        hits = [(text, flagged[key]) for _, _, key, _, _, text in self._FAMILIES if flagged[key]]
+        for text, ranks in hits:
+            self.logger.warning(f"STRAGGLER DETECTION WARNING: {text} Affected ranks: {ranks}")
+        if hits:
+            self._telemetry_of_a_flagged_reporter(ranks for _, ranks in hits)
+        enabled = [f for f in self._FAMILIES if getattr(self, f[0])]
+        n = self.num_gpu_perf_scores_to_print
+        if n > 0:
+            for _, field, _, heading, _, _ in enabled:
+                self.logger.info(f"\n{heading}:\n{self._ranking(getattr(report, field), report.rank_to_node, n, n)}")
         if self.enable_ptl_logging:
-            self._log_gpu_scores(pl_module, report)
-        return found
+            for _, field, _, _, prefix, _ in enabled:
+                self._log_extremes(pl_module, getattr(report, field), prefix)
+        return bool(hits)
 
-    def _gather_flag_from_rank0(self, flag) -> bool:
+    def _telemetry_of_a_flagged_reporter(self, groups) -> None:
+        # MI355X extra: when the reporting rank itself is flagged, say what ROCm SMI sees on its GPU (clock below
+        # peak, hot junction, power) -- the first things to rule out for a slow GPU
+        det = straggler.Detector
+        me = getattr(det.reporter, "rank", None) if det.initialized else None
+        if me is not None and any(getattr(s, "rank", None) == me for group in groups for s in group):
+            self.logger.warning(f"rank {me}: {det.gpu_telemetry_line()}")
+
+    @staticmethod
+    def _ranking(rank_to_score, rank_to_node, num_best=3, num_worst=3) -> str:
+        """Worst ``num_worst`` and best ``num_best`` ranks (all of them if there are no more than that), one
+        ``Rank= Node= Score=`` line each; ties go by rank, as sorting (score, rank) pairs gives them."""
+        ascending = sorted((score, rank) for rank, score in rank_to_score.items())
+        total = len(ascending)
+
+        def lines(pairs):
+            return "".join(f"  Rank={rank} Node={rank_to_node[rank]} Score={score:.2f}\n" for score, rank in pairs)
+
+        if total <= num_best + num_worst:
+            return lines(ascending)
+        return (f" Worst performing {num_worst}/{total} ranks:\n" + lines(ascending[:num_worst])
+                + f" Best performing {num_best}/{total} ranks:\n" + lines(reversed(ascending[-num_best:])))
+
+    # the reference's name for the same text (a static helper some users call directly)
+    _format_gpu_scores = _ranking
+
+    def _log_extremes(self, pl_module, rank_to_score, prefix) -> None:
+        """min / median / max of one score family to every PTL logger; NaN when the family is empty."""
+        stats = dict.fromkeys(("min", "median", "max"), float("nan"))
+        if rank_to_score:
+            t = torch.tensor(list(rank_to_score.values()), dtype=torch.float32)
+            stats = {"min": torch.min(t).item(), "median": torch.median(t).item(), "max": torch.max(t).item()}
+        try:
+            pl_module.log_dict({f"{prefix}/{k}": v for k, v in stats.items()}, logger=True, batch_size=1, rank_zero_only=True)
+        except Exception as e:  # logging must never take training down
+            self.logger.error(f"Failed to log GPU performance scores: {e}")
+
+    # ---- stopping the job -----------------------------------------------------------------------------
+    def _decision_of_rank0(self, flag) -> bool:
+        """Rank 0's verdict on every rank (a broadcast on the process group's own device; no group: the flag)."""
         if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             return bool(flag)
         t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=dist_utils.get_device_for_backend(None))
         torch.distributed.broadcast(t, 0)
         return bool(t.item() > 0)
 
-    def _stop_training(self, trainer) -> None:
+    def _halt(self, trainer) -> None:
         self.logger.error("Detected stragglers. Terminating training...")
         trainer.should_stop = True
-        ckpt = trainer.checkpoint_callback
-        if ckpt:
-            ckpt._save_last_checkpoint(trainer, ckpt._monitor_candidates(trainer))
-            io = trainer.strategy.checkpoint_io
-            if hasattr(io, "maybe_finalize_save_checkpoint"):
-                self.logger.info("Async checkpointing detected, waiting for it to complete...")
-                io.maybe_finalize_save_checkpoint(blocking=True)
-            sys.exit(1)
+        checkpointing = trainer.checkpoint_callback
+        if not checkpointing:
+            return
+        # a last checkpoint, an asynchronous one awaited, then out
+        checkpointing._save_last_checkpoint(trainer, checkpointing._monitor_candidates(trainer))
+        finalize = getattr(trainer.strategy.checkpoint_io, "maybe_finalize_save_checkpoint", None)
+        if finalize is not None:
+            self.logger.info("Async checkpointing detected, waiting for it to complete...")
+            finalize(blocking=True)
+        sys.exit(1)

@@ -156,7 +156,7 @@ def drive(callback_cls, straggler_module, report_cls, scenario, patch_gather=Fal
     try:
         cb = callback_cls(logger_name=logger_name, **CONFIGS[config])
         if patch_gather:
-            cb._gather_flag_from_rank0 = lambda flag: bool(flag)   # the reference's needs a CUDA device (:231-238)
+            setattr(cb, "_gather_flag_from_rank0", lambda flag: bool(flag))   # the reference's needs a CUDA device (:231-238)
         trainer, module = Trainer(), Module()
         cb.setup(trainer, module, "fit")
         cb.setup(trainer, module, "fit")   # second call must be a no-op
