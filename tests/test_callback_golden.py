@@ -63,3 +63,43 @@ def test_the_golden_exercises_every_branch_of_the_callback():
     g = _golden()["scenarios"]
     assert any(it["exit"] == 1 for sc in g for it in sc["iterations"])
     assert any(p[k] is None for sc in g for it in sc["iterations"] for p, _ in it["log_dict"] for k in p)
+
+
+def test_a_flagged_reporter_adds_one_telemetry_line_and_nothing_else_changes(caplog):
+    """The one branch the reference callback does not have: with the ``Detector`` live and the REPORTING rank among the
+    flagged ones, one extra warning carries what ROCm SMI sees on its GPU (here, without a GPU, the 'unavailable' text);
+    a flagged set without the reporter, or a detector that is not initialised, logs exactly the reference's lines."""
+    import logging
+
+    from nvrx_straggler import Detector, backend
+    from oracle_backend import OracleBackend
+
+    cls, _, report_cls = _ours()
+    cb = cls(**dict(callback_script.CONFIGS["print2_log_stop"], logger_name="test.straggler.telemetry"))
+    specs = callback_script.reports(8)
+    with_reporter, without_reporter = report_cls(**specs[5]), report_cls(**specs[3])   # ranks {0, 5} / {3} flagged
+
+    class _Module:
+        def log_dict(self, payload, **kw):
+            pass
+
+    def lines(report):
+        caplog.clear()
+        assert cb._digest(_Module(), report) is True
+        return [r.getMessage() for r in caplog.records if r.levelno == logging.WARNING]
+
+    caplog.set_level(logging.INFO, logger="test.straggler.telemetry")
+    assert not Detector.initialized
+    cold = lines(with_reporter)
+    assert len(cold) == 2 and all(m.startswith("STRAGGLER DETECTION WARNING") for m in cold)
+    backend.set_backend(OracleBackend())
+    try:
+        Detector.initialize(scores_to_compute=["relative_perf_scores", "individual_perf_scores"], gather_on_rank0=True)
+        live = lines(with_reporter)
+        assert live[:2] == cold and len(live) == 3
+        assert live[2].startswith("rank 0: gpu telemetry")
+        assert lines(without_reporter) == [m for m in lines(without_reporter) if m.startswith("STRAGGLER DETECTION WARNING")]
+        assert len(lines(without_reporter)) == 1
+    finally:
+        Detector.shutdown()
+        backend.set_backend(None)
