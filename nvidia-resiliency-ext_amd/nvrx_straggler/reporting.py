@@ -638,14 +638,18 @@ class ReportGenerator:
         from . import peer_exchange, rccl_direct
 
         index = getattr(be.device, "index", None)
+        # the exchange kernel gives up a little BEFORE the host's wait for the completion word does: a peer that is
+        # later than the report timeout then surfaces as the exchange's own error (NaN rows, error word, the next
+        # report unaffected) instead of a timed-out wait that retires the workspace under a still-spinning kernel
+        peer_wait_s = 0.9 * _backend_mod.report_timeout_s() or 1e9
         rccl = rccl_direct.create(self.group, index)
         peer = None
         mode = peer_exchange.exchange_mode()
         if mode != "rccl" and (rccl is not None or mode == "peer"):
             # windows need a group that can reach every rank's GPU: built next to the RCCL route (a gloo group whose
             # ranks share one GPU qualifies too when asked for explicitly: that is how the tests run it)
-            peer = peer_exchange.create(self.group, index, _backend_mod.report_timeout_s() or 1e9)
-        self._direct, self.exchange_info = (peer_exchange.choose(self.group, be, rccl, peer, _backend_mod.report_timeout_s() or 1e9)
+            peer = peer_exchange.create(self.group, index, peer_wait_s)
+        self._direct, self.exchange_info = (peer_exchange.choose(self.group, be, rccl, peer, peer_wait_s)
                                             if (rccl or peer) else (None, {}))
         if self._direct is not None:
             self.exchange_info["route"] = getattr(self._direct, "route", "ncclAllGather on the detector's stream")
@@ -867,14 +871,15 @@ class ReportGenerator:
             rings.report_local(ws, True, rows_active=plan.rows_used)
             be.score(ws, ws.send, self.is_computing_indiv_scores, self.is_computing_rel_scores, self.thresholds,
                      wait=True, stats_rows=plan.stats_needed)
-        if multi:
-            self._check_exchange()
         if fused:
-            # a resident score kernel forwards the statistics rows AFTER the scores: whatever this call returns, the
-            # next user of the workspace must see them landed (meta[5]) before it enqueues anything that writes them
+            # a resident score kernel forwards the statistics rows AFTER the scores: whatever this call returns or
+            # raises, the next user of the workspace must see them landed (meta[5]) before it enqueues anything that
+            # writes them
             mark = getattr(ws, "mark_live", None)  # (the CPU checker backend of the tests has no deferred rows)
             if mark is not None:
                 mark(ws.seq)
+        if multi:
+            self._check_exchange()  # a peer that never arrived: this report's scores are invalid, the next one is not
         if ws.meta[0] != 1:
             return False  # another rank met a new name: fall back to the general (name-syncing) path
         if self.gather_on_rank0 and self.rank != 0:

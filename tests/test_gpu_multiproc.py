@@ -179,6 +179,28 @@ def test_config2_loop_over_peer_windows(asynchronous):
         compare_reports(got, exp, ("loop-peer", asynchronous, t), rel=1e-4)
 
 
+def test_a_process_later_than_the_exchange_wait_fails_one_report_and_only_that_one():
+    """delay one rank past the peer-window exchange's bounded wait.  Two processes x 4 logical ranks; the
+    second reaches report 3 a second after the first one's exchange kernel has given up (0.4 s): rank 0's report 3
+    raises the exchange's own error, ONCE; the late process' report completes; reports 4..9 are the reference's again
+    (the error word keeps the old epoch and is not raised a second time; the windows' parity / epoch protocol is back in
+    step without any resynchronisation)."""
+    g = load_golden("loop.json")
+    res = run_ranks(workers.folded_loop_late_process, 2, timeout=150, use_oracle_backend=False, device=0, env=_PEER_ENV,
+                    late_report=3, late_by_s=1.5, peer_wait_s=0.4)
+    assert res[0]["route"].startswith("xGMI peer stores")
+    assert [t for t, _ in res[0]["raised"]] == [3] and "did not publish its row" in res[0]["raised"][0][1]
+    assert res[1]["raised"] == [] and res[1]["timed_out_epoch"] == 0 and res[0]["timed_out_epoch"] != 0
+    assert all(rep is None for rep in res[1]["reports"])
+    for t, exp in enumerate(g["rank0_reports"]):
+        got = res[0]["reports"][t]
+        if t == 3:
+            assert got == "raised"
+            continue
+        got["rank_to_node"] = exp["rank_to_node"]
+        compare_reports(got, exp, ("loop-peer-late", t), rel=1e-4)
+
+
 def test_ptl_callback_on_hip_backend_flags_the_slow_gpu():
     """StragglerDetectionCallback (duck-typed trainer; Lightning is not in the image) on the HIP backend, two ranks
     sharing the GPU: training_step is wrapped into a GPU-timed section, reports come on the time-derived interval, the

@@ -411,6 +411,46 @@ def folded_loop_config2(rank, world, asynchronous):
         job.close()
 
 
+def folded_loop_late_process(rank, world, late_report, late_by_s, peer_wait_s):
+    """Config #2 as in folded_loop_config2, but the LAST process reaches report `late_report` `late_by_s` seconds after
+    the others, whose exchange kernels give up on it after `peer_wait_s`: their report raises (once), the late process'
+    own report completes (its peers' rows were published long ago), and every later report is the golden one again."""
+    import torch.distributed as dist
+
+    import synth
+    from nvrx_straggler import _native
+    from nvrx_straggler.folded import FoldedJob
+
+    cfg = {"S": 4, "n": 100, "reports": 10, "slow_rank": 3, "slow_factor": 1.2, "slow_from": 5}
+    names = [synth.section_name(s) for s in range(cfg["S"])]
+    job = FoldedJob(total_ranks=8, section_names=names, ring_cap=8192, node_name=f"node{rank}")
+    try:
+        out, raised = [], []
+        for t in range(cfg["reports"]):
+            slow = cfg["slow_rank"] if t >= cfg["slow_from"] else -1
+            for lr, r in enumerate(job.logical_ranks()):
+                job.load(lr, synth.loop_samples(r, t, cfg["S"], cfg["n"], slow_rank=slow, slow_factor=cfg["slow_factor"]))
+            dist.barrier()
+            if t == late_report:
+                job.reporter._direct.set_timeout(peer_wait_s)
+                if rank == world - 1:
+                    time.sleep(late_by_s)
+            try:
+                out.append(report_to_plain(job.report(), (0.75, 0.9)))
+            except _native.NativeError as e:
+                raised.append((t, str(e)))
+                out.append("raised")
+                job.rings.reset()  # what job.report() would have done after the report
+            if t == late_report:
+                dist.barrier()  # the late process has finished the report the others gave up on
+                job.reporter._direct.set_timeout(20.0)
+        route = job.reporter._direct
+        return {"reports": out, "raised": raised, "route": getattr(route, "route", "none"),
+                "timed_out_epoch": route.timed_out_epoch()}
+    finally:
+        job.close()
+
+
 def ptl_callback_run(rank, world, slow_rank):
     """StragglerDetectionCallback driven by a duck-typed trainer (Lightning is not in the image): training_step does
     real GPU work when a GPU backend is active, the slow rank does 8x of it; returns what the callback logged/decided."""
