@@ -8,8 +8,26 @@ hipEvent profiler (``hip_profiler.CuptiProfiler``; import name ``nvrx_cupti_modu
 """
 from __future__ import annotations
 
+import functools
 import os
 import threading
+
+
+def _serialised(needs_init: bool = True):
+    """Every call into the native profiler holds the manager's lock; all but ``initialize`` / ``shutdown`` refuse to
+    run before ``initialize`` (the reference's RuntimeError text)."""
+
+    def wrap(method):
+        @functools.wraps(method)
+        def locked(self, *args, **kwargs):
+            with self.lock:
+                if needs_init and not self.is_initialized:
+                    raise RuntimeError("CuptiManager was not initialized")
+                return method(self, *args, **kwargs)
+
+        return locked
+
+    return wrap
 
 
 class CuptiManager:
@@ -22,73 +40,62 @@ class CuptiManager:
         """
         import nvrx_cupti_module as profiler_module  # lazy, like the reference (cupti.py:35)
 
-        kwargs = {} if rings is None else {"rings": rings}
         # NVRX_GPU_TIMING=kernels: per-kernel durations by kernel name through rocprofiler-sdk (ktrace.py);
         # otherwise one GPU-time row per profiled region (hip_profiler.py)
         self.per_kernel = os.environ.get("NVRX_GPU_TIMING", "stamp") == "kernels"
         profiler_cls = profiler_module.KernelTraceProfiler if self.per_kernel else profiler_module.CuptiProfiler
-        self.cupti_ext = profiler_cls(
-            bufferSize=bufferSize, numBuffers=numBuffers, statsMaxLenPerKernel=statsMaxLenPerKernel, **kwargs
-        )
-        self.is_initialized = False
-        self.started_cnt = 0
+        self.cupti_ext = profiler_cls(bufferSize=bufferSize, numBuffers=numBuffers, statsMaxLenPerKernel=statsMaxLenPerKernel,
+                                      **({} if rings is None else {"rings": rings}))
         self.lock = threading.Lock()
+        self.is_initialized = False
+        self.started_cnt = 0  # nesting depth of start_profiling(): only the outermost pair opens / closes a region
 
-    def _ensure_initialized(self):
-        if not self.is_initialized:
-            raise RuntimeError("CuptiManager was not initialized")
-
+    @_serialised(needs_init=False)
     def initialize(self):
-        with self.lock:
-            self.cupti_ext.initialize()
-            self.is_initialized = True
+        self.cupti_ext.initialize()
+        self.is_initialized = True
 
+    @_serialised(needs_init=False)
     def shutdown(self):
-        with self.lock:
-            self.cupti_ext.shutdown()
-            close = getattr(self.cupti_ext, "close", None)
-            if close is not None:
-                close()
-            self.is_initialized = False
-            self.started_cnt = 0
+        ext = self.cupti_ext
+        ext.shutdown()
+        getattr(ext, "close", lambda: None)()
+        self.is_initialized, self.started_cnt = False, 0
 
+    @_serialised()
     def start_profiling(self, key=None):
         """Enter a GPU-timed region; only the outermost entry records the start event."""
-        with self.lock:
-            self._ensure_initialized()
-            if self.started_cnt == 0:
-                if key is None:
-                    self.cupti_ext.start()
-                else:
-                    self.cupti_ext.start(key)
-            self.started_cnt += 1
+        self.started_cnt += 1
+        if self.started_cnt == 1:
+            try:
+                self.cupti_ext.start(*(() if key is None else (key,)))
+            except BaseException:
+                self.started_cnt = 0
+                raise
 
+    @_serialised()
     def stop_profiling(self, cpu_row: int = -1, cpu_value: float = 0.0) -> bool:
         """Leave a GPU-timed region.  ``cpu_row`` / ``cpu_value`` (optional): a host-measured sample the
         closing device kernel may append for the caller; True is returned when it was taken."""
-        with self.lock:
-            self._ensure_initialized()
-            if self.started_cnt <= 0:
-                raise RuntimeError("No active profiling run.")
-            self.started_cnt -= 1
-            if self.started_cnt == 0:
-                if cpu_row >= 0:
-                    return bool(self.cupti_ext.stop(cpu_row, cpu_value))
-                self.cupti_ext.stop()
+        if self.started_cnt <= 0:
+            raise RuntimeError("No active profiling run.")
+        self.started_cnt -= 1
+        if self.started_cnt:
+            return False  # an inner region of a nest: the outermost one is still open
+        if cpu_row < 0:
+            self.cupti_ext.stop()
             return False
+        return bool(self.cupti_ext.stop(cpu_row, cpu_value))
 
+    @_serialised()
     def harvest(self, wait: bool = True) -> int:
         """Bring every finished GPU measurement into the device rings (report time)."""
-        with self.lock:
-            self._ensure_initialized()
-            return self.cupti_ext.harvest(wait)
+        return self.cupti_ext.harvest(wait)
 
+    @_serialised()
     def get_results(self):
-        with self.lock:
-            self._ensure_initialized()
-            return dict(self.cupti_ext.get_stats())
+        return dict(self.cupti_ext.get_stats())  # a copy, as in the reference (cupti.py:88-89)
 
+    @_serialised()
     def reset_results(self):
-        with self.lock:
-            self._ensure_initialized()
-            self.cupti_ext.reset()
+        self.cupti_ext.reset()
