@@ -122,17 +122,21 @@ class Detector:
     (the device ring buffers).
     """
 
+    # configuration (set by initialize)
     initialized: bool = False
     scores_to_compute: Sequence[str]
     gather_on_rank0: bool
     profiling_interval: int
     report_time_interval: float
+    # state
+    rings: Any = None  # device ring buffers: one row per section / GPU-timed region
     custom_sections: Dict[str, CustomSection]
+    original_callables: Optional[Dict[CallableId, Any]]
+    # collaborators
     cupti_manager: Optional[CuptiManager]
     reporter: ReportGenerator
     report_interval_tracker: ReportIntervalTracker
-    original_callables: Optional[Dict[CallableId, Any]]
-    rings: Any = None
+    # which rows held samples at the last report, and the name -> row tables derived from that
     _occupied_key: Optional[bytes] = None
     _active_sections: Dict[str, int] = {}
     _active_kernels: Dict[str, int] = {}
@@ -166,44 +170,42 @@ class Detector:
                 False = the reference's synchronous behaviour.
         """
         assert not cls.initialized
+        everything = str(scores_to_compute) == "all"
+        cls.scores_to_compute = ["relative_perf_scores", "individual_perf_scores"] if everything else scores_to_compute
+        cls.gather_on_rank0, cls.profiling_interval = gather_on_rank0, profiling_interval
+        cls.report_time_interval = report_time_interval
+        cls.custom_sections, cls.original_callables, cls._occupied_key = {}, {}, None
 
-        cls.scores_to_compute = (
-            ["relative_perf_scores", "individual_perf_scores"] if str(scores_to_compute) == "all" else scores_to_compute
-        )
-        cls.gather_on_rank0 = gather_on_rank0
-        cls.profiling_interval = profiling_interval
-        cls.custom_sections = {}
-        cls._occupied_key = None
-        ring_cap = int(CustomSection.max_elapseds_len)
-        if os.environ.get("NVRX_GPU_TIMING", "") == "kernels" and int(max_rows) == 256:
+        # device side: the rings every section / GPU-timed region records into, and the profiler that feeds them
+        capacity = int(CustomSection.max_elapseds_len)
+        per_kernel = os.environ.get("NVRX_GPU_TIMING", "") == "kernels"
+        if per_kernel and int(max_rows) == 256:
             max_rows = 4096  # one row per distinct kernel key; 4096 x 8192 f32 = 128 MB of 288 GB
-        cls.rings = _backend_mod.get_backend().make_rings(1, int(max_rows), ring_cap)
-        cls.cupti_manager = CuptiManager(statsMaxLenPerKernel=ring_cap, rings=cls.rings)
+        cls.rings = _backend_mod.get_backend().make_rings(1, int(max_rows), capacity)
+        cls.cupti_manager = CuptiManager(statsMaxLenPerKernel=capacity, rings=cls.rings)
         cls.cupti_manager.initialize()
+
+        # host side: who scores, and when
         if asynchronous is None:
             asynchronous = os.environ.get("NVRX_ASYNC_REPORT", "0") not in ("", "0")
-        cls.reporter = ReportGenerator(
-            scores_to_compute=cls.scores_to_compute,
-            gather_on_rank0=gather_on_rank0,
-            node_name=(node_name if node_name else socket.gethostname()),
-            asynchronous=asynchronous,
-        )
-        cls.report_interval_tracker = ReportIntervalTracker(
-            time_interval=report_time_interval, profiling_interval=profiling_interval
-        )
+        cls.reporter = ReportGenerator(scores_to_compute=cls.scores_to_compute, gather_on_rank0=gather_on_rank0,
+                                       node_name=node_name or socket.gethostname(), asynchronous=asynchronous)
+        cls.report_interval_tracker = ReportIntervalTracker(time_interval=report_time_interval,
+                                                            profiling_interval=profiling_interval)
         cls.initialized = True
-        cls.original_callables = {}
 
     @classmethod
     def shutdown(cls):
-        cls.cupti_manager.shutdown()
+        """Undo ``initialize``: wrapped callables get their originals back, profiler, rings and exchange route close."""
+        manager, cls.cupti_manager = cls.cupti_manager, None
+        manager.shutdown()
         cls.restore_original_callables()
-        cls.cupti_manager = None
-        if cls.rings is not None:
-            cls.rings.close()
-            cls.rings = None
-        if getattr(cls, "reporter", None) is not None:
-            cls.reporter.close()
+        rings, cls.rings = cls.rings, None
+        if rings is not None:
+            rings.close()
+        reporter = getattr(cls, "reporter", None)
+        if reporter is not None:
+            reporter.close()
         cls.initialized = False
 
     # ---- system-side context (not in the reference) --------------------------------------------------
@@ -286,10 +288,9 @@ class Detector:
         """Call once per training iteration on every rank; reports when the (rank-synchronised)
         iteration interval has elapsed, otherwise returns None."""
         assert cls.initialized
-        cls.report_interval_tracker.iter_increase()
-        if cls.report_interval_tracker.is_interval_elapsed():
-            return cls.generate_report()
-        return None
+        tracker = cls.report_interval_tracker
+        tracker.iter_increase()
+        return cls.generate_report() if tracker.is_interval_elapsed() else None
 
     @classmethod
     def is_interval_elapsed(cls) -> bool:
@@ -355,27 +356,25 @@ class Detector:
     # ---- callable wrapping -------------------------------------------------------------------------
     @classmethod
     def _build_wrapper(cls, fn, callable_id, profile_cuda: bool = True):
-        section_name = str(callable_id)
+        """``fn`` run inside the section named after ``callable_id``."""
+        section = functools.partial(cls.detection_section, name=str(callable_id), profile_cuda=profile_cuda)
 
         @functools.wraps(fn)
-        def wrapper(*args, **kwargs):
-            with cls.detection_section(name=section_name, profile_cuda=profile_cuda):
+        def timed(*args, **kwargs):
+            with section():
                 return fn(*args, **kwargs)
 
-        return wrapper
+        return timed
 
     @classmethod
     def wrap_callables(cls, callable_ids: List[CallableId], profile_cuda: bool = True):
         """Replace each ``getattr(cid.obj, cid.name)`` by a version that runs inside
         ``detection_section(str(cid))``."""
-        cls.original_callables = {}
-        for cid in callable_ids:
-            original = getattr(cid.obj, cid.name)
-            cls.original_callables[cid] = original
+        cls.original_callables = {cid: getattr(cid.obj, cid.name) for cid in callable_ids}
+        for cid, original in cls.original_callables.items():
             setattr(cid.obj, cid.name, cls._build_wrapper(original, cid, profile_cuda=profile_cuda))
 
     @classmethod
     def restore_original_callables(cls):
-        if cls.original_callables:
-            for cid, original in cls.original_callables.items():
-                setattr(cid.obj, cid.name, original)
+        for cid, original in (cls.original_callables or {}).items():
+            setattr(cid.obj, cid.name, original)
