@@ -1,7 +1,6 @@
 """GPU parity of the statistics kernel and the device rings against the CPU oracle and the golden
 vectors from the real reference.  All calls go through the C ABI (ctypes)."""
 import ctypes
-import hashlib
 
 import numpy as np
 import pytest

@@ -14,7 +14,7 @@ import torch
 
 import workers
 from mp_util import run_ranks
-from util import close, compare_reports, load_golden
+from util import compare_reports, load_golden
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -2,7 +2,6 @@
 package -- tools/run_reference_tests.sh.  Skipped where the reference tree is absent (the GPU box)."""
 import os
 import subprocess
-import sys
 
 import pytest
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which selection path do the rows of the bench data take, and how long does k_row_stats run on different data?"""
-import os, sys, time
+import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (REPO, os.path.join(REPO, "nvidia-resiliency-ext_amd"), os.path.join(REPO, "tests", "golden")):
     sys.path.insert(0, p)
