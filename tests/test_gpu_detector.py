@@ -83,6 +83,48 @@ def test_stress_capacity_10000_vs_oracle():
         job.close()
 
 
+@pytest.mark.parametrize("R", [65, 96, 512])
+def test_one_call_report_beyond_the_single_workgroup_scorer(R):
+    """More ranks than `k_score1` takes (64): the one-call report goes through `k_colmin` + `k_score` (one workgroup
+    per rank), non-resident.  R logical ranks x 8 sections folded onto one GPU, two reports (the second one's
+    individual scores use the minima of both), every score against the oracle, flagged sets against the scores."""
+    from nvrx_straggler import Statistic
+    from nvrx_straggler.folded import FoldedJob
+
+    S, n = 8, 301
+    names = [synth.section_name(s) for s in range(S)]
+    job = FoldedJob(total_ranks=R, section_names=names, ring_cap=512, node_name="n")
+    try:
+        hist = None
+        slow = (R - 2, R // 3)
+        for t in range(2):
+            xs = [synth.stress_samples(r + 1000 * t, S, n, slow_rank=slow[t] + 1000 * t, slow_factor=1.5) for r in range(R)]
+            for r in range(R):
+                job.load(r, xs[r])
+            rep = job.report()
+            med = np.stack([oracle.rows_stats(xs[r], np.full(S, n, dtype=np.uint32))[:, 2] for r in range(R)])
+            hist = med if hist is None else np.minimum(hist, med)
+            T = np.zeros((R, oracle.table_len(0, S)), dtype=np.float32)
+            T[:, :S], T[:, S : 2 * S], T[:, -1] = med, hist, 1.0
+            exp = oracle.score_table(T, 0, S)
+            for s, name in enumerate(names):
+                rel, ind = rep.section_relative_perf_scores[name], rep.section_individual_perf_scores[name]
+                assert list(rel) == list(range(R))
+                for r in range(R):
+                    assert close(ind[r], exp[r, 2 + s], rel=1e-6), (t, name, r)
+                    assert close(rel[r], exp[r, 2 + S + s], rel=1e-6), (t, name, r)
+            got = rep.identify_stragglers()
+            assert {k: {x.rank for x in v} for k, v in got["straggler_sections_relative"].items()} == \
+                {name: {slow[t]} for name in names}
+            exp_ind = {name: {r for r in range(R) if exp[r, 2 + s] < 0.75} for s, name in enumerate(names)}
+            assert {k: {x.rank for x in v} for k, v in got["straggler_sections_individual"].items()} == \
+                {k: v for k, v in exp_ind.items() if v}
+            assert rep.local_section_summaries[names[0]][Statistic.NUM] == n
+            assert job.reporter._ring_plan.ws.meta[0] == 1
+    finally:
+        job.close()
+
+
 def test_detector_sleep_sections_single_rank():
     """Detector API end to end on one rank: NUM honours profiling_interval, report resets the rings,
     GPU-timed section produces a hipevent:: kernel summary, scores of a lone rank are 1."""

@@ -43,7 +43,7 @@ def _score(be, T, K, S, do_indiv=True, do_rel=True, thr=(0.75, 0.75, 0.75, 0.75)
 
 
 @pytest.mark.parametrize("R,K,S", [(1, 0, 1), (1, 3, 0), (2, 2, 2), (8, 0, 64), (8, 5, 6), (8, 4096, 8), (64, 17, 33),
-                                   (100, 7, 9), (3, 0, 0), (16, 13000, 40)])
+                                   (100, 7, 9), (3, 0, 0), (16, 13000, 40), (65, 0, 64), (1024, 0, 64), (4096, 32, 16)])
 def test_score_kernel_matches_oracle(be, R, K, S):
     rng = np.random.default_rng(R * 1000 + K + S)
     T = _random_table(rng, R, K, S)
