@@ -95,9 +95,9 @@ int nvrx_row_stats(const float *d_samples, const uint32_t *d_counts, const uint8
  *      flag [L-1]               1.0 if rank r has ids for all its names, else 0.0
  *   thresholds[4] = {gpu_rel, section_rel, gpu_indiv, section_indiv} (Report.identify_stragglers
  *      argument order, reporting.py:84-90); NULL => 0.75 each;
- *   d_scores [R][NVRX_SCORE_LEN(S)] f32 out, NaN where the reference reports NaN / nothing.  For R <= 64 one
- *      workgroup scores the whole table and writes d_scores / d_flags in 16-byte units when both are 16-byte
- *      aligned: pad each array to a multiple of 16 bytes;
+ *   d_scores [R][NVRX_SCORE_LEN(S)] f32 out, NaN where the reference reports NaN / nothing.  When d_scores and
+ *      d_flags are both 16-byte aligned they are written in 16-byte units (R <= 64: one workgroup scores the whole
+ *      table; larger jobs: one workgroup per tile of 16 ranks): pad each array to a multiple of 16 bytes;
  *   d_flags  [R][NVRX_SCORE_LEN(S)] u8 out, 1 where score < threshold (strict; NaN never flagged);
  *   d_meta   [NVRX_META_WORDS] u32 out: {all ranks' name flags set, R, K, S, seq, seq of the statistics rows,
  *      wait for the rows [10 ns ticks], (last row -> scores staged) << 16 | (last row -> completion word) [10 ns ticks, 16 bits each]}

@@ -1065,6 +1065,8 @@ __global__ void k_send_init(float *send, int rows, int K, int S) {
     send[i] = v;
 }
 
+typedef float nvrx_f4 __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------------------------------------
 // k_colmin / k_score: cross-rank scoring on the exchanged table (layout in nvrx_straggler.h).
 // ------------------------------------------------------------------------------------------------
@@ -1116,6 +1118,170 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(ScoreArgs a) {
             if (ticket == (uint32_t)a.R - 1u) {
                 *a.done_counter = 0u;  // ready for the next launch (launches on one stream are ordered)
                 a.meta[5] = a.seq;     // statistics were forwarded by every block before its ticket
+                __threadfence_system();
+                __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Jobs beyond the single-workgroup scorer (R > 64 ranks): k_colmin_part / k_colmin_finish + k_score_tile.
+//
+// k_colmin walks the R rows of a column with ONE lane and k_score spends a workgroup, a system-scope fence and a
+// device-scope ticket on every rank (the ticket alone: ~40 ns x R on one word), so both grow linearly with the job:
+// 189 us at 1024 ranks x 64 sections, 728 us at 4096 (tools/score_scale.py).  Here the column minima are taken in two
+// levels (row chunks x 64-column tiles, four waves per workgroup striding the chunk's rows with eight loads in flight
+// each; a second, tiny pass folds the <= 32 chunk minima and applies the -1 -> NaN rule), and one workgroup scores a TILE
+// of 8 or 16 ranks: results staged in LDS, stored to the (pinned) result block as 16-byte units, one fence and one
+// ticket per tile.  Same arithmetic as score_rank (section scores: the f64 quotient rounded to f32; GPU scores: f64
+// sums, one wave per rank), so the oracle comparisons of k_score apply unchanged.
+// ------------------------------------------------------------------------------------------------
+constexpr int COLMIN_MAX_CHUNKS = 32;
+
+__global__ __launch_bounds__(256) void k_colmin_part(const float *__restrict__ table, int R, int KS, int L,
+                                                     int rows_per_chunk, float *__restrict__ part) {
+    __shared__ float s_m[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int r_end = min(R, ((int)blockIdx.y + 1) * rows_per_chunk);
+    float m = INFINITY;
+    if (j < KS) {
+        for (int r = (int)blockIdx.y * rows_per_chunk + wave; r < r_end; r += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = r + 4 * u < r_end ? table[(size_t)(r + 4 * u) * L + j] : INFINITY;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (v[u] < m) m = v[u];
+        }
+    }
+    s_m[wave][lane] = m;
+    __syncthreads();
+    if (wave == 0 && j < KS) {
+#pragma unroll
+        for (int w = 1; w < 4; w++)
+            if (s_m[w][lane] < m) m = s_m[w][lane];
+        part[(size_t)blockIdx.y * KS + j] = m;
+    }
+}
+
+__global__ void k_colmin_finish(const float *__restrict__ part, int chunks, int KS, float *__restrict__ minmed) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= KS) return;
+    float m = INFINITY;
+    for (int c = 0; c < chunks; c++) {
+        const float v = part[(size_t)c * KS + j];
+        if (v < m) m = v;
+    }
+    minmed[j] = m >= 0.0f ? m : __builtin_nanf("");  // reporting.py:289,295
+}
+
+constexpr int TILE_THREADS = 256;
+constexpr size_t TILE_MAX_LDS = 48 * 1024;
+
+__host__ __device__ inline size_t score_tile_lds_bytes(int ranks, int S) {
+    const size_t nout = (size_t)ranks * NVRX_SCORE_LEN(S);
+    return ((nout + 3) & ~(size_t)3) * 4 + ((nout + 15) & ~(size_t)15);
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void k_score_tile(ScoreArgs a, int tile_ranks) {
+    extern __shared__ __attribute__((aligned(16))) float s_tile[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, S = a.S, KS = K + S, W = NVRX_SCORE_LEN(S);
+    const int L = NVRX_TABLE_LEN(K, S);
+    const int r0 = (int)blockIdx.x * tile_ranks;
+    const int n = min(tile_ranks, a.R - r0);
+    const int nout = n * W, nout4 = (nout + 3) & ~3, nfl16 = (nout + 15) & ~15;
+    float *s_out = s_tile;
+    uint8_t *s_fl = reinterpret_cast<uint8_t *>(s_tile + nout4);
+    const float *__restrict__ minmed = a.minmed_pre;
+    const float NaN = __builtin_nanf("");
+
+    // forward the local statistics rows next to the scores (keeps PCIe stores out of k_row_stats)
+    for (int i = (int)blockIdx.x * TILE_THREADS + tid; i < a.stats_n4; i += (int)gridDim.x * TILE_THREADS)
+        a.stats_dst[i] = a.stats_src[i];
+    // the padding of the staged arrays is stored too
+    if (tid < nout4 - nout) s_out[nout + tid] = 0.f;
+    if (tid < nfl16 - nout) s_fl[nout + tid] = 0;
+
+    // section scores: reference / MED (reporting.py:196-217), rounded to f32 (reporting.py:352); every (rank, section)
+    // pair of the tile is independent
+    for (int idx = tid; idx < n * S; idx += TILE_THREADS) {
+        const int q = idx / S, sct = idx - q * S;
+        const float *__restrict__ row = a.table + (size_t)(r0 + q) * L;
+        const float med = row[K + sct];
+        float si = NaN, sr = NaN;
+        if (med >= 0.0f) {
+            if (a.do_indiv) si = (float)((double)row[KS + K + sct] / (double)med);
+            if (a.do_rel) sr = (float)((double)minmed[K + sct] / (double)med);
+        }
+        s_out[q * W + 2 + sct] = si;
+        s_out[q * W + 2 + S + sct] = sr;
+        s_fl[q * W + 2 + sct] = ((double)si < a.thr[3]) ? 1 : 0;
+        s_fl[q * W + 2 + S + sct] = ((double)sr < a.thr[1]) ? 1 : 0;
+    }
+    // GPU scores: weighted mean of per-kernel ratios (reporting.py:219-253), one wave per rank
+    for (int q = wave; q < n; q += TILE_THREADS / 64) {
+        const float *__restrict__ row = a.table + (size_t)(r0 + q) * L;
+        double wi = 0.0, si = 0.0, wr = 0.0, sr = 0.0;
+        uint32_t nk = 0, ncommon = 0;
+        for (int k = lane; k < K; k += 64) {
+            const float medf = row[k];
+            if (!(medf >= 0.0f)) continue;
+            const double med = (double)medf;
+            const double w = (double)row[2 * KS + k];
+            nk++;
+            si += ((double)row[KS + k] / med) * w;
+            wi += w;
+            const float mm = minmed[k];
+            if (mm == mm) {
+                ncommon++;
+                sr += ((double)mm / med) * w;
+                wr += w;
+            }
+        }
+        if (K > 0) {  // wave-uniform
+            wi = wave_sum_f64(wi);
+            si = wave_sum_f64(si);
+            wr = wave_sum_f64(wr);
+            sr = wave_sum_f64(sr);
+            nk = wave_sum_u32(nk);
+            ncommon = wave_sum_u32(ncommon);
+        }
+        if (lane == 0) {
+            const float gi = (a.do_indiv && nk > 0) ? (float)(si / wi) : NaN;  // no kernels -> NaN, never flagged
+            const float gr = (a.do_rel && ncommon > 0) ? (float)(sr / wr) : NaN;
+            s_out[q * W] = gi;
+            s_out[q * W + 1] = gr;
+            s_fl[q * W] = ((double)gi < a.thr[2]) ? 1 : 0;
+            s_fl[q * W + 1] = ((double)gr < a.thr[0]) ? 1 : 0;
+        }
+    }
+    if (blockIdx.x == 0 && a.meta && wave == 1) score_meta(a, a.table, lane);
+    __syncthreads();
+
+    // staged results -> result block, 16 bytes per lane (the tile's rows are one contiguous, 16-byte aligned span)
+    {
+        const nvrx_f4 *src = reinterpret_cast<const nvrx_f4 *>(s_out);
+        nvrx_f4 *dst = reinterpret_cast<nvrx_f4 *>(a.scores + (size_t)r0 * W);
+        for (int i = tid; i < nout4 / 4; i += TILE_THREADS) dst[i] = src[i];
+        if (a.flags) {
+            const nvrx_f4 *fsrc = reinterpret_cast<const nvrx_f4 *>(s_fl);
+            nvrx_f4 *fdst = reinterpret_cast<nvrx_f4 *>(a.flags + (size_t)r0 * W);
+            for (int i = tid; i < nfl16 / 16; i += TILE_THREADS) fdst[i] = fsrc[i];
+        }
+    }
+    if (a.done_counter) {
+        // completion word for a polling host, as in k_score: every tile makes its stores visible system-wide, then
+        // takes a ticket; the last one publishes `seq`
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t ticket = atomicAdd(a.done_counter, 1u);
+            if (ticket == gridDim.x - 1u) {
+                *a.done_counter = 0u;  // ready for the next launch (launches on one stream are ordered)
+                a.meta[5] = a.seq;     // statistics were forwarded by every tile before its ticket
                 __threadfence_system();
                 __hip_atomic_store(&a.meta[4], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -1235,8 +1401,6 @@ constexpr int SCORE1_THREADS = 1024;
 constexpr int SCORE1_RESIDENT_THREADS = 256;
 constexpr int SCORE1_MAX_RANKS = 64;
 constexpr size_t SCORE1_MAX_LDS = 60 * 1024;
-
-typedef float nvrx_f4 __attribute__((ext_vector_type(4)));
 
 // 16-byte write-through store at system scope (sc0 sc1): not tracked by the compiler's waitcnt insertion,
 // the caller drains with s_waitcnt vmcnt(0) before publishing.
@@ -2008,25 +2172,44 @@ static int score_launch(const float *d_table, int R, int K, int S, int do_indiv,
     if (ga) return fail(NVRX_ERR_STATE, "the resident scorer needs the single-workgroup score kernel");
     if (pa) return fail(NVRX_ERR_STATE, "the exchange prologue needs the single-workgroup score kernel");
     size_t lds = (size_t)KS * sizeof(float);
+    int tile_ranks = 0;
     if (R > 64 || lds > 48 * 1024) {
-        // large jobs: column minima in their own pass over a coalesced grid
+        // large jobs: column minima in their own two-level pass over a coalesced grid
+        const int chunks = std::max(1, std::min(COLMIN_MAX_CHUNKS, (R + 63) / 64));
+        const int rows_per_chunk = (R + chunks - 1) / chunks;
+        const size_t need = (size_t)KS * (size_t)(chunks + 1);
         std::lock_guard<std::mutex> lk(g_scratch_mu);
-        if (g_scratch_elems < (size_t)KS) {
+        if (g_scratch_elems < need) {
             if (g_scratch) HIP_TRY(hipFree(g_scratch));
             g_scratch = nullptr;
             g_scratch_elems = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_scratch), std::max<size_t>((size_t)KS, 1024) * sizeof(float)));
-            g_scratch_elems = std::max<size_t>((size_t)KS, 1024);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_scratch), std::max<size_t>(need, 1024) * sizeof(float)));
+            g_scratch_elems = std::max<size_t>(need, 1024);
         }
         if (KS > 0) {
-            hipLaunchKernelGGL(k_colmin, dim3((KS + 255) / 256), dim3(256), 0, st, d_table, R, KS,
-                               NVRX_TABLE_LEN(K, S), g_scratch);
+            float *part = g_scratch + KS;
+            hipLaunchKernelGGL(k_colmin_part, dim3((KS + 63) / 64, chunks), dim3(256), 0, st, d_table, R, KS,
+                               NVRX_TABLE_LEN(K, S), rows_per_chunk, part);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_colmin_finish, dim3((KS + 255) / 256), dim3(256), 0, st, part, chunks, KS, g_scratch);
             HIP_TRY(hipGetLastError());
         }
         a.minmed_pre = g_scratch;
         lds = 0;
+        // a tile of 16 (or 8) ranks per workgroup when its staged results fit in LDS and the result arrays can be
+        // written in 16-byte units (every tile then starts on a 16-byte boundary of both arrays: the score row is an
+        // even number of floats / bytes)
+        const bool aligned = ((reinterpret_cast<uintptr_t>(d_scores) | reinterpret_cast<uintptr_t>(d_flags)) & 15u) == 0;
+        if (aligned && R > 64)
+            for (int t : {16, 8})
+                if (!tile_ranks && score_tile_lds_bytes(t, S) <= TILE_MAX_LDS) tile_ranks = t;
     }
-    hipLaunchKernelGGL(k_score, dim3(R), dim3(SCORE_THREADS), lds, st, a);
+    if (tile_ranks) {
+        hipLaunchKernelGGL(k_score_tile, dim3((R + tile_ranks - 1) / tile_ranks), dim3(TILE_THREADS),
+                           score_tile_lds_bytes(tile_ranks, S), st, a, tile_ranks);
+    } else {
+        hipLaunchKernelGGL(k_score, dim3(R), dim3(SCORE_THREADS), lds, st, a);
+    }
     HIP_TRY(hipGetLastError());
     return NVRX_OK;
 }
