@@ -27,6 +27,7 @@
 #include <deque>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "nvrx_straggler.h"
@@ -1856,10 +1857,15 @@ int peer_prologue_enabled() {
     return v;
 }
 
-// scratch for the two-kernel scoring path (large R or K+S)
+// scratch for the multi-kernel scoring path (large R or K+S): column minima and their per-chunk partials.  One buffer
+// per launch stream -- launches on one stream are ordered, so a buffer is reused safely there, while two contexts
+// scoring on their own streams at the same time must not share one.
+struct ScoreScratch {
+    float *ptr = nullptr;
+    size_t elems = 0;
+};
 std::mutex g_scratch_mu;
-float *g_scratch = nullptr;
-size_t g_scratch_elems = 0;
+std::unordered_map<void *, ScoreScratch> g_scratch_by_stream;
 
 }  // namespace
 
@@ -2178,23 +2184,27 @@ static int score_launch(const float *d_table, int R, int K, int S, int do_indiv,
         const int chunks = std::max(1, std::min(COLMIN_MAX_CHUNKS, (R + 63) / 64));
         const int rows_per_chunk = (R + chunks - 1) / chunks;
         const size_t need = (size_t)KS * (size_t)(chunks + 1);
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
-        if (g_scratch_elems < need) {
-            if (g_scratch) HIP_TRY(hipFree(g_scratch));
-            g_scratch = nullptr;
-            g_scratch_elems = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_scratch), std::max<size_t>(need, 1024) * sizeof(float)));
-            g_scratch_elems = std::max<size_t>(need, 1024);
+        float *scratch = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_scratch_mu);
+            ScoreScratch &sc = g_scratch_by_stream[stream];
+            if (sc.elems < need) {
+                if (sc.ptr) HIP_TRY(hipFree(sc.ptr));  // (waits for the device: nothing still reads the old buffer)
+                sc = ScoreScratch{};
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc.ptr), std::max<size_t>(need, 1024) * sizeof(float)));
+                sc.elems = std::max<size_t>(need, 1024);
+            }
+            scratch = sc.ptr;
         }
         if (KS > 0) {
-            float *part = g_scratch + KS;
+            float *part = scratch + KS;
             hipLaunchKernelGGL(k_colmin_part, dim3((KS + 63) / 64, chunks), dim3(256), 0, st, d_table, R, KS,
                                NVRX_TABLE_LEN(K, S), rows_per_chunk, part);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k_colmin_finish, dim3((KS + 255) / 256), dim3(256), 0, st, part, chunks, KS, g_scratch);
+            hipLaunchKernelGGL(k_colmin_finish, dim3((KS + 255) / 256), dim3(256), 0, st, part, chunks, KS, scratch);
             HIP_TRY(hipGetLastError());
         }
-        a.minmed_pre = g_scratch;
+        a.minmed_pre = scratch;
         lds = 0;
         // a tile of 16 (or 8) ranks per workgroup when its staged results fit in LDS and the result arrays can be
         // written in 16-byte units (every tile then starts on a 16-byte boundary of both arrays: the score row is an
