@@ -39,10 +39,30 @@ from .statistics import NUM_COLUMN, STAT_KEYS, Statistic
 _SummaryType = Mapping[Statistic, float]
 _LOG = logging.getLogger(__name__)
 
-try:  # csrc/nvrx_pyread.c: the same dicts without numpy's intermediate lists (host-side formatting only; same results)
-    from . import _nvrx_pyread as _pyread
-except ImportError:  # not built: the Python builders below
-    _pyread = None
+
+
+def _load_pyread():
+    """csrc/nvrx_pyread.c: the same dicts without numpy's intermediate lists (host-side formatting only; same results).
+    ``NVRX_LIB_DIR`` (the sanitizer builds, tools/run_sanitized.sh) may hold its own build of it, which then wins."""
+    alt = os.environ.get("NVRX_LIB_DIR", "")
+    if alt:
+        import glob
+        import importlib.util
+
+        for path in sorted(glob.glob(os.path.join(alt, "_nvrx_pyread*.so"))):
+            spec = importlib.util.spec_from_file_location(f"{__package__}._nvrx_pyread", path)
+            if spec is not None and spec.loader is not None:
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                return mod
+    try:
+        from . import _nvrx_pyread
+    except ImportError:  # not built: the Python builders below
+        return None
+    return _nvrx_pyread
+
+
+_pyread = _load_pyread()
 
 
 def _copy_sets(d: Dict[str, set]) -> Dict[str, set]:

@@ -1,4 +1,4 @@
-"""The native libraries' HOST code under AddressSanitizer + UndefinedBehaviorSanitizer (`make -C csrc asan`,
+"""The native libraries' HOST code (and the CPython dict builders, csrc/nvrx_pyread.c) under AddressSanitizer + UndefinedBehaviorSanitizer (`make -C csrc asan`,
 tools/run_sanitized.sh): the device-free paths -- loader, every exported symbol, argument checks and error strings,
 the tracer library's queue / key table behind the fake tracer.  On a GPU box `SAN=ubsan tools/run_sanitized.sh -m gpu`
 covers the paths that need a device (the ASan runtime cannot be preloaded next to HSA: tools/run_sanitized.sh)."""
