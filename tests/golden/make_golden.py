@@ -286,6 +286,75 @@ def make_scoring():
     print("scoring.json:", len(out), "scenarios")
 
 
+def _fuzz_worker(rank, world_size, store_file, scenarios, ret_queue):
+    """All scenarios of one world size in ONE set of processes (a fresh ReportGenerator each)."""
+    import torch
+
+    _install_reference()
+    from nvidia_resiliency_ext.attribution import straggler
+
+    torch.set_num_threads(1)
+    if world_size > 1:
+        torch.distributed.init_process_group("gloo", init_method=f"file://{store_file}", world_size=world_size, rank=rank)
+    S = straggler.Statistic
+    key = {"MIN": S.MIN, "MAX": S.MAX, "MED": S.MED, "AVG": S.AVG, "STD": S.STD, "NUM": S.NUM}
+
+    def conv(summ):
+        return {n: {key[k]: (float(v) if k != "NUM" else int(v)) for k, v in s.items()} for n, s in summ.items()}
+
+    results = []
+    for scenario in scenarios:
+        gen = straggler.reporting.ReportGenerator(
+            scenario["scores_to_compute"], gather_on_rank0=scenario["gather_on_rank0"], node_name=f"node{rank}"
+        )
+        reports = []
+        for step in scenario["steps"]:
+            sec, ker = step[rank]
+            rep = gen.generate_report(conv(sec), conv(ker))
+            d = _report_to_json(rep)
+            if rep is not None:
+                d["stragglers"] = _stragglers_to_json(rep, scenario.get("thresholds", [0.75]))
+            reports.append(d)
+        ids = {"sections": dict(gen.name_mapper.section_name_to_id), "kernels": dict(gen.name_mapper.kernel_name_to_id)}
+        results.append({"reports": reports, "ids": ids})
+    ret_queue.put((rank, results))
+    if world_size > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def make_fuzz():
+    """Random scenarios (synth.fuzz_scenarios) through the real ReportGenerator -> scoring_fuzz.json."""
+    import torch.multiprocessing as mp
+
+    scenarios = synth.fuzz_scenarios()
+    per_rank = {}
+    for W in sorted({sc["world_size"] for sc in scenarios}):
+        batch = [sc for sc in scenarios if sc["world_size"] == W]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        with tempfile.NamedTemporaryFile(delete=True) as tmpf:
+            store = tmpf.name
+        procs = [ctx.Process(target=_fuzz_worker, args=(r, W, store, batch, q)) for r in range(W)]
+        for p in procs:
+            p.start()
+        got = {}
+        for _ in range(W):
+            r, res = q.get(timeout=600)
+            got[r] = res
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0, p.exitcode
+        for i, sc in enumerate(batch):
+            per_rank[sc["name"]] = [got[r][i] for r in range(W)]
+        print("  world", W, ":", len(batch), "scenarios ok")
+    out = [{"scenario": sc, "per_rank": per_rank[sc["name"]]} for sc in scenarios]
+    with open(os.path.join(HERE, "scoring_fuzz.json"), "w") as f:
+        json.dump({"generator": "reference ReportGenerator.generate_report on gloo ranks (reporting.py:421-554), random "
+                                "scenarios of synth.fuzz_scenarios()", "scenarios": _jsonable(out)}, f)
+    print("scoring_fuzz.json:", len(out), "scenarios")
+
+
 # ------------------------------------------------------------------------------------------------
 # 4. full Detector.generate_report on 8 gloo ranks x 64 sections x 10k samples (configs #3 / #5)
 # ------------------------------------------------------------------------------------------------
@@ -473,7 +542,7 @@ def make_callback():
 
 if __name__ == "__main__":
     assert os.path.isdir(REF_SRC), "reference tree not found; golden vectors can only be regenerated in the build container"
-    which = sys.argv[1:] or ["section", "native", "scoring", "stress", "loop", "callback"]
+    which = sys.argv[1:] or ["section", "native", "scoring", "stress", "loop", "callback", "fuzz"]
     if "native" in which:
         make_native()
     if "section" in which:
@@ -486,3 +555,5 @@ if __name__ == "__main__":
         make_loop()
     if "callback" in which:
         make_callback()
+    if "fuzz" in which:
+        make_fuzz()

@@ -14,6 +14,9 @@ from util import compare_reports, load_golden
 
 pytestmark = pytest.mark.gpu
 
+# the peer-window route, with waits short enough for a test
+_PEER_ENV = {"NVRX_EXCHANGE": "peer", "NVRX_REPORT_TIMEOUT_S": "20", "NVRX_PEER_TRIAL_TIMEOUT_S": "5"}
+
 _SCENARIOS = load_golden("scoring.json")["scenarios"]
 # one scenario of every world size / option class (the full list runs on the CPU backend in test_host_logic.py)
 _PICK = ["rel_gpu_4ranks_gather1", "rel_gpu_4ranks_gather0", "sections_2ranks_gather1", "sections_2ranks_gather0",
@@ -29,6 +32,25 @@ def test_report_generator_on_hip_backend_matches_reference(name):
         for t in range(len(sc["steps"])):
             compare_reports(res[r]["reports"][t], g["per_rank"][r]["reports"][t], (name, r, t))
         assert res[r]["ids"] == g["per_rank"][r]["ids"], (name, r)
+
+
+_FUZZ = load_golden("scoring_fuzz.json")["scenarios"]
+
+
+@pytest.mark.parametrize("world,route", [(1, "gloo"), (2, "gloo"), (3, "gloo"), (4, "gloo"), (5, "gloo"), (2, "peer"), (4, "peer")])
+def test_random_scenarios_on_hip_backend_match_reference(world, route):
+    """The random scenarios of scoring_fuzz.json (outputs of the real reference) through the HIP backend: every scenario
+    of one world size in one set of processes sharing the GPU; over the gloo host hop, and over the peer windows."""
+    batch = [g for g in _FUZZ if g["scenario"]["world_size"] == world]
+    env = _PEER_ENV if route == "peer" else None
+    res = run_ranks(workers.scoring_scenarios_batch, world, timeout=300, use_oracle_backend=False, device=0, env=env,
+                    scenarios=[g["scenario"] for g in batch])
+    for i, g in enumerate(batch):
+        sc = g["scenario"]
+        for r in range(world):
+            for t in range(len(sc["steps"])):
+                compare_reports(res[r][i]["reports"][t], g["per_rank"][r]["reports"][t], (sc["name"], route, r, t))
+            assert res[r][i]["ids"] == g["per_rank"][r]["ids"], (sc["name"], r)
 
 
 @pytest.mark.parametrize("route", ["gloo", "peer+resident"])
@@ -89,7 +111,6 @@ def test_config2_loop_ten_reports_on_hip_backend():
 # --------------------------------------------------------------------------------------------------
 # the peer-window exchange (direct stores into IPC-mapped windows): same GPU, several processes
 # --------------------------------------------------------------------------------------------------
-_PEER_ENV = {"NVRX_EXCHANGE": "peer", "NVRX_REPORT_TIMEOUT_S": "20", "NVRX_PEER_TRIAL_TIMEOUT_S": "5"}
 
 
 def test_peer_window_single_rank_abi():

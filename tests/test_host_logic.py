@@ -508,6 +508,24 @@ def test_report_generator_matches_reference_on_gloo_ranks(idx):
         assert res[r]["ids"] == g["per_rank"][r]["ids"], (sc["name"], r)
 
 
+_FUZZ = load_golden("scoring_fuzz.json")["scenarios"]
+
+
+@pytest.mark.parametrize("world", sorted({g["scenario"]["world_size"] for g in _FUZZ}))
+def test_report_generator_matches_reference_on_random_scenarios(world):
+    """The 48 random scenarios of tests/golden/scoring_fuzz.json (real reference outputs; names missing on some ranks or
+    appearing mid-run, ranks without kernels, NCCL kernels to ignore, every combination of score families and
+    gather_on_rank0), all scenarios of one world size in one set of gloo processes."""
+    batch = [g for g in _FUZZ if g["scenario"]["world_size"] == world]
+    res = run_ranks(workers.scoring_scenarios_batch, world, timeout=300, scenarios=[g["scenario"] for g in batch])
+    for i, g in enumerate(batch):
+        sc = g["scenario"]
+        for r in range(world):
+            for t in range(len(sc["steps"])):
+                compare_reports(res[r][i]["reports"][t], g["per_rank"][r]["reports"][t], (sc["name"], r, t))
+            assert res[r][i]["ids"] == g["per_rank"][r]["ids"], (sc["name"], r)
+
+
 def test_world_and_rank_is_remembered_per_default_process_group():
     """The per-report (world, rank) lookup is cached per default process group OBJECT: tearing the group down and
     bringing a new one up (elastic restarts do) must not leave a stale answer behind."""

@@ -77,10 +77,21 @@ def _summ(d):
     return {n: {k: v for k, v in s.items()} for n, s in d.items()}
 
 
-@pytest.mark.parametrize("idx", range(11))
+def _scenario(idx):
+    """Golden scenario by index: the hand-written ones (scoring.json) first, then the random ones (scoring_fuzz.json)."""
+    fixed = load_golden("scoring.json")["scenarios"]
+    return fixed[idx] if idx < len(fixed) else load_golden("scoring_fuzz.json")["scenarios"][idx - len(fixed)]
+
+
+N_FIXED, N_FUZZ = 11, 48
+
+
+@pytest.mark.parametrize("idx", range(N_FIXED + N_FUZZ))
 def test_ref_port_scoring_matches_reference_report_generator(idx):
-    """RefPortReportGenerator (dict-level port) == reference ReportGenerator on gloo ranks."""
-    g = load_golden("scoring.json")["scenarios"][idx]
+    """RefPortReportGenerator (dict-level port) == reference ReportGenerator on gloo ranks: the eleven hand-written
+    scenarios and 48 random ones (names missing on some ranks / appearing mid-run, ranks without kernels, 1-5 ranks,
+    1-4 reports, every combination of score families and gather_on_rank0)."""
+    g = _scenario(idx)
     sc = g["scenario"]
     W = sc["world_size"]
     port = oracle.RefPortReportGenerator(W, sc["scores_to_compute"], sc["gather_on_rank0"])
@@ -143,11 +154,11 @@ def _table_from_step(step, W, kid, sid, hist):
     return T
 
 
-@pytest.mark.parametrize("idx", [i for i in range(11)])
+@pytest.mark.parametrize("idx", range(N_FIXED + N_FUZZ))
 def test_table_scoring_matches_reference(idx):
     """oracle_score_table (array form, what the HIP score kernel is checked against) reproduces the
     reference's gathered scores within f32 rounding (contract: 1e-4; observed <= 1e-6)."""
-    g = load_golden("scoring.json")["scenarios"][idx]
+    g = _scenario(idx)
     sc = g["scenario"]
     if not sc["gather_on_rank0"]:
         pytest.skip("gathered form only")

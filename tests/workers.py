@@ -50,6 +50,26 @@ def scoring_scenario(rank, world, scenario):
     return {"reports": reports, "ids": ids}
 
 
+def scoring_scenarios_batch(rank, world, scenarios):
+    """Several scenarios of one world size through OUR ReportGenerator in one set of processes (a fresh generator per
+    scenario; its exchange route is closed before the next one builds its own)."""
+    out = []
+    for scenario in scenarios:
+        from nvrx_straggler.reporting import ReportGenerator
+
+        gen = ReportGenerator(scenario["scores_to_compute"], gather_on_rank0=scenario["gather_on_rank0"], node_name=f"node{rank}")
+        try:
+            reports = []
+            for step in scenario["steps"]:
+                sec, ker = step[rank]
+                reports.append(report_to_plain(gen.generate_report(_summ(sec), _summ(ker)), scenario.get("thresholds", [0.75])))
+            ids = {"sections": dict(gen.name_mapper.section_name_to_id), "kernels": dict(gen.name_mapper.kernel_name_to_id)}
+            out.append({"reports": reports, "ids": ids})
+        finally:
+            gen.close()
+    return out
+
+
 def gather_object_call_counts(rank, world, n_kernels):
     """all_gather_object is used only when some rank meets a new name
     (reference: tests/straggler/unit/test_data_shared.py:69-100 -> 2, 0, 1, 0, 1)."""
