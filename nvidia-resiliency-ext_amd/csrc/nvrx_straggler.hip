@@ -723,6 +723,10 @@ __global__ __launch_bounds__(THREADS) void k_row_stats(const float *__restrict__
                 lo0 = kmn;
                 const int top = 32 - __clz((int)(kmx - kmn));
                 sh = (uint32_t)(top > HIST_BITS ? top - HIST_BITS : 0);
+                // every wave must be done with the first locate (it reads s_hist after its barrier) before any wave
+                // clears the histogram: a wave that read cleared bins picked another bin, did not rebuild, and the row's
+                // median came out wrong (seen with 16 waves on rows whose first tile is the row's maximum)
+                __syncthreads();
 #pragma unroll
                 for (int j = 0; j < PER; j++) s_hist[tid * PER + j] = 0u;
                 __syncthreads();

@@ -127,6 +127,53 @@ def test_random_rows_every_launch_shape(be, stride):
     _check_against_oracle(got, m, counts, kinds, f"stride{stride}")
 
 
+@pytest.mark.parametrize("stride", [1000, 4096, 4100, 10000, 20000, 33000, 40000, 50000, 65536])
+def test_rows_that_defeat_the_range_estimate(be, stride):
+    """The kernel bins every key over a range estimated from the row's FIRST tile (THREADS x 4 samples) and clamps what
+    falls outside into the two edge bins.  Rows built to make that estimate as wrong as possible -- the first tile a
+    constant, a narrow cluster or the low / high end of a sorted row; the rest far away on one or both sides; two
+    clusters with the median in the gap; 60 orders of magnitude; denormals and signed zeros; one value different from
+    all others -- for both kinds (lower median / mean of the two middles) and odd, even and ragged counts.  Selections
+    bit-exact against the oracle."""
+    rng = np.random.default_rng(stride)
+    n = stride
+    first = min(4096, n // 2)
+    rows = []
+
+    def add(x):
+        rows.append(np.asarray(x, dtype=np.float32))
+
+    x = rng.uniform(100.0, 200.0, n); x[:first] = 1.0; add(x)                      # first tile constant, rest far above
+    x = rng.uniform(100.0, 200.0, n); x[:first] = 1e6; add(x)                      # ... far below the first tile
+    x = rng.uniform(1.0, 1.001, n); x[first:] = rng.uniform(-1e5, 1e5, n - first); add(x)   # narrow first tile, both sides
+    x = np.full(n, 7.25); x[:first] = rng.uniform(0.0, 1e4, first); add(x)         # wide first tile, the rest one value
+    add(np.sort(rng.lognormal(0.0, 3.0, n)))                                        # ascending: first tile = the low end
+    add(np.sort(rng.lognormal(0.0, 3.0, n))[::-1].copy())                           # descending
+    x = np.concatenate([rng.normal(1.0, 0.01, n // 2), rng.normal(1e4, 1.0, n - n // 2)]); add(x)     # median in the gap
+    x = np.concatenate([rng.normal(1e4, 1.0, n // 2), rng.normal(1.0, 0.01, n - n // 2)]); add(x)     # ... clusters swapped
+    add(10.0 ** rng.uniform(-30.0, 30.0, n))                                        # 60 orders of magnitude
+    x = rng.choice(np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39, 1e-38], dtype=np.float32), n); add(x)   # denormals, signed zeros
+    x = np.full(n, 3.0); x[n // 3] = 2.0; add(x)                                    # one value below all others
+    x = np.full(n, 3.0); x[-1] = 4.0; add(x)                                        # ... above, in the last slot
+    x = rng.normal(10.0, 0.3, n); x[first:] += np.linspace(0.0, 50.0, n - first); add(x)             # a drifting row
+    x = rng.integers(0, 3, n).astype(np.float32); add(x)                            # three distinct values
+    m = np.stack(rows)
+    R = m.shape[0]
+    for kinds, counts in (
+        (np.zeros(R, np.uint8), np.full(R, n, np.uint32)),
+        (np.ones(R, np.uint8), np.full(R, n, np.uint32)),
+        (np.ones(R, np.uint8), np.full(R, n - 1, np.uint32)),
+        ((np.arange(R) % 2).astype(np.uint8), rng.integers(first + 1, n + 1, R).astype(np.uint32)),
+    ):
+        got = _run(be, m, counts, kinds)
+        exp = oracle.rows_stats(m, counts, kinds)
+        for r in range(R):
+            for c, name in ((0, "MIN"), (1, "MAX"), (2, "MED")):
+                assert got[r, c] == np.float32(exp[r, c]) or (got[r, c] == 0.0 and exp[r, c] == 0.0), \
+                    (stride, r, name, int(kinds[r]), int(counts[r]), got[r, c], exp[r, c])
+            assert got[r, 5] == counts[r]
+
+
 def test_stress_shape_512_rows_x_10000(be):
     """The folded N=1 workload (8 ranks x 64 sections x 10 000 samples): exact medians for all rows."""
     m = np.concatenate([synth.stress_samples(r, 64, 10_000) for r in range(8)], axis=0)

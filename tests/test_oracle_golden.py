@@ -236,3 +236,54 @@ def test_port_job_on_gloo_ranks_runs_and_reports_times():
     for k in ("summaries_us", "exchange_scoring_us", "all_gather_object_us", "report_us"):
         assert r[k] > 0.0
     assert r["report_us"] >= 0.5 * (r["summaries_us"] + r["exchange_scoring_us"])
+
+
+# --------------------------------------------------------------------------------------------------
+# property tests: the oracle against the arithmetic it restates, on inputs nobody chose
+# --------------------------------------------------------------------------------------------------
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as st  # noqa: E402
+from hypothesis.extra import numpy as hnp  # noqa: E402
+
+_F32 = st.floats(min_value=-float(np.float32(1e30)), max_value=float(np.float32(1e30)), allow_nan=False, allow_infinity=False, width=32)
+_PROP = settings(max_examples=300, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+
+
+@_PROP
+@given(hnp.arrays(np.float32, st.integers(0, 300), elements=_F32))
+def test_kernel_stats_equal_the_live_reference_on_random_rows(x):
+    """oracle_kernel_stats vs the reference's own computeStats (CuptiProfiler.cpp:44-74, compiled into oracle/_ref from
+    where it lies): every output bit for bit -- sorted-order f32 sums, mean-of-middles median, population deviation,
+    the all-NaN / 0 result of an empty row -- on arbitrary finite f32 rows (duplicates, negatives, denormals, 1e30)."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this box)")
+    a, b = oracle.kernel_stats(x), oracle.ref_kernel_stats(x)
+    assert np.array_equal(a, b, equal_nan=True), (x.tolist(), a, b)
+
+
+@_PROP
+@given(st.integers(0, 200), st.integers(1, 64))
+def test_ring_equals_the_live_reference_for_any_length_and_capacity(n, capacity):
+    """Overwrite-oldest ring (CircularBuffer.h:53-69): what survives, and in which order."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this box)")
+    vals = (np.arange(n, dtype=np.float32) * 0.25 - 3.0)
+    assert np.array_equal(oracle.ring_run(vals, capacity), oracle.ref_ring_run(vals, capacity))
+    assert np.array_equal(oracle.ring_run(vals, capacity), vals[-capacity:] if n > capacity else vals)
+
+
+@_PROP
+@given(hnp.arrays(np.float64, st.integers(1, 200), elements=st.floats(min_value=-1e12, max_value=1e12, allow_nan=False, width=64)))
+def test_section_stats_equal_torch_on_random_rows(x):
+    """oracle_section_stats vs the five torch reductions of straggler.py:185-195 on an f64 tensor (the third-party
+    arithmetic the reference delegates to): selections exact (torch's LOWER median), mean / unbiased deviation to
+    1e-12, NaN deviation of a single sample."""
+    import torch
+
+    t = torch.tensor(x.tolist(), dtype=torch.float64)
+    got = oracle.section_stats(x)
+    assert got[0] == torch.min(t).item() and got[1] == torch.max(t).item() and got[2] == torch.median(t).item()
+    assert got[5] == len(x)
+    assert close(got[3], torch.mean(t).item(), rel=1e-12, abs_=1e-300)
+    std = torch.std(t).item()
+    assert close(got[4], std, rel=1e-9, abs_=1e-9 * max(1.0, float(np.abs(x).max()))) or (np.isnan(std) and np.isnan(got[4]))
