@@ -362,6 +362,21 @@ def _pmc_traffic(rows: int):
         return None
 
 
+def _pmc_traffic_of_an_older_source(rows: int):
+    """When ``traffic`` is null because the kernel's text changed after the last PMC pass: that pass' figure, labelled
+    with the sha it belongs to -- information, not this source's measurement."""
+    try:
+        with open(os.path.join(REPO, "profiles", "pmc_row_stats.json")) as f:
+            d = json.load(f)
+        if d.get("kernel_source_sha16") == _kernel_source_sha():
+            return None
+        b = d.get("rows", {}).get(str(rows), {}).get("hbm_bytes_per_launch")
+        return None if b is None else {"hbm_bytes_per_launch": b, "kernel_source_sha16": d.get("kernel_source_sha16"),
+                                       "source": d.get("source"), "this_source_sha16": _kernel_source_sha()}
+    except Exception:
+        return None
+
+
 def _kernel_leg(job, steps, samples, cold=False, sweep=None):
     """Average k_row_stats duration over `steps` reports of `job` (hipExtLaunchKernel start/stop events on the launch
     stream).  cold=True: a 1 GiB sweep between reports evicts L2 and the Infinity Cache, so the rows come from HBM."""
@@ -781,6 +796,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": _pmc_traffic(job.local_ranks * SECTIONS),
+                "traffic_of_an_older_source": _pmc_traffic_of_an_older_source(job.local_ranks * SECTIONS),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_us_avg": round(kern_us, 3),
                 "launches_timed": kern_launches,
