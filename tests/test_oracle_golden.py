@@ -272,6 +272,7 @@ def test_ring_equals_the_live_reference_for_any_length_and_capacity(n, capacity)
     assert np.array_equal(oracle.ring_run(vals, capacity), vals[-capacity:] if n > capacity else vals)
 
 
+@pytest.mark.filterwarnings("ignore:std\\(\\)")
 @_PROP
 @given(hnp.arrays(np.float64, st.integers(1, 200), elements=st.floats(min_value=-1e12, max_value=1e12, allow_nan=False, width=64)))
 def test_section_stats_equal_torch_on_random_rows(x):
