@@ -12,6 +12,10 @@
  *   sections(names, ranks, scores, n_rows, width, first_col, cols) -> {name: {rank: float}}
  *   summaries(names, stat_keys, stats, rows) -> {name: {stat_key: float, ..., stat_keys[5]: int}}
  *   copy_sets(d) -> {key: set(value) for key, value in d.items()}      (fresh sets for every caller of identify_stragglers)
+ *   flagged(buf, offset, rows, width, S, has_rel, has_indiv, ids, names, cols, memo) -> (gpu_rel, gpu_indiv, sec_rel, sec_indiv)
+ *       the sets identify_stragglers returns, straight from the score kernel's flag bytes ([rows][2+2S] u8 at buf+offset):
+ *       no numpy call, no Python frame per column -- what a report read once a minute pays for is cold code and cold
+ *       objects, so the fewer of both the better (Report.identify_stragglers: 75 -> ... us cold on the build host).
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
@@ -116,17 +120,24 @@ done:
     return out;
 }
 
+static PyObject *copy_set_dict(PyObject *d);
+
 static PyObject *pyread_copy_sets(PyObject *self, PyObject *arg) {
     if (!PyDict_Check(arg)) {
         PyErr_SetString(PyExc_TypeError, "nvrx_pyread.copy_sets: a dict of sets expected");
         return NULL;
     }
+    return copy_set_dict(arg);  /* a set built from a set keeps the stored hashes: nothing is re-hashed */
+}
+
+/* one level deep copy of {name: set}; NULL on error */
+static PyObject *copy_set_dict(PyObject *d) {
     PyObject *out = PyDict_New();
     if (!out) return NULL;
     PyObject *key, *value;
     Py_ssize_t pos = 0;
-    while (PyDict_Next(arg, &pos, &key, &value)) {
-        PyObject *c = PySet_New(value);  /* a set built from a set keeps the stored hashes: nothing is re-hashed */
+    while (PyDict_Next(d, &pos, &key, &value)) {
+        PyObject *c = PySet_New(value);
         if (!c || PyDict_SetItem(out, key, c) < 0) {
             Py_XDECREF(c);
             Py_DECREF(out);
@@ -137,7 +148,124 @@ static PyObject *pyread_copy_sets(PyObject *self, PyObject *arg) {
     return out;
 }
 
+/* the flagged rows of one column as a set of ids[r]; *out stays NULL when the column holds no flag */
+static int column_members(const unsigned char *f, int rows, int width, int col, PyObject **ids, PyObject **out) {
+    for (int r = 0; r < rows; r++) {
+        if (!f[(Py_ssize_t)r * width + col]) continue;
+        if (!*out && !(*out = PySet_New(NULL))) return -1;
+        if (PySet_Add(*out, ids[r]) < 0) return -1;
+    }
+    return 0;
+}
+
+static PyObject *pyread_flagged(PyObject *self, PyObject *args) {
+    Py_buffer view;
+    Py_ssize_t offset;
+    int rows, width, S, has_rel, has_indiv;
+    PyObject *ids_obj, *names, *cols, *memo;
+    if (!PyArg_ParseTuple(args, "y*niiippOO!OO", &view, &offset, &rows, &width, &S, &has_rel, &has_indiv, &ids_obj, &PyTuple_Type,
+                          &names, &cols, &memo))
+        return NULL;
+    PyObject *ids_fast = NULL, *gr = NULL, *gi = NULL, *sr = NULL, *si = NULL, *result = NULL;
+    const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
+    const Py_ssize_t n = (Py_ssize_t)rows * width;
+    if (rows < 0 || S < 0 || width != 2 + 2 * S || offset < 0 || view.len < offset + n ||
+        (cols != Py_None && (!PyTuple_Check(cols) || PyTuple_GET_SIZE(cols) != n_names)) ||
+        (memo != Py_None && (!PyList_Check(memo) || PyList_GET_SIZE(memo) != 2))) {
+        PyErr_SetString(PyExc_ValueError, "nvrx_pyread.flagged: inconsistent shapes");
+        goto done;
+    }
+    ids_fast = PySequence_Fast(ids_obj, "nvrx_pyread.flagged: ids must be a sequence");
+    if (!ids_fast) goto done;
+    if (PySequence_Fast_GET_SIZE(ids_fast) != rows) {
+        PyErr_SetString(PyExc_ValueError, "nvrx_pyread.flagged: one id per row expected");
+        goto done;
+    }
+    PyObject **ids = PySequence_Fast_ITEMS(ids_fast);
+    const unsigned char *f = (const unsigned char *)view.buf + offset;
+
+    unsigned char any = 0;
+    for (Py_ssize_t i = 0; i < n; i++) any |= f[i];
+    if (any && memo != Py_None) {
+        /* a straggler usually stays one for many reports: the sets of an unchanged flag table are handed out as copies
+         * (a set built from a set keeps the stored hashes, StragglerId.__hash__ is a Python function) */
+        PyObject *key = PyList_GET_ITEM(memo, 0), *hit = PyList_GET_ITEM(memo, 1);
+        if (PyBytes_Check(key) && PyBytes_GET_SIZE(key) == n && PyTuple_Check(hit) && PyTuple_GET_SIZE(hit) == 5 &&
+            PyTuple_GET_ITEM(hit, 0) == ids_obj && memcmp(PyBytes_AS_STRING(key), f, (size_t)n) == 0) {
+            gr = PySet_New(PyTuple_GET_ITEM(hit, 1));
+            gi = PySet_New(PyTuple_GET_ITEM(hit, 2));
+            sr = copy_set_dict(PyTuple_GET_ITEM(hit, 3));
+            si = copy_set_dict(PyTuple_GET_ITEM(hit, 4));
+            if (gr && gi && sr && si) result = PyTuple_Pack(4, gr, gi, sr, si);
+            goto done;
+        }
+    }
+    gr = PySet_New(NULL);
+    gi = PySet_New(NULL);
+    sr = PyDict_New();
+    si = PyDict_New();
+    if (!gr || !gi || !sr || !si) goto done;
+    if (any) {
+        PyObject *tmp = NULL;
+        if (has_indiv) {
+            if (column_members(f, rows, width, 0, ids, &tmp) < 0) { Py_XDECREF(tmp); goto done; }
+            if (tmp) { Py_SETREF(gi, tmp); tmp = NULL; }
+        }
+        if (has_rel) {
+            if (column_members(f, rows, width, 1, ids, &tmp) < 0) { Py_XDECREF(tmp); goto done; }
+            if (tmp) { Py_SETREF(gr, tmp); tmp = NULL; }
+        }
+        for (int family = 0; family < 2; family++) {  /* 0: individual (columns 2..), 1: relative (columns 2+S..) */
+            if (!(family ? has_rel : has_indiv)) continue;
+            PyObject *dst = family ? sr : si;
+            for (Py_ssize_t i = 0; i < n_names; i++) {  /* the report's own section order */
+                long c = i;
+                if (cols != Py_None) {
+                    c = PyLong_AsLong(PyTuple_GET_ITEM(cols, i));
+                    if (c == -1 && PyErr_Occurred()) goto done;
+                }
+                if (c < 0 || c >= S) {
+                    PyErr_SetString(PyExc_ValueError, "nvrx_pyread.flagged: column out of range");
+                    goto done;
+                }
+                tmp = NULL;
+                if (column_members(f, rows, width, 2 + (family ? S : 0) + (int)c, ids, &tmp) < 0 ||
+                    (tmp && PyDict_SetItem(dst, PyTuple_GET_ITEM(names, i), tmp) < 0)) {
+                    Py_XDECREF(tmp);
+                    goto done;
+                }
+                Py_XDECREF(tmp);
+            }
+        }
+        if (memo != Py_None) {
+            PyObject *key = PyBytes_FromStringAndSize((const char *)f, n);
+            PyObject *c_gr = PySet_New(gr), *c_gi = PySet_New(gi), *c_sr = copy_set_dict(sr), *c_si = copy_set_dict(si);
+            PyObject *hit = (key && c_gr && c_gi && c_sr && c_si) ? PyTuple_Pack(5, ids_obj, c_gr, c_gi, c_sr, c_si) : NULL;
+            Py_XDECREF(c_gr);
+            Py_XDECREF(c_gi);
+            Py_XDECREF(c_sr);
+            Py_XDECREF(c_si);
+            if (!hit || PyList_SetItem(memo, 0, key) < 0) {  /* (SetItem steals key, also on failure) */
+                if (!hit) Py_XDECREF(key);
+                Py_XDECREF(hit);
+                goto done;
+            }
+            if (PyList_SetItem(memo, 1, hit) < 0) goto done;
+        }
+    }
+    result = PyTuple_Pack(4, gr, gi, sr, si);
+done:
+    Py_XDECREF(gr);
+    Py_XDECREF(gi);
+    Py_XDECREF(sr);
+    Py_XDECREF(si);
+    Py_XDECREF(ids_fast);
+    PyBuffer_Release(&view);
+    return result;
+}
+
 static PyMethodDef pyread_methods[] = {
+    {"flagged", pyread_flagged, METH_VARARGS, "the sets of identify_stragglers from the score kernel's flag bytes"},
     {"sections", pyread_sections, METH_VARARGS, "section -> {rank -> score} from an f32 score block"},
     {"summaries", pyread_summaries, METH_VARARGS, "name -> {Statistic -> value} from f32 statistics rows"},
     {"copy_sets", pyread_copy_sets, METH_O, "a dict of sets, copied one level deep"},

@@ -199,7 +199,7 @@ class _View:
     exist, where this report's rows sit in the result block, the thresholds the score kernel flagged with."""
 
     __slots__ = ("S", "ranks", "names", "cols", "has_rel", "has_indiv", "section_rows", "kernel_rows", "layout", "thresholds",
-                 "_rank_list", "_col_index", "_selectors", "_ids", "_memo", "_tuples")
+                 "_rank_list", "_col_index", "_selectors", "_ids", "_memo", "_tuples", "_flag_args")
 
     def memo(self) -> dict:
         try:
@@ -207,6 +207,16 @@ class _View:
         except AttributeError:
             self._memo = {}
             return self._memo
+
+    def flag_memo(self) -> list:
+        """[flag bytes, (ids, gpu_rel, gpu_indiv, sec_rel, sec_indiv)] of the last flag table ``_nvrx_pyread.flagged``
+        decoded for this plan (it hands an unchanged table's sets out as copies)."""
+        m = self.memo()
+        try:
+            return m["c"]
+        except KeyError:
+            m["c"] = [None, None]
+            return m["c"]
 
     def rank_list(self) -> list:
         try:
@@ -310,6 +320,41 @@ class _ScoreSource:
             _, off_f, _, _, W, lo, hi, _ = self.view.layout
             return self.pending.head_bytes()[off_f + lo * W : off_f + hi * W]
         return self.ensure().flags.tobytes()
+
+    def flagged(self, rank_to_node, thresholds):
+        """``identify_stragglers`` at the thresholds the score kernel flagged with, decoded by ``_nvrx_pyread.flagged``
+        straight from the flag bytes (None: other thresholds, or the helper was not built -- the caller's general path).
+        One Python frame and one C call: a report read once a minute runs all of this cold."""
+        v = self.view
+        if _pyread is None or thresholds != v.thresholds:
+            return None
+        try:
+            owner, off, args = v._flag_args
+        except AttributeError:
+            owner = None
+        if owner is not rank_to_node:  # once per plan: the generator hands the same rank_to_node to all its reports
+            _, off_f, _, _, W, lo, hi, _ = v.layout
+            off = off_f + lo * W
+            args = (hi - lo, W, v.S, v.has_rel, v.has_indiv, v.straggler_ids(rank_to_node), v.names_tuple(), v.col_tuple(),
+                    v.flag_memo())
+            v._flag_args = (rank_to_node, off, args)
+        pend = self.pending
+        out = None
+        if self.scores is None and type(pend) is _LiveBlock:
+            with _LIVE_LOCK:
+                # the result block itself, nothing copied: under the lock the generator cannot collect this report
+                # (``detach`` takes it too), and until it has, nothing is enqueued that writes the block again
+                blk = pend.blk
+                live = getattr(blk, "_host", None) if pend._head_bytes is None else None
+                if live is not None:
+                    out = _pyread.flagged(live, off, *args)
+            if out is None:
+                out = _pyread.flagged(pend.head_bytes(), off, *args)
+        else:
+            buf = self.ensure().flags
+            out = _pyread.flagged(buf if buf.flags.c_contiguous else np.ascontiguousarray(buf), 0, *args)
+        return {"straggler_gpus_relative": out[0], "straggler_gpus_individual": out[1],
+                "straggler_sections_relative": out[2], "straggler_sections_individual": out[3]}
 
     def device_flags(self) -> "_DeviceFlags":
         v = self.view
@@ -459,6 +504,12 @@ class Report:
         'straggler_sections_relative': {section: set}, 'straggler_sections_individual': {section:
         set}}``; a section appears only if at least one rank is flagged for it.
         """
+        src = self.__dict__.get("_src")
+        if src is not None and src.view.layout is not None:
+            fast = src.flagged(self.rank_to_node, (gpu_rel_threshold, section_rel_threshold, gpu_indiv_threshold,
+                                                   section_indiv_threshold))
+            if fast is not None:
+                return fast
         flags = self._flags()
         if flags is not None and flags.matches(
             gpu_rel_threshold, section_rel_threshold, gpu_indiv_threshold, section_indiv_threshold

@@ -900,3 +900,59 @@ def test_c_dict_builders_equal_the_python_builders(monkeypatch):
             copy = reporting._copy_sets(flagged)
         assert copy == flagged and list(copy) == list(flagged) and all(type(v) is set for v in copy.values())
         assert all(copy[k] is not flagged[k] for k in flagged)
+
+
+@pytest.mark.parametrize("order", ["identity", "permuted"])
+def test_c_flag_decoder_equals_the_python_decoder(order, monkeypatch):
+    """``_nvrx_pyread.flagged`` (identify_stragglers at the kernel's thresholds: flag bytes -> sets, no numpy) against
+    ``_DeviceFlags.decode``: random flag tables of every density (none, one, many per column, all), both score families
+    and each alone, a rank's own section order, rows [lo, hi) of a larger table; the memo hands out equal but fresh
+    sets, and what a caller does to its sets never shows up in the next answer."""
+    from nvrx_straggler import reporting
+
+    assert reporting._pyread is not None and hasattr(reporting._pyread, "flagged")
+    rng = np.random.default_rng(11)
+    R_all, S = 12, 23
+    W = 2 + 2 * S
+    names = [f"section_{i:02d}" for i in range(S)]
+    if order == "permuted":
+        names = [names[i] for i in rng.permutation(S)][: S - 3]   # a rank's own order, not every column used
+    cols = {n: int(n.split("_")[1]) for n in names}
+    off_f = 64 + R_all * W * 4
+    for has_rel, has_indiv in ((True, True), (True, False), (False, True)):
+        for lo, hi in ((0, R_all), (3, 9), (5, 6)):
+            v = reporting._View()
+            v.S, v.ranks, v.names, v.cols = S, range(lo, hi), names, cols
+            v.has_rel, v.has_indiv = has_rel, has_indiv
+            v.layout = (64, off_f, off_f + R_all * W, R_all, W, lo, hi, 0)
+            v.thresholds = (0.75, 0.75, 0.75, 0.75)
+            rank_to_node = {r: f"node{r // 4}" for r in range(R_all)}
+            for density in (0.0, 0.002, 0.05, 0.5, 1.0, 0.05):
+                table = (rng.random((R_all, W)) < density).astype(np.uint8)
+                blob = np.zeros(off_f + R_all * W, dtype=np.uint8)
+                blob[off_f:] = table.reshape(-1)
+                src = reporting._ScoreSource(v, blob.copy())
+                got = src.flagged(rank_to_node, (0.75, 0.75, 0.75, 0.75))
+                assert src.flagged(rank_to_node, (0.75, 0.75, 0.75, 0.7)) is None        # other thresholds: not ours
+                with monkeypatch.context() as m:
+                    m.setattr(reporting._ScoreSource, "flagged", lambda self, a, b: None)
+                    rep = reporting.Report._from_device(reporting._ScoreSource(v, blob.copy()), rank_to_node, 0.0, True, 0)
+                    want = rep.identify_stragglers()
+                assert got == want, (has_rel, has_indiv, lo, hi, density)
+                assert list(got["straggler_sections_relative"]) == list(want["straggler_sections_relative"])
+                assert list(got["straggler_sections_individual"]) == list(want["straggler_sections_individual"])
+                # the same table again: served from the memo, equal, and not the same objects
+                again = reporting._ScoreSource(v, blob.copy()).flagged(rank_to_node, (0.75, 0.75, 0.75, 0.75))
+                assert again == got
+                for k in got:
+                    assert again[k] is not got[k]
+                    if isinstance(got[k], dict):
+                        assert all(again[k][n] is not got[k][n] for n in got[k])
+                # a caller emptying its sets changes nobody else's answer
+                for k in again:
+                    again[k].clear()
+                assert reporting._ScoreSource(v, blob.copy()).flagged(rank_to_node, (0.75, 0.75, 0.75, 0.75)) == want
+    with pytest.raises(ValueError):
+        reporting._pyread.flagged(b"\x00" * 10, 0, 2, 6, 2, True, True, [1, 2], ("a", "b"), None, None)   # buffer too short
+    with pytest.raises(ValueError):
+        reporting._pyread.flagged(b"\x01" * 12, 0, 2, 6, 2, True, True, [1, 2], ("a", "b"), (0, 5), None)  # column out of range
