@@ -347,7 +347,10 @@ class _ScoreSource:
                 blk = pend.blk
                 live = getattr(blk, "_host", None) if pend._head_bytes is None else None
                 if live is not None:
-                    out = _pyread.flagged(live, off, *args)
+                    try:
+                        out = _pyread.flagged(live, off, *args)
+                    except (BufferError, TypeError):  # a block that does not export a flat byte buffer: its private copy
+                        out = None
             if out is None:
                 out = _pyread.flagged(pend.head_bytes(), off, *args)
         else:
