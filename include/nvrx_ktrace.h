@@ -46,6 +46,9 @@ typedef struct nvrx_ktrace_record {
  * records held between two drains (<= 0: 1 << 20); beyond it records are dropped and counted, the way the
  * reference drops records when its buffer pool is exhausted (BufferPool.cpp:46-48). */
 int nvrx_ktrace_setup(int max_pending);
+/* Libraries whose names the last nvrx_ktrace_setup kept out of rocprofiler-sdk's tool search (the SDK reads every
+ * library of the link map front to back while it looks for tools; see nvrx_ktrace.cpp "tool discovery guard"). */
+int nvrx_ktrace_hidden_libraries(void);
 /* 1 once the SDK has called the tool's initialiser and its context is valid (after the first HIP call). */
 int nvrx_ktrace_ready(void);
 /* Enable / disable kernel-dispatch tracing (cuptiActivityEnable / Disable, CuptiProfiler.cpp:116-133). */

@@ -20,6 +20,10 @@
 #include <rocprofiler-sdk/rocprofiler.h>
 
 
+#include <dlfcn.h>
+#include <link.h>
+#include <sys/stat.h>
+
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -81,6 +85,47 @@ State &st() {
     static State *s = new State();  // leaked on purpose: SDK threads may outlive static destruction
     return *s;
 }
+
+// ---- tool discovery guard ---------------------------------------------------------------------------------------
+// When rocprofiler-sdk initialises (rocprofiler_force_configure, or the HIP runtime handing over its API table) it looks
+// for tools by ELF-parsing EVERY shared library of the process' link map, and its parser reads each file front to back
+// (std::ifstream::read of the whole file; backtrace in tools/debug/readtrace.c / profiles/r04c_ktrace_start_up.txt):
+// 10.7 GB of read() calls in a PyTorch process (libmagma 1.3 GB, MIOpen 0.95, rocsolver 0.76, libtorch_hip 0.42 ...).
+// From a warm page cache that is 3 s; where storage is cold it is minutes -- the "start-up stall" of rounds 1-3.  The
+// tool we want the SDK to find is handed over explicitly (rocprofiler_force_configure), so for the duration of that one
+// call the large libraries are taken out of the search: their link-map names are pointed at "" (what the main program
+// has, which the search skips) and put back right after.  Nothing is unloaded or remapped; only the name the SDK's
+// search would open is hidden.  NVRX_KTRACE_SCAN_GUARD=0 turns it off, NVRX_KTRACE_SCAN_GUARD_MIN_MB (default 4) is the size from
+// which a library is hidden.  A tool library (one exporting rocprofiler_configure) larger than that would not be
+// discovered by the search while hidden; tools named in ROCP_TOOL_LIBRARIES are loaded by name and unaffected.
+struct HiddenName {
+    link_map *lm;
+    char *name;
+};
+
+std::vector<HiddenName> hide_large_libraries(size_t min_bytes) {
+    std::vector<HiddenName> out;
+    void *self = dlopen(nullptr, RTLD_LAZY | RTLD_NOLOAD);
+    link_map *lm = nullptr;
+    if (!self || dlinfo(self, RTLD_DI_LINKMAP, &lm) != 0 || !lm) return out;
+    while (lm->l_prev) lm = lm->l_prev;
+    static char empty[1] = {0};
+    for (; lm; lm = lm->l_next) {
+        if (!lm->l_name || !lm->l_name[0]) continue;
+        if (strstr(lm->l_name, "rocprofiler") || strstr(lm->l_name, "nvrx_ktrace")) continue;
+        struct stat sb;
+        if (stat(lm->l_name, &sb) != 0 || (size_t)sb.st_size < min_bytes) continue;
+        out.push_back(HiddenName{lm, lm->l_name});
+        lm->l_name = empty;
+    }
+    return out;
+}
+
+void restore_library_names(const std::vector<HiddenName> &hidden) {
+    for (const HiddenName &h : hidden) h.lm->l_name = h.name;
+}
+
+std::atomic<int> g_hidden_last{0};
 
 void on_code_object(rocprofiler_callback_tracing_record_t record, rocprofiler_user_data_t *, void *) {
     if (record.kind != ROCPROFILER_CALLBACK_TRACING_CODE_OBJECT ||
@@ -213,13 +258,24 @@ int nvrx_ktrace_setup(int max_pending) {
                     "nvrx_straggler with NVRX_GPU_TIMING=kernels before the first HIP call, or name libnvrx_ktrace.so in "
                     "ROCP_TOOL_LIBRARIES");
     KT_DBG("setup: calling rocprofiler_force_configure");
+    std::vector<HiddenName> hidden;
+    const char *guard = getenv("NVRX_KTRACE_SCAN_GUARD");
+    if (!guard || strcmp(guard, "0") != 0) {
+        const char *mb = getenv("NVRX_KTRACE_SCAN_GUARD_MIN_MB");
+        const long min_mb = mb && atol(mb) > 0 ? atol(mb) : 4;
+        hidden = hide_large_libraries((size_t)min_mb << 20);
+    }
+    g_hidden_last.store((int)hidden.size());
     rocprofiler_status_t rs = rocprofiler_force_configure(&rocprofiler_configure);
+    restore_library_names(hidden);
     KT_DBG("setup: rocprofiler_force_configure returned");
     if (rs != ROCPROFILER_STATUS_SUCCESS)
         return fail(rs == ROCPROFILER_STATUS_ERROR_CONFIGURATION_LOCKED ? NVRX_KTRACE_ERR_STATE : NVRX_KTRACE_ERR_SDK,
                     "rocprofiler_force_configure failed: %s", rocprofiler_get_status_string(rs));
     return NVRX_KTRACE_OK;
 }
+
+int nvrx_ktrace_hidden_libraries(void) { return g_hidden_last.load(); }
 
 int nvrx_ktrace_ready(void) { return st().ready.load(std::memory_order_acquire); }
 

@@ -9,7 +9,8 @@
  * the intermediates.  Pure host-side formatting: no arithmetic happens here, the package falls back to the Python
  * implementation if the module was not built (same results).
  *
- *   sections(names, ranks, scores, n_rows, width, first_col, cols) -> {name: {rank: float}}
+ *   sections(names, ranks, buf, offset, n_rows, width, first_col, cols[, second_col]) -> {name: {rank: float}} (or a pair of them)
+ *   ranks(ranks, buf, offset, n_rows, width, col) -> {rank: float}
  *   summaries(names, stat_keys, stats, rows) -> {name: {stat_key: float, ..., stat_keys[5]: int}}
  *   copy_sets(d) -> {key: set(value) for key, value in d.items()}      (fresh sets for every caller of identify_stragglers)
  *   flagged(buf, offset, rows, width, S, has_rel, has_indiv, ids, names, cols, memo) -> (gpu_rel, gpu_indiv, sec_rel, sec_indiv)
@@ -20,53 +21,155 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
-static PyObject *pyread_sections(PyObject *self, PyObject *args) {
-    PyObject *names, *ranks, *cols;
-    Py_buffer view;
-    int n_rows, width, first_col;
-    if (!PyArg_ParseTuple(args, "O!O!y*iiiO", &PyTuple_Type, &names, &PyTuple_Type, &ranks, &view, &n_rows, &width, &first_col, &cols))
+/* Dicts are created at their final size (a dict grown insert by insert reallocates its table at 6, 11, 22, 43 ...
+ * entries: every inner dict of 8 ranks once, the outer dict of 64 names three times) and keys are inserted with the
+ * hash they already carry.  Both are CPython-private but exported entry points (cpython/dictobject.h). */
+#if PY_VERSION_HEX >= 0x03080000 && !defined(PYPY_VERSION)
+#define NEW_DICT(n) _PyDict_NewPresized(n)
+#define SET_KNOWN(d, k, v, h) _PyDict_SetItem_KnownHash(d, k, v, h)
+#else
+#define NEW_DICT(n) PyDict_New()
+#define SET_KNOWN(d, k, v, h) PyDict_SetItem(d, k, v)
+#endif
+
+#define MAX_STACK_HASHES 256
+
+/* hashes of a tuple's items into out (heap-allocated beyond MAX_STACK_HASHES); NULL + exception on an unhashable key */
+static Py_hash_t *tuple_hashes(PyObject *t, Py_hash_t *stack) {
+    const Py_ssize_t n = PyTuple_GET_SIZE(t);
+    Py_hash_t *h = n <= MAX_STACK_HASHES ? stack : PyMem_Malloc((size_t)n * sizeof(Py_hash_t));
+    if (!h) {
+        PyErr_NoMemory();
         return NULL;
-    PyObject *out = NULL;
-    const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
-    if (n_rows < 0 || width <= 0 || first_col < 0 || PyTuple_GET_SIZE(ranks) != n_rows ||
-        view.len < (Py_ssize_t)n_rows * width * (Py_ssize_t)sizeof(float) ||
-        (cols != Py_None && (!PyTuple_Check(cols) || PyTuple_GET_SIZE(cols) != n_names))) {
-        PyErr_SetString(PyExc_ValueError, "nvrx_pyread.sections: inconsistent shapes");
-        goto done;
     }
-    out = PyDict_New();
-    if (!out) goto done;
-    const float *p = (const float *)view.buf;
+    for (Py_ssize_t i = 0; i < n; i++) {
+        h[i] = PyObject_Hash(PyTuple_GET_ITEM(t, i));
+        if (h[i] == -1 && PyErr_Occurred()) {
+            if (h != stack) PyMem_Free(h);
+            return NULL;
+        }
+    }
+    return h;
+}
+
+/* one {name: {rank: float}} mapping over columns first_col + c of the [n_rows][width] f32 block p */
+static PyObject *section_mapping(const float *p, int n_rows, int width, int first_col, PyObject *names, PyObject *ranks,
+                                 const long *col, const Py_hash_t *name_hash, const Py_hash_t *rank_hash) {
+    const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
+    PyObject *out = NEW_DICT(n_names);
+    if (!out) return NULL;
     for (Py_ssize_t i = 0; i < n_names; i++) {
-        long c = i;
-        if (cols != Py_None) {
-            c = PyLong_AsLong(PyTuple_GET_ITEM(cols, i));
-            if (c == -1 && PyErr_Occurred()) goto fail;
-        }
-        if (c < 0 || first_col + c >= width) {
-            PyErr_SetString(PyExc_ValueError, "nvrx_pyread.sections: column out of range");
-            goto fail;
-        }
-        PyObject *d = PyDict_New();
+        const float *q = p + first_col + (col ? col[i] : i);
+        PyObject *d = NEW_DICT(n_rows);
         if (!d) goto fail;
         for (int r = 0; r < n_rows; r++) {
-            PyObject *f = PyFloat_FromDouble((double)p[(Py_ssize_t)r * width + first_col + c]);
-            if (!f || PyDict_SetItem(d, PyTuple_GET_ITEM(ranks, r), f) < 0) {
+            PyObject *f = PyFloat_FromDouble((double)q[(Py_ssize_t)r * width]);
+            if (!f || SET_KNOWN(d, PyTuple_GET_ITEM(ranks, r), f, rank_hash[r]) < 0) {
                 Py_XDECREF(f);
                 Py_DECREF(d);
                 goto fail;
             }
             Py_DECREF(f);
         }
-        if (PyDict_SetItem(out, PyTuple_GET_ITEM(names, i), d) < 0) {
+        if (SET_KNOWN(out, PyTuple_GET_ITEM(names, i), d, name_hash[i]) < 0) {
             Py_DECREF(d);
             goto fail;
         }
         Py_DECREF(d);
     }
-    goto done;
+    return out;
 fail:
-    Py_CLEAR(out);
+    Py_DECREF(out);
+    return NULL;
+}
+
+/* sections(names, ranks, buf, offset, n_rows, width, first_col, cols[, second_col]) -> mapping, or a pair of mappings when
+ * second_col >= 0 (both score families of a report in one call: the name / rank hashes and the column table are shared).
+ * buf + offset: the first of n_rows rows of width f32 (the report's rows inside the result block, or an ndarray). */
+static PyObject *pyread_sections(PyObject *self, PyObject *args) {
+    PyObject *names, *ranks, *cols;
+    Py_buffer view;
+    Py_ssize_t offset;
+    int n_rows, width, first_col, second_col = -1;
+    if (!PyArg_ParseTuple(args, "O!O!y*niiiO|i", &PyTuple_Type, &names, &PyTuple_Type, &ranks, &view, &offset, &n_rows, &width, &first_col,
+                          &cols, &second_col))
+        return NULL;
+    PyObject *out = NULL, *a = NULL, *b = NULL;
+    Py_hash_t nh_stack[MAX_STACK_HASHES], rh_stack[MAX_STACK_HASHES], *nh = NULL, *rh = NULL;
+    long col_stack[MAX_STACK_HASHES], *col = NULL;
+    const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
+    if (n_rows < 0 || width <= 0 || first_col < 0 || offset < 0 || (offset % (Py_ssize_t)sizeof(float)) != 0 || PyTuple_GET_SIZE(ranks) != n_rows ||
+        view.len < offset + (Py_ssize_t)n_rows * width * (Py_ssize_t)sizeof(float) ||
+        (cols != Py_None && (!PyTuple_Check(cols) || PyTuple_GET_SIZE(cols) != n_names))) {
+        PyErr_SetString(PyExc_ValueError, "nvrx_pyread.sections: inconsistent shapes");
+        goto done;
+    }
+    const int last_first = second_col > first_col ? second_col : first_col;
+    if (cols != Py_None) {
+        col = n_names <= MAX_STACK_HASHES ? col_stack : PyMem_Malloc((size_t)n_names * sizeof(long));
+        if (!col) {
+            PyErr_NoMemory();
+            goto done;
+        }
+        for (Py_ssize_t i = 0; i < n_names; i++) {
+            col[i] = PyLong_AsLong(PyTuple_GET_ITEM(cols, i));
+            if (col[i] == -1 && PyErr_Occurred()) goto done;
+            if (col[i] < 0 || last_first + col[i] >= width) {
+                PyErr_SetString(PyExc_ValueError, "nvrx_pyread.sections: column out of range");
+                goto done;
+            }
+        }
+    } else if (n_names && last_first + n_names - 1 >= width) {
+        PyErr_SetString(PyExc_ValueError, "nvrx_pyread.sections: column out of range");
+        goto done;
+    }
+    if (!(nh = tuple_hashes(names, nh_stack)) || !(rh = tuple_hashes(ranks, rh_stack))) goto done;
+    const float *p = (const float *)((const char *)view.buf + offset);
+    a = section_mapping(p, n_rows, width, first_col, names, ranks, col, nh, rh);
+    if (!a) goto done;
+    if (second_col >= 0) {
+        b = section_mapping(p, n_rows, width, second_col, names, ranks, col, nh, rh);
+        if (!b) goto done;
+        out = PyTuple_Pack(2, a, b);
+    } else {
+        out = a;
+        a = NULL;
+    }
+done:
+    Py_XDECREF(a);
+    Py_XDECREF(b);
+    if (nh && nh != nh_stack) PyMem_Free(nh);
+    if (rh && rh != rh_stack) PyMem_Free(rh);
+    if (col && col != col_stack) PyMem_Free(col);
+    PyBuffer_Release(&view);
+    return out;
+}
+
+/* ranks(ranks, buf, offset, n_rows, width, col) -> {rank: float}: one column of the score block (the GPU scores) */
+static PyObject *pyread_ranks(PyObject *self, PyObject *args) {
+    PyObject *ranks;
+    Py_buffer view;
+    Py_ssize_t offset;
+    int n_rows, width, col;
+    if (!PyArg_ParseTuple(args, "O!y*niii", &PyTuple_Type, &ranks, &view, &offset, &n_rows, &width, &col)) return NULL;
+    PyObject *out = NULL;
+    if (n_rows < 0 || width <= 0 || col < 0 || col >= width || offset < 0 || (offset % (Py_ssize_t)sizeof(float)) != 0 ||
+        PyTuple_GET_SIZE(ranks) != n_rows || view.len < offset + (Py_ssize_t)n_rows * width * (Py_ssize_t)sizeof(float)) {
+        PyErr_SetString(PyExc_ValueError, "nvrx_pyread.ranks: inconsistent shapes");
+        goto done;
+    }
+    out = NEW_DICT(n_rows);
+    if (!out) goto done;
+    const float *p = (const float *)((const char *)view.buf + offset) + col;
+    for (int r = 0; r < n_rows; r++) {
+        PyObject *f = PyFloat_FromDouble((double)p[(Py_ssize_t)r * width]);
+        if (!f || PyDict_SetItem(out, PyTuple_GET_ITEM(ranks, r), f) < 0) {
+            Py_XDECREF(f);
+            Py_CLEAR(out);
+            goto done;
+        }
+        Py_DECREF(f);
+    }
 done:
     PyBuffer_Release(&view);
     return out;
@@ -77,13 +180,18 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
     Py_buffer view;
     if (!PyArg_ParseTuple(args, "O!O!y*O!", &PyTuple_Type, &names, &PyTuple_Type, &keys, &view, &PyTuple_Type, &rows)) return NULL;
     PyObject *out = NULL;
+    Py_hash_t kh[6];
     const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
     const Py_ssize_t total_rows = view.len / (Py_ssize_t)(8 * sizeof(float));
     if (PyTuple_GET_SIZE(keys) != 6 || PyTuple_GET_SIZE(rows) != n_names) {
         PyErr_SetString(PyExc_ValueError, "nvrx_pyread.summaries: six statistic keys and one row per name expected");
         goto done;
     }
-    out = PyDict_New();
+    for (int k = 0; k < 6; k++) {
+        kh[k] = PyObject_Hash(PyTuple_GET_ITEM(keys, k));
+        if (kh[k] == -1 && PyErr_Occurred()) goto done;
+    }
+    out = NEW_DICT(n_names);
     if (!out) goto done;
     const float *p = (const float *)view.buf;
     for (Py_ssize_t i = 0; i < n_names; i++) {
@@ -94,12 +202,14 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
             goto fail;
         }
         const float *v = p + row * 8;
-        PyObject *d = PyDict_New();
+        PyObject *d = NEW_DICT(6);
         if (!d) goto fail;
         for (int k = 0; k < 6; k++) {
-            /* NUM (column 5) is an integer in the reference's summaries (straggler.py:194) */
+            /* NUM (column 5) is an integer in the reference's summaries (straggler.py:194); a NUM that is not a finite
+             * number cannot come out of the statistics kernel: ValueError / OverflowError from PyLong_FromDouble, the
+             * same exceptions the Python builder raises */
             PyObject *x = k == 5 ? PyLong_FromDouble((double)v[k]) : PyFloat_FromDouble((double)v[k]);
-            if (!x || PyDict_SetItem(d, PyTuple_GET_ITEM(keys, k), x) < 0) {
+            if (!x || SET_KNOWN(d, PyTuple_GET_ITEM(keys, k), x, kh[k]) < 0) {
                 Py_XDECREF(x);
                 Py_DECREF(d);
                 goto fail;
@@ -266,7 +376,8 @@ done:
 
 static PyMethodDef pyread_methods[] = {
     {"flagged", pyread_flagged, METH_VARARGS, "the sets of identify_stragglers from the score kernel's flag bytes"},
-    {"sections", pyread_sections, METH_VARARGS, "section -> {rank -> score} from an f32 score block"},
+    {"sections", pyread_sections, METH_VARARGS, "section -> {rank -> score} from an f32 score block (one or both score families)"},
+    {"ranks", pyread_ranks, METH_VARARGS, "rank -> score: one column of an f32 score block"},
     {"summaries", pyread_summaries, METH_VARARGS, "name -> {Statistic -> value} from f32 statistics rows"},
     {"copy_sets", pyread_copy_sets, METH_O, "a dict of sets, copied one level deep"},
     {NULL, NULL, 0, NULL},

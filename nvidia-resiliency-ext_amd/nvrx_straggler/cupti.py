@@ -40,9 +40,11 @@ class CuptiManager:
         """
         import nvrx_cupti_module as profiler_module  # lazy, like the reference (cupti.py:35)
 
-        # NVRX_GPU_TIMING=kernels: per-kernel durations by kernel name through rocprofiler-sdk (ktrace.py);
-        # otherwise one GPU-time row per profiled region (hip_profiler.py)
-        self.per_kernel = os.environ.get("NVRX_GPU_TIMING", "stamp") == "kernels"
+        # mode "kernels" (NVRX_GPU_TIMING=kernels, or a multi-rank job: ktrace.timing_mode): per-kernel durations by
+        # kernel name through rocprofiler-sdk (ktrace.py); otherwise one GPU-time row per profiled region (hip_profiler.py)
+        from . import ktrace as _ktrace
+
+        self.per_kernel = _ktrace.timing_mode() == "kernels"
         profiler_cls = profiler_module.KernelTraceProfiler if self.per_kernel else profiler_module.CuptiProfiler
         self.cupti_ext = profiler_cls(bufferSize=bufferSize, numBuffers=numBuffers, statsMaxLenPerKernel=statsMaxLenPerKernel,
                                       **({} if rings is None else {"rings": rings}))

@@ -59,7 +59,8 @@ def _warn_region_mode_once() -> None:
             "nvrx straggler: GPU time is measured per profiled REGION (NVRX_GPU_TIMING=%s). Collectives inside a "
             "profile_cuda=True section add peer-wait time to it and cannot be excluded the way the reference excludes "
             "ncclDev* kernels; relative GPU scores may flatten. Keep collectives outside GPU-timed sections or set "
-            "NVRX_GPU_TIMING=kernels.", os.environ.get("NVRX_GPU_TIMING", "stamp"))
+            "NVRX_GPU_TIMING=kernels (the default of a multi-rank job when nvrx_straggler is imported before the HIP "
+            "runtime starts).", os.environ.get("NVRX_GPU_TIMING", "stamp"))
 
 
 class KernelStats:
@@ -100,7 +101,7 @@ class CuptiProfiler:
         self._active_row: Optional[int] = None
         self._closed = False
         # device timestamps unless asked otherwise (or the backend cannot: the CPU test backend)
-        self._stamps = os.environ.get("NVRX_GPU_TIMING", "stamp") != "event" and hasattr(rings, "stamp_begin")
+        self._stamps = os.environ.get("NVRX_GPU_TIMING", "stamp").strip().lower() != "event" and hasattr(rings, "stamp_begin")
         CuptiProfiler._live = weakref.ref(self)
 
     # ---- lifecycle -----------------------------------------------------------------------------

@@ -13,10 +13,10 @@ collected on the SDK's thread, ``harvest()`` drains them and appends each kernel
 ring row, and the statistics (mean-of-middles median, population stddev; CuptiProfiler.cpp:44-74) are
 computed by the same HIP kernel as every other row.
 
-The SDK only accepts tools before the HIP runtime initialises.  Importing ``nvrx_straggler`` with
-``NVRX_GPU_TIMING=kernels`` set adds the library to ``ROCP_TOOL_LIBRARIES`` at import time, so the SDK picks it up
-when HIP starts; if HIP was initialised earlier the profiler raises with the advice to set the variable (or the
-import order) accordingly.
+The SDK only accepts tools before the HIP runtime initialises.  Importing ``nvrx_straggler`` registers the tool
+right away (``setup``: ``rocprofiler_force_configure`` with the SDK's tool search kept off the large libraries) when
+the mode is ``kernels`` -- named by ``NVRX_GPU_TIMING=kernels``, or chosen for the processes of a multi-rank job
+(``timing_mode``); if HIP was initialised earlier the profiler raises with the advice to import the package first.
 """
 from __future__ import annotations
 
@@ -50,6 +50,7 @@ _ROW_UNKNOWN = -2  # key id without an entry in the key -> row table yet (-1: th
 # every symbol include/nvrx_ktrace.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("nvrx_ktrace_setup", c_int, [c_int]),
+    ("nvrx_ktrace_hidden_libraries", c_int, []),
     ("nvrx_ktrace_ready", c_int, []),
     ("nvrx_ktrace_start", c_int, []),
     ("nvrx_ktrace_stop", c_int, []),
@@ -100,13 +101,18 @@ def _check(rc: int) -> int:
 def setup(max_pending: int = 0) -> None:
     """Register the tool with rocprofiler-sdk.  Call before the first HIP call of the process.
 
-    Default: name the library in ``ROCP_TOOL_LIBRARIES`` -- the SDK then loads it when the HIP runtime
-    initialises, the same route ``rocprofv3`` uses for its own tool.  ``NVRX_KTRACE_FORCE=1`` registers
-    immediately through ``rocprofiler_force_configure`` instead.  Either way the SDK's own start-up is slow the
-    first time on a freshly booted machine (~50 s measured on ROCm 7.2 while it pages its libraries in, ~3 s
-    afterwards); the default route pays that inside the first HIP call rather than inside ``import``."""
+    Default: ``rocprofiler_force_configure`` right now, with the SDK's tool search kept away from the large libraries of
+    the process (``nvrx_ktrace.cpp``, "tool discovery guard").  What rounds 1-3 knew as the SDK's start-up stall is that
+    search: the SDK ELF-parses EVERY loaded shared library for a ``rocprofiler_configure`` symbol and its parser reads
+    each file front to back -- 10.7 GB of ``read()`` calls in a PyTorch process, 3 s from a warm page cache, 70 s in the
+    build container, 130-165 s on a GPU box with cold storage (``tools/debug/readtrace.c`` has the backtrace:
+    ``rocprofiler_set_api_table -> ... -> std::istream::read``).  Handing our tool over explicitly while the big libraries
+    are hidden from that one search costs 0.1 GB of reads and 0.05 s (``profiles/r04c_ktrace_start_up.txt``).
+
+    ``NVRX_KTRACE_FORCE=0`` takes the SDK's own route instead -- the library named in ``ROCP_TOOL_LIBRARIES``, loaded
+    when the HIP runtime registers with the SDK (what ``rocprofv3`` does for its tool) -- and pays the full search."""
     global _setup_error
-    if os.environ.get("NVRX_KTRACE_FORCE", "") == "1":
+    if os.environ.get("NVRX_KTRACE_FORCE", "1") != "0":
         try:
             _check(load().nvrx_ktrace_setup(int(max_pending)))
             _setup_error = None
@@ -123,75 +129,84 @@ def setup(max_pending: int = 0) -> None:
     _setup_error = None
 
 
-_prefetch_thread: Optional[threading.Thread] = None
-prefetch_stats: Dict[str, float] = {}
+_mode: Optional[str] = None
+_mode_note: str = ""
 
 
-def _prefetch_gpu_libraries() -> Optional[threading.Thread]:
-    """OPT-IN (``NVRX_KTRACE_PREFETCH=1``): read the large GPU libraries PyTorch links into the page cache, sequentially,
-    on a background thread, before HIP starts.
+def _hip_is_up() -> bool:
+    try:
+        import torch
 
-    With a tool attached that asks for code-object callbacks, the first HIP call loads EVERY GPU code object of every
-    loaded library instead of deferring them: 10.7 GB of ``read()`` calls on this image (libmagma 1.3 GB, MIOpen 0.95,
-    rocsolver 0.76, libtorch_hip 0.42, rocsparse 0.39 ...), against 0.00 GB without a tool.  From a warm page cache
-    that takes 3 s; on a box whose storage is cold 1.5-1.8 GB of it come from storage at 10-14 MB/s (process in D
-    state, ``submit_bio_wait``) and the call takes 130-165 s -- the "rocprofiler-sdk start-up stall" of rounds 1-2
-    (tools/debug/ktrace_stall_io.sh, ktrace_eager_load.py).  Reading the files front to back was measured at ~900 MB/s on
-    one box (there the read-ahead turns minutes into seconds) but a box that is slow for sequential reads as well
-    gains nothing and reads 5.3 GB instead of 1.8: a cold box still ran into the 150 s limit of the GPU test with the
-    read-ahead on.  Hence opt-in, for deployments that know their storage."""
-    if os.environ.get("NVRX_KTRACE_PREFETCH", "0") in ("0", ""):
-        return None
+        return bool(torch.cuda.is_initialized())
+    except Exception:  # noqa: BLE001
+        return False
 
-    def run() -> None:
-        import glob
-        import importlib.util
-        import time
 
-        t0 = time.monotonic()
-        total = 0
+def timing_mode() -> str:
+    """How ``profile_cuda=True`` sections measure GPU time in this process: ``stamp`` | ``event`` | ``kernels``.
+
+    ``NVRX_GPU_TIMING`` names it outright.  Unset (or ``auto``) it is decided ONCE, the first time anybody asks -- at
+    ``import nvrx_straggler``:
+
+    * a process of a multi-rank job (``WORLD_SIZE`` > 1 in the environment, what ``torchrun`` and every launcher that
+      follows its convention exports) gets ``kernels`` -- the reference's data model (CuptiProfiler.cpp:168-207): the GPU
+      score is the kernel-weighted mean over real kernels and RCCL's ``ncclDev*`` kernels, whose duration is peer-wait
+      time, are left out (reporting.py:330-336).  One row per REGION cannot do that: a step that ends in a collective
+      lasts as long as the slowest rank's on every rank and a slow GPU scores 1.0 (tests/test_host_logic.py,
+      ``test_region_timing_flattens_gpu_scores...``; tests/test_gpu_multiproc.py runs it on real kernels);
+    * a single-process job, or a process whose HIP runtime is already up (rocprofiler-sdk accepts tools only before
+      that), gets ``stamp``.
+
+    Registration is cheap now (``setup``); if it fails the mode falls back to ``stamp`` and ``mode_note()`` says why."""
+    global _mode, _mode_note
+    if _mode is not None:
+        return _mode
+    with _lock:
+        if _mode is not None:
+            return _mode
+        want = os.environ.get("NVRX_GPU_TIMING", "").strip().lower() or "auto"
+        if want in ("stamp", "event"):
+            _mode = want
+        elif want == "kernels":
+            _mode = "kernels"  # asked for by name: errors of the registration surface when the profiler is built
+        else:
+            try:
+                world = int(os.environ.get("WORLD_SIZE", "1") or "1")
+            except ValueError:
+                world = 1
+            if world <= 1:
+                _mode, _mode_note = "stamp", "single-process job"
+            elif not os.path.exists("/dev/kfd"):
+                _mode, _mode_note = "stamp", "no AMD GPU driver node (/dev/kfd) in this process' view"
+            elif _hip_is_up():
+                _mode, _mode_note = "stamp", ("multi-rank job, but the HIP runtime was initialised before nvrx_straggler was "
+                                              "imported: rocprofiler-sdk accepts tools only before that")
+            else:
+                _mode, _mode_note = "kernels", f"multi-rank job (WORLD_SIZE={world})"
+    if _mode == "kernels":
         try:
-            spec = importlib.util.find_spec("torch")
-            if spec is None or not spec.origin:
-                return
-            libdir = os.path.join(os.path.dirname(spec.origin), "lib")
-            files = sorted(((os.path.getsize(f), f) for f in glob.glob(os.path.join(libdir, "*.so*")) if os.path.isfile(f)),
-                           reverse=True)
-            chunk = memoryview(bytearray(16 << 20))
-            for size, path in files:
-                if size < (32 << 20):
-                    break
-                with open(path, "rb", buffering=0) as f:
-                    try:
-                        os.posix_fadvise(f.fileno(), 0, 0, os.POSIX_FADV_SEQUENTIAL)
-                    except (AttributeError, OSError):
-                        pass
-                    while True:
-                        n = f.readinto(chunk)  # releases the GIL
-                        if not n:
-                            break
-                        total += n
-        except Exception:  # noqa: BLE001  (an optimisation: never in the way)
-            pass
-        finally:
-            prefetch_stats["seconds"] = time.monotonic() - t0
-            prefetch_stats["gigabytes"] = total / 1e9
+            setup()
+        except Exception as e:  # noqa: BLE001
+            if want == "auto":
+                with _lock:
+                    _mode, _mode_note = "stamp", f"per-kernel tracing could not be registered ({e})"
+    return _mode
 
-    t = threading.Thread(target=run, name="nvrx-ktrace-prefetch", daemon=True)
-    t.start()
-    return t
+
+def mode_note() -> str:
+    timing_mode()
+    return _mode_note
+
+
+def _reset_mode_for_tests() -> None:
+    global _mode, _mode_note
+    _mode, _mode_note = None, ""
 
 
 def setup_from_env() -> None:
-    """Import-time hook: register early when ``NVRX_GPU_TIMING=kernels`` (errors surface at first use)."""
-    if os.environ.get("NVRX_GPU_TIMING", "") == "kernels":
-        global _prefetch_thread
-        try:
-            setup()
-            if _prefetch_thread is None:
-                _prefetch_thread = _prefetch_gpu_libraries()
-        except Exception:  # noqa: BLE001  (reported by KernelTraceProfiler.__init__)
-            pass
+    """Import-time hook: settle the timing mode, which registers the tracer when the mode is ``kernels`` (it has to
+    happen before anything touches HIP; errors of an explicitly requested mode surface at first use)."""
+    timing_mode()
 
 
 def drain_all() -> np.ndarray:
@@ -248,8 +263,6 @@ class KernelTraceProfiler:
         if not self._lib.nvrx_ktrace_ready():
             import torch
 
-            if _prefetch_thread is not None:
-                _prefetch_thread.join(timeout=60.0)  # (opt-in read-ahead: let it finish before HIP starts reading page by page)
             torch.cuda.init()  # the SDK calls the tool's initialiser when the runtime comes up
             if not self._lib.nvrx_ktrace_ready():
                 raise RuntimeError(

@@ -32,6 +32,7 @@ from typing import Any, Dict, Iterable, List, Optional, Sequence, Union
 
 from . import _native
 from . import backend as _backend_mod
+from . import ktrace as _ktrace
 from .cupti import CuptiManager
 from .interval_tracker import ReportIntervalTracker
 from .reporting import ReportGenerator
@@ -178,7 +179,7 @@ class Detector:
 
         # device side: the rings every section / GPU-timed region records into, and the profiler that feeds them
         capacity = int(CustomSection.max_elapseds_len)
-        per_kernel = os.environ.get("NVRX_GPU_TIMING", "") == "kernels"
+        per_kernel = _ktrace.timing_mode() == "kernels"
         if per_kernel and int(max_rows) == 256:
             max_rows = 4096  # one row per distinct kernel key; 4096 x 8192 f32 = 128 MB of 288 GB
         cls.rings = _backend_mod.get_backend().make_rings(1, int(max_rows), capacity)

@@ -6,13 +6,10 @@ drained, RCCL-style names are kept out of the GPU score, and nothing is recorded
 The tool has to register with rocprofiler-sdk before the HIP runtime initialises, so the scenario runs in a
 fresh interpreter (and this file sorts first, so it runs before the test session itself holds a HIP context).
 
-The first HIP call of a process with this tool attached is slow where storage is cold: HIP then loads every GPU code
-object of every loaded library eagerly (10.7 GB of read() calls on this image, 0.00 GB without a tool) and the
-loader's access pattern pulls them in at 10-14 MB/s -- 130-165 s on such a box, 3 s from a warm page cache
-(tools/debug/ktrace_stall_io.sh, ktrace_eager_load.py; rounds 1-2 knew it as "rocprofiler-sdk's start-up stall").
-An opt-in sequential read-ahead exists (``NVRX_KTRACE_PREFETCH=1``: ~900 MB/s on one box, no help on a box whose
-storage is slow either way); the scenario gets 150 s and is reported as XFAIL with the measured wait if a box is
-slower than that."""
+Start-up: rocprofiler-sdk looks for tools by reading EVERY loaded library front to back (10.7 GB of read() calls in a
+PyTorch process: the 130-165 s "start-up stall" of rounds 1-3 on boxes with cold storage).  ``ktrace.setup`` hands the tool
+over explicitly with the large libraries hidden from that one search (``nvrx_ktrace.cpp``, "tool discovery guard"), so
+the scenarios below have no slow-box branch any more: registration has to finish in seconds and the test asserts it."""
 import json
 import os
 import subprocess
@@ -28,14 +25,23 @@ faulthandler.enable()
 faulthandler.dump_traceback_later(140, exit=True)   # a hang becomes a traceback, not a lost GPU box
 sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
 os.environ["NVRX_GPU_TIMING"] = "kernels"
+import time
 import numpy as np
+import torch                               # (libraries resident, HIP not started)
+def _rchar():
+    return int(dict(l.split(": ") for l in open("/proc/self/io").read().strip().splitlines())["rchar"])
+_t0, _r0 = time.monotonic(), _rchar()
 import nvrx_straggler                      # registers the tracer: no HIP call has happened yet
 from nvrx_straggler import Detector, Statistic, ktrace
-import torch
 from oracle import oracle
 
-out = {}
+out = {"register_s": time.monotonic() - _t0, "register_read_gb": (_rchar() - _r0) / 1e9,
+       "hidden_libraries": int(ktrace.load().nvrx_ktrace_hidden_libraries())}
+_t0, _r0 = time.monotonic(), _rchar()
 torch.cuda.set_device(0)
+torch.zeros(1, device="cuda")
+out["first_hip_call_s"] = time.monotonic() - _t0
+out["first_hip_call_read_gb"] = (_rchar() - _r0) / 1e9
 x = torch.randn(1024, 1024, device="cuda")
 y = torch.randn(1 << 20, device="cuda")
 (x @ x).sum().item()                        # warm-up OUTSIDE any section: must not be recorded
@@ -78,36 +84,32 @@ report2 = Detector.generate_report()
 out["second_keys"] = sorted(report2.local_kernel_summaries.keys())
 out["second_nums"] = [int(v[Statistic.NUM]) for v in report2.local_kernel_summaries.values()]
 out["dropped"] = prof.dropped
-from nvrx_straggler import ktrace as _kt
-out["prefetch"] = dict(_kt.prefetch_stats)
 Detector.shutdown()
 print("RESULT " + json.dumps(out))
 '''
 
 
-@pytest.mark.gpu
-def test_kernels_are_traced_by_name_and_scored():
+def _run(script, env_extra=None, timeout=150):
     env = dict(os.environ)
-    env.pop("NVRX_GPU_TIMING", None)
-    import time as _time
-
-    t_start = _time.monotonic()
-    try:
-        p = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\n" + SCRIPT], capture_output=True, text=True, timeout=150, env=env)
-    except subprocess.TimeoutExpired:
-        # visible in the GPU test summary as XFAIL with the measured wait (a silent skip would hide that the per-kernel
-        # mode's evidence is missing on this box); the stall is inside rocprofiler-sdk's own start-up
-        pytest.xfail(f"rocprofiler-sdk start-up did not complete within {_time.monotonic() - t_start:.0f} s on this box "
-                     "(inside the first HIP call, before any nvrx code ran)")
-    if p.returncode != 0 and "Timeout (0:02:20)" in p.stderr and ("_lazy_init" in p.stderr or "ktrace.py" in p.stderr):
-        pytest.xfail(f"rocprofiler-sdk start-up stalled for {_time.monotonic() - t_start:.0f} s inside the first HIP call")
-    print(f"[ktrace] subprocess wall time {_time.monotonic() - t_start:.1f} s (SDK start-up + test body)")
-    for l in p.stdout.splitlines():
-        if l.startswith("RESULT "):
-            print("[ktrace] read-ahead of the GPU libraries:", json.loads(l[len("RESULT "):]).get("prefetch"))
+    for k in ("NVRX_GPU_TIMING", "WORLD_SIZE", "RANK"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\n" + script], capture_output=True, text=True, timeout=timeout, env=env)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
-    out = json.loads(line[len("RESULT "):])
+    return json.loads(line[len("RESULT "):])
+
+
+@pytest.mark.gpu
+def test_kernels_are_traced_by_name_and_scored():
+    out = _run(SCRIPT)
+    print(f"[ktrace] registration {out['register_s']:.2f} s / {out['register_read_gb']:.2f} GB read "
+          f"({out['hidden_libraries']} libraries kept out of the SDK's tool search), first HIP call "
+          f"{out['first_hip_call_s']:.2f} s / {out['first_hip_call_read_gb']:.2f} GB read")
+    # the start-up that used to take minutes where storage is cold: seconds, and next to nothing read
+    assert out["register_s"] < 30.0 and out["first_hip_call_s"] < 30.0, out
+    assert out["register_read_gb"] < 1.0 and out["first_hip_call_read_gb"] < 1.0, out
+    assert out["hidden_libraries"] > 0
     assert out["ready"] == 1
     assert out["pending_before"] == 0  # the warm-up matmul ran outside a section
     names = out["names"]
@@ -130,3 +132,184 @@ def test_kernels_are_traced_by_name_and_scored():
     assert abs(out["gpu_rel"]["0"] - 1.0) < 1e-6 and abs(out["gpu_ind"]["0"] - 1.0) < 1e-6
     assert out["second_keys"] and all(n == 5 for n in out["second_nums"]), out
     assert out["dropped"] == 0
+
+
+GRAPH_SCRIPT = r'''
+import faulthandler, json, os, sys
+faulthandler.enable()
+faulthandler.dump_traceback_later(140, exit=True)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+os.environ["NVRX_GPU_TIMING"] = "kernels"
+import nvrx_straggler                      # registers the tracer before HIP starts
+import nvrx_cupti_module as cupti_module
+import torch
+from torch import nn
+
+torch.cuda.set_device(0)
+model = nn.Sequential(nn.Linear(256, 256, bias=False), nn.ReLU(), nn.Linear(256, 64, bias=False), nn.Sigmoid()).to("cuda", torch.float32)
+x = torch.randn(256, 256, device="cuda")
+# PyTorch's capture recipe: one eager pass on a side stream first (BLAS handles / workspaces exist before capture)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side), torch.no_grad():
+    for _ in range(2):
+        model(x)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g), torch.no_grad():
+    _ = model(x)
+torch.cuda.synchronize()
+
+prof = cupti_module.KernelTraceProfiler()
+prof.initialize()
+prof.start()
+g.replay()
+torch.cuda.synchronize()
+with_graph = prof.get_stats()
+prof.reset()
+with torch.no_grad():
+    _ = model(x)
+torch.cuda.synchronize()
+no_graph = prof.get_stats()
+prof.reset()
+# REPS replays against REPS eager passes: the counts have to follow
+REPS = 7
+for _ in range(REPS):
+    g.replay()
+torch.cuda.synchronize()
+with_graph_n = prof.get_stats()
+prof.reset()
+prof.stop()
+g.replay()                                  # after stop(): not recorded
+torch.cuda.synchronize()
+after_stop = prof.get_stats()
+prof.shutdown()
+prof.close()
+plain = lambda st: {k: int(v.num_calls) for k, v in st.items()}
+print("RESULT " + json.dumps({"with_graph": plain(with_graph), "no_graph": plain(no_graph), "with_graph_n": plain(with_graph_n),
+                              "after_stop": plain(after_stop), "reps": REPS,
+                              "medians": {k: [with_graph[k].median, no_graph[k].median] for k in no_graph if k in with_graph}}))
+'''
+
+
+@pytest.mark.gpu
+def test_kernels_of_a_replayed_graph_are_recorded_like_the_same_kernels_launched_one_by_one():
+    """Twin of the reference's tests/straggler/unit/test_cupti_ext.py:125-174 (``test_with_cuda_graph``): the forward pass of
+    the same four-layer model, once as a replayed graph and once eagerly, with the profiler running -- every kernel key of
+    the eager pass must be among the keys of the replay with the same ``num_calls``.  rocprofiler-sdk reports the
+    dispatches of a graph launch one by one with the kernel ids of the captured kernels, so key (name + launch geometry)
+    and count carry over; the test also replays seven times (counts x 7) and once after ``stop()`` (nothing)."""
+    out = _run(GRAPH_SCRIPT)
+    ng, wg = out["no_graph"], out["with_graph"]
+    print("[ktrace graph] eager keys:", ng, "\n[ktrace graph] replay keys:", wg)
+    assert ng, "the eager forward pass recorded no kernel"
+    for k, n in ng.items():                  # the reference's assertion, word for word
+        assert k in wg, (k, sorted(wg))
+        assert n == wg[k], (k, n, wg[k])
+    assert sum(ng.values()) >= 4             # two GEMMs, ReLU, Sigmoid
+    for k, n in wg.items():
+        assert out["with_graph_n"].get(k) == out["reps"] * n, (k, out["with_graph_n"])
+    assert out["after_stop"] == {}
+    for k, (a, b) in out["medians"].items():  # the same kernel on the same data: durations of the same order
+        assert 0.2 < a / b < 5.0, (k, a, b)
+
+
+COLLECTIVE_SCRIPT = r'''
+import faulthandler, json, os, sys
+faulthandler.enable()
+faulthandler.dump_traceback_later(170, exit=True)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+import nvrx_straggler                      # WORLD_SIZE=2 is in the environment and HIP is not up: this settles the GPU-timing mode
+from nvrx_straggler import Detector, Statistic, ktrace
+import torch
+import torch.distributed as dist
+
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)                    # both ranks share the one MI355X of the box (gloo group; RCCL refuses that)
+dist.init_process_group("gloo", init_method=os.environ["NVRX_TEST_INIT"], rank=rank, world_size=2)
+Detector.initialize(scores_to_compute=["relative_perf_scores"], gather_on_rank0=True, node_name=f"node{rank}")
+cycles = int(float(os.environ["NVRX_TEST_CYCLES"]) * (1.25 if rank == 1 else 1.0))   # rank 1: the same kernel, 25 % slower
+t = torch.ones(4096, device="cuda")
+for i in range(40):
+    with Detector.detection_section("train_step", profile_cuda=True):
+        torch.cuda._sleep(cycles)           # the step's compute: one kernel, one key, duration set by its argument
+        dist.all_reduce(t)                  # the step ends in a collective: nobody leaves before the slowest rank arrives
+torch.cuda.synchronize()
+local = Detector.cupti_manager.get_results()      # this rank's kernel statistics (every rank; the report exists on rank 0 only)
+out = {"mode": ktrace.timing_mode(), "note": ktrace.mode_note(),
+       "keys": {k: [float(v.median), int(v.num_calls)] for k, v in local.items()}}
+report = Detector.generate_report()
+if rank == 0:
+    out["gpu_rel"] = {str(k): float(v) for k, v in report.gpu_relative_perf_scores.items()}
+    out["flagged"] = sorted(s.rank for s in report.identify_stragglers(gpu_rel_threshold=0.85)["straggler_gpus_relative"])
+    out["report_keys"] = sorted(report.local_kernel_summaries)
+else:
+    assert report is None
+dist.barrier()
+Detector.shutdown()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _run_two_ranks(env_extra, cycles):
+    import socket
+    import tempfile
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ)
+        env.pop("NVRX_GPU_TIMING", None)
+        env.update({"RANK": str(rank), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "NVRX_TEST_INIT": f"tcp://127.0.0.1:{port}",
+                    "NVRX_TEST_CYCLES": str(cycles), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        env.update(env_extra)
+        procs.append(subprocess.Popen([sys.executable, "-c", f"REPO = {REPO!r}\n" + COLLECTIVE_SCRIPT], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=env))
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=200)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, so[-2000:] + "\n" + se[-3000:]
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]))
+    return outs
+
+
+@pytest.mark.gpu
+def test_a_step_that_ends_in_a_collective_per_kernel_default_sees_the_slow_gpu_region_timing_does_not():
+    """tests/test_host_logic.py::test_region_timing_flattens_gpu_scores_when_the_region_holds_a_collective on REAL kernels:
+    two processes, rank 1's compute kernel takes 25 % longer, the GPU-timed section ends in an all-reduce.
+
+    * default of a multi-rank job (``WORLD_SIZE=2``, nothing else set): ``ktrace.timing_mode()`` picks ``kernels`` -- the
+      reference's data model (CuptiProfiler.cpp:168-207, reporting.py:237-253) -- and rank 1 scores 1/1.25 = 0.8 and is
+      flagged at 0.85, whatever the collective's wait looks like;
+    * ``NVRX_GPU_TIMING=stamp`` (one row per REGION): both regions last as long as the slow rank's compute plus the
+      exchange, both GPUs score ~1.0, nothing is flagged -- the deviation INTEGRATION.md documents.
+
+    The two ranks share the box's one GPU, so the collective is gloo's (RCCL refuses two ranks on one device) and no RCCL
+    kernel can show up here; the ``ncclDev`` filter is pinned on the kernel names of the installed librccl.so instead
+    (tests/test_host_logic.py::test_rccl_kernel_names_of_the_installed_library_are_filtered)."""
+    cycles = 4.0e6
+    k0, k1 = _run_two_ranks({}, cycles)
+    print("[ktrace collective] per-kernel:", k0["mode"], k0["note"], k0.get("gpu_rel"), sorted(k0["keys"]))
+    assert k0["mode"] == k1["mode"] == "kernels", (k0["mode"], k0["note"], k1["mode"], k1["note"])
+    spin = [k for k in k0["keys"] if "spin" in k.lower() or "sleep" in k.lower()]
+    assert spin, sorted(k0["keys"])
+    assert k0["keys"][spin[0]][1] == 40 and k1["keys"][spin[0]][1] == 40       # one record per step under the same key
+    ratio = k0["keys"][spin[0]][0] / k1["keys"][spin[0]][0]
+    assert abs(ratio - 0.8) < 0.03, (ratio, k0["keys"], k1["keys"])
+    assert abs(k0["gpu_rel"]["0"] - 1.0) < 0.03 and abs(k0["gpu_rel"]["1"] - 0.8) < 0.04, k0["gpu_rel"]
+    assert k0["flagged"] == [1]
+    r0, r1 = _run_two_ranks({"NVRX_GPU_TIMING": "stamp"}, cycles)
+    print("[ktrace collective] per-region:", r0["mode"], r0.get("gpu_rel"), sorted(r0["keys"]))
+    assert r0["mode"] == r1["mode"] == "stamp"
+    assert r0["report_keys"] == ["hipevent::train_step"] and len(r0["keys"]) == 1
+    assert min(r0["gpu_rel"].values()) > 0.9, r0["gpu_rel"]                   # the slow GPU is invisible ...
+    assert r0["flagged"] == []                                                 # ... and not flagged

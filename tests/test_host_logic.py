@@ -6,6 +6,8 @@ import math
 import os
 import pickle
 import re
+import subprocess
+import sys
 import time
 
 import numpy as np
@@ -47,7 +49,7 @@ def test_ktrace_library_exports_every_symbol_in_its_header():
 
     header = open(os.path.join(REPO, "include", "nvrx_ktrace.h")).read()
     declared = set(re.findall(r"^(?:int|uint64_t|const char \*)\s*(nvrx_ktrace_\w+)\s*\(", header, flags=re.M))
-    assert len(declared) == 12, declared
+    assert len(declared) == 13, declared
     lib = ktrace.load()
     assert declared == {name for name, _, _ in ktrace.SYMBOLS}
     for name in declared:
@@ -956,3 +958,128 @@ def test_c_flag_decoder_equals_the_python_decoder(order, monkeypatch):
         reporting._pyread.flagged(b"\x00" * 10, 0, 2, 6, 2, True, True, [1, 2], ("a", "b"), None, None)   # buffer too short
     with pytest.raises(ValueError):
         reporting._pyread.flagged(b"\x01" * 12, 0, 2, 6, 2, True, True, [1, 2], ("a", "b"), (0, 5), None)  # column out of range
+
+
+def test_rccl_kernel_names_of_the_installed_library_are_filtered():
+    """The reference keeps collective kernels out of the GPU score by the substring "ncclDev" (reporting.py:330-336:
+    NCCL's ``ncclDevKernel_*``).  RCCL's device kernels have other names -- ``rcclGenericKernel<N, bool>`` and the
+    ``mscclKernel_*`` family -- so the filter is checked against what the INSTALLED librccl.so actually launches: every
+    kernel entry point of the library (its host-side launch stubs carry the device kernels' mangled names, which is what
+    the tracer's keys are made of) must be dropped by ``is_collective_kernel``, and by the reference's plain substring
+    too (the mangled names spell out the argument types ``ncclDevKernelArgsStorage`` / ``ncclDevComm``)."""
+    import importlib.util
+    import re
+
+    from nvrx_straggler import reporting
+
+    spec = importlib.util.find_spec("torch")
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+    if not os.path.exists(path):
+        pytest.skip("no librccl.so next to this PyTorch")
+    names = set()
+    pat = re.compile(rb"_Z\d+(?:rcclGenericKernel|mscclKernel|ncclDevKernel|ncclKernel)[A-Za-z0-9_]*")
+    with open(path, "rb") as f:
+        tail = b""
+        while True:
+            chunk = f.read(16 << 20)
+            if not chunk:
+                break
+            buf = tail + chunk
+            names.update(m.group(0).decode() for m in pat.finditer(buf))
+            tail = buf[-256:]
+    assert len(names) >= 8, sorted(names)[:10]
+    assert any("rcclGenericKernel" in n for n in names) and any("mscclKernel" in n for n in names), sorted(names)[:10]
+    for n in names:
+        key = f"{n}_blk_256_1_1_grid_64_1_1"
+        assert reporting.is_collective_kernel(key), n
+        assert "ncclDev" in key, n   # the reference's own filter hits RCCL's mangled names as well
+    # and nothing else is caught
+    for n in ("Cijk_Ailk_Bljk_SB_MT128x128x16_blk_256_1_1_grid_64_1_1", "_ZN2at6native29vectorized_elementwise_kernelILi4E_blk_256_1_1_grid_8_1_1",
+              "hipevent::train_step"):
+        assert not reporting.is_collective_kernel(n)
+    kept = reporting.ReportGenerator._filter_out_nccl_kernels if hasattr(reporting.ReportGenerator, "_filter_out_nccl_kernels") else None
+    if kept is not None:
+        some = {f"{next(iter(names))}_blk_1_1_1_grid_1_1_1": 1, "gemm_blk_1_1_1_grid_1_1_1": 2}
+        try:
+            out = kept(some)
+        except TypeError:
+            out = kept(None, some)
+        assert list(out) == ["gemm_blk_1_1_1_grid_1_1_1"]
+
+
+def test_gpu_timing_mode_defaults(monkeypatch):
+    """``ktrace.timing_mode``: a name in NVRX_GPU_TIMING wins; unset, a process of a multi-rank job whose HIP runtime is not
+    up yet gets per-kernel tracing (the reference's data model), everything else region stamps."""
+    from nvrx_straggler import ktrace
+
+    calls = []
+    monkeypatch.setattr(ktrace, "setup", lambda max_pending=0: calls.append("setup"))
+    monkeypatch.setattr(ktrace, "_hip_is_up", lambda: False)
+    real_exists = os.path.exists
+    monkeypatch.setattr(ktrace.os.path, "exists", lambda p: True if p == "/dev/kfd" else real_exists(p))
+
+    def mode(env):
+        for k in ("NVRX_GPU_TIMING", "WORLD_SIZE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ktrace._reset_mode_for_tests()
+        del calls[:]
+        return ktrace.timing_mode(), list(calls)
+
+    try:
+        assert mode({}) == ("stamp", [])
+        assert mode({"WORLD_SIZE": "1"}) == ("stamp", [])
+        assert mode({"WORLD_SIZE": "8"}) == ("kernels", ["setup"])
+        assert "WORLD_SIZE=8" in ktrace.mode_note()
+        assert mode({"WORLD_SIZE": "8", "NVRX_GPU_TIMING": "stamp"}) == ("stamp", [])
+        assert mode({"WORLD_SIZE": "8", "NVRX_GPU_TIMING": "event"}) == ("event", [])
+        assert mode({"NVRX_GPU_TIMING": "kernels"}) == ("kernels", ["setup"])
+        assert mode({"WORLD_SIZE": "8", "NVRX_GPU_TIMING": "auto"}) == ("kernels", ["setup"])
+        monkeypatch.setattr(ktrace, "_hip_is_up", lambda: True)
+        assert mode({"WORLD_SIZE": "8"}) == ("stamp", [])
+        assert "before" in ktrace.mode_note()
+        monkeypatch.setattr(ktrace, "_hip_is_up", lambda: False)
+
+        def broken(max_pending=0):
+            raise RuntimeError("no sdk")
+
+        monkeypatch.setattr(ktrace, "setup", broken)
+        assert mode({"WORLD_SIZE": "8"})[0] == "stamp" and "no sdk" in ktrace.mode_note()
+        assert mode({"NVRX_GPU_TIMING": "kernels"})[0] == "kernels"   # asked for by name: the error surfaces at first use
+        monkeypatch.setattr(ktrace.os.path, "exists", lambda p: False if p == "/dev/kfd" else real_exists(p))
+        monkeypatch.setattr(ktrace, "setup", lambda max_pending=0: calls.append("setup"))
+        assert mode({"WORLD_SIZE": "8"}) == ("stamp", [])
+    finally:
+        monkeypatch.undo()
+        ktrace._reset_mode_for_tests()
+
+
+def test_tool_search_guard_keeps_rocprofiler_sdk_off_the_large_libraries():
+    """rocprofiler-sdk looks for tools by reading every library of the link map front to back (10.7 GB in a PyTorch
+    process: the start-up stall of rounds 1-3).  Registration through ``nvrx_ktrace_setup`` hides the large ones from that
+    one search: in a fresh interpreter with PyTorch loaded it must read well under 1 GB and take seconds (no GPU needed:
+    the search runs when the SDK is configured, before any device is touched)."""
+    code = r'''
+import os, sys, time
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd")]
+import torch
+os.environ["NVRX_GPU_TIMING"] = "kernels"
+def rchar():
+    return int(dict(l.split(": ") for l in open("/proc/self/io").read().strip().splitlines())["rchar"])
+a, t = rchar(), time.monotonic()
+from nvrx_straggler import ktrace
+mode = ktrace.timing_mode()
+lib = ktrace.load()
+print("RESULT", mode, int(lib.nvrx_ktrace_ready()), int(lib.nvrx_ktrace_hidden_libraries()), (rchar() - a) / 1e9, time.monotonic() - t)
+'''
+    env = dict(os.environ)
+    for k in ("NVRX_GPU_TIMING", "NVRX_KTRACE_FORCE", "NVRX_KTRACE_SCAN_GUARD", "ROCP_TOOL_LIBRARIES"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\n" + code], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    _, mode, ready, hidden, gb, secs = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    assert mode == "kernels" and int(ready) == 1
+    assert int(hidden) >= 5, hidden          # libtorch_*, the BLAS / solver / MIOpen libraries ...
+    assert float(gb) < 1.0, gb               # (10.7 GB without the guard)
+    assert float(secs) < 20.0, secs
