@@ -376,18 +376,32 @@ class _ScoreSource:
         v = self.view
         return _DeviceFlags(v.thresholds, self, v.ranks, v.names, v.cols, v.S, v.has_rel, v.has_indiv)
 
-    def build(self, field: str):
+    def build(self, field: str, stash: Optional[dict] = None):
+        """One of the six mappings as a plain dict.  ``stash``: the report's ``__dict__`` -- a call that can build a
+        sibling in the same pass (both section-score families share names, ranks and hashes) leaves it there."""
         self.ensure()
         v = self.view
         S = v.S
-        if field == "gpu_relative_perf_scores":
-            return dict(zip(v.ranks, self.scores[:, 1].tolist())) if v.has_rel else {}
-        if field == "gpu_individual_perf_scores":
-            return dict(zip(v.ranks, self.scores[:, 0].tolist())) if v.has_indiv else {}
-        if field == "section_relative_perf_scores":
-            return self._sections(2 + S) if (v.has_rel and v.names) else {}
-        if field == "section_individual_perf_scores":
-            return self._sections(2) if (v.has_indiv and v.names) else {}
+        sc = self.scores
+        fast = _pyread is not None and sc.dtype == np.float32 and sc.flags.c_contiguous
+        if field == "gpu_relative_perf_scores" or field == "gpu_individual_perf_scores":
+            col = 1 if field == "gpu_relative_perf_scores" else 0
+            if not (v.has_rel if col else v.has_indiv):
+                return {}
+            if fast:
+                return _pyread.ranks(v.rank_tuple(), sc, 0, sc.shape[0], sc.shape[1], col)
+            return dict(zip(v.ranks, sc[:, col].tolist()))
+        if field == "section_relative_perf_scores" or field == "section_individual_perf_scores":
+            rel = field == "section_relative_perf_scores"
+            if not ((v.has_rel if rel else v.has_indiv) and v.names):
+                return {}
+            other = "section_individual_perf_scores" if rel else "section_relative_perf_scores"
+            if fast and stash is not None and other not in stash and (v.has_indiv if rel else v.has_rel):
+                mine, sibling = _pyread.sections(v.names_tuple(), v.rank_tuple(), sc, 0, sc.shape[0], sc.shape[1],
+                                                 2 + S if rel else 2, v.col_tuple(), 2 if rel else 2 + S)
+                stash[other] = sibling
+                return mine
+            return self._sections(2 + S if rel else 2)
         if field == "local_section_summaries":
             return _summaries_from_rows(v.section_rows, self.statistics(), v.selector("section_rows")) if v.section_rows else {}
         if field == "local_kernel_summaries":
@@ -402,8 +416,7 @@ class _ScoreSource:
         sc = self.scores
         idx = v.col_index()
         if _pyread is not None and sc.dtype == np.float32 and sc.flags.c_contiguous:
-            return _pyread.sections(v.names_tuple(), v.rank_tuple(), sc, sc.shape[0], sc.shape[1], first_col,
-                                    None if idx is None else v.col_tuple())
+            return _pyread.sections(v.names_tuple(), v.rank_tuple(), sc, 0, sc.shape[0], sc.shape[1], first_col, v.col_tuple())
         block = sc[:, first_col : first_col + v.S].T
         if idx is not None:
             block = block[idx]
@@ -480,7 +493,8 @@ class Report:
         if name in _LAZY_FIELDS:
             src = self.__dict__.get("_src")
             if src is not None:
-                value = self.__dict__[name] = src.build(name)
+                d = self.__dict__
+                value = d[name] = src.build(name, d)
                 return value
         raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
 
