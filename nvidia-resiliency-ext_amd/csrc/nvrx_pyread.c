@@ -300,8 +300,11 @@ static PyObject *pyread_flagged(PyObject *self, PyObject *args) {
         /* a straggler usually stays one for many reports: the sets of an unchanged flag table are handed out as copies
          * (a set built from a set keeps the stored hashes, StragglerId.__hash__ is a Python function) */
         PyObject *key = PyList_GET_ITEM(memo, 0), *hit = PyList_GET_ITEM(memo, 1);
-        if (PyBytes_Check(key) && PyBytes_GET_SIZE(key) == n && PyTuple_Check(hit) && PyTuple_GET_SIZE(hit) == 5 &&
-            PyTuple_GET_ITEM(hit, 0) == ids_obj && memcmp(PyBytes_AS_STRING(key), f, (size_t)n) == 0) {
+        /* the hit belongs to one (ids, names, cols, families) combination: a memo list shared across views must miss */
+        if (PyBytes_Check(key) && PyBytes_GET_SIZE(key) == n && PyTuple_Check(hit) && PyTuple_GET_SIZE(hit) == 9 &&
+            PyTuple_GET_ITEM(hit, 0) == ids_obj && PyTuple_GET_ITEM(hit, 5) == names && PyTuple_GET_ITEM(hit, 6) == cols &&
+            PyTuple_GET_ITEM(hit, 7) == (has_rel ? Py_True : Py_False) && PyTuple_GET_ITEM(hit, 8) == (has_indiv ? Py_True : Py_False) &&
+            memcmp(PyBytes_AS_STRING(key), f, (size_t)n) == 0) {
             gr = PySet_New(PyTuple_GET_ITEM(hit, 1));
             gi = PySet_New(PyTuple_GET_ITEM(hit, 2));
             sr = copy_set_dict(PyTuple_GET_ITEM(hit, 3));
@@ -350,17 +353,22 @@ static PyObject *pyread_flagged(PyObject *self, PyObject *args) {
         if (memo != Py_None) {
             PyObject *key = PyBytes_FromStringAndSize((const char *)f, n);
             PyObject *c_gr = PySet_New(gr), *c_gi = PySet_New(gi), *c_sr = copy_set_dict(sr), *c_si = copy_set_dict(si);
-            PyObject *hit = (key && c_gr && c_gi && c_sr && c_si) ? PyTuple_Pack(5, ids_obj, c_gr, c_gi, c_sr, c_si) : NULL;
+            PyObject *hit = (key && c_gr && c_gi && c_sr && c_si)
+                                ? PyTuple_Pack(9, ids_obj, c_gr, c_gi, c_sr, c_si, names, cols, has_rel ? Py_True : Py_False,
+                                               has_indiv ? Py_True : Py_False)
+                                : NULL;
             Py_XDECREF(c_gr);
             Py_XDECREF(c_gi);
             Py_XDECREF(c_sr);
             Py_XDECREF(c_si);
-            if (!hit || PyList_SetItem(memo, 0, key) < 0) {  /* (SetItem steals key, also on failure) */
-                if (!hit) Py_XDECREF(key);
+            if (!key || !hit) {  /* both objects exist before either slot changes: the memo is never half updated */
+                Py_XDECREF(key);
                 Py_XDECREF(hit);
                 goto done;
             }
-            if (PyList_SetItem(memo, 1, hit) < 0) goto done;
+            /* (memo was checked to be a list of two: these cannot fail; SetItem steals the references) */
+            PyList_SetItem(memo, 0, key);
+            PyList_SetItem(memo, 1, hit);
         }
     }
     result = PyTuple_Pack(4, gr, gi, sr, si);

@@ -1886,6 +1886,10 @@ struct StageBuf {
     StagedSample *h_entries = nullptr;  // [stage_cap]
     hipEvent_t done = nullptr;
     bool in_flight = false;
+    // a re-homed report left the "scatter done" event out (its completion word releases the buffer): until it has, the
+    // buffer must not be handed to a concurrent pusher on the strength of a stale event
+    bool deferred = false;
+    hipStream_t deferred_stream = nullptr;
 };
 
 struct nvrx_ctx {
@@ -1955,6 +1959,7 @@ struct nvrx_ctx {
     };
     std::vector<OpenStamp> open_stamps;
     std::vector<hipStream_t> stamp_streams;  // user streams with stamp kernels the rings have not been ordered after
+    std::vector<hipStream_t> report_streams;  // every stream a report of this context launched its score kernel on (scratch ownership)
     hipEvent_t stamp_ev = nullptr;
     hipEvent_t order_ev = nullptr;  // nvrx_report: report stream ordered after the caller's stream
     // asynchronous reports: the statistics kernel of a report the host did not wait for may still be reading the
@@ -2046,10 +2051,13 @@ int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, in
                        ctx->meta_dirty ? ctx->h_kinds : nullptr, ctx->d_kinds,
                        ctx->meta_dirty ? ctx->h_gid : nullptr, ctx->d_gid);
     HIP_TRY(hipGetLastError());
-    if (deferred_buf && !ctx->meta_dirty)
+    if (deferred_buf && !ctx->meta_dirty) {
         *deferred_buf = ctx->cur;
-    else
+        b.deferred = true;
+        b.deferred_stream = stream;
+    } else {
         HIP_TRY(hipEventRecord(b.done, stream));
+    }
     b.in_flight = true;
     if (ctx->meta_dirty) {
         // h_kinds/h_gid are read by the kernel just launched: do not let the host modify them until
@@ -2063,6 +2071,13 @@ int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, in
     ctx->cur = (ctx->cur + 1) % nvrx_ctx::NBUF;
     StageBuf &nb = ctx->buf[ctx->cur];
     if (nb.in_flight) {
+        if (nb.deferred) {
+            // rotated all the way round onto the buffer of a re-homed report that has not completed yet (a concurrent
+            // pusher filled the other buffers meanwhile): nb.done belongs to an EARLIER flush, so give the buffer its
+            // event now, behind the scatter that still reads it
+            HIP_TRY(hipEventRecord(nb.done, nb.deferred_stream));
+            nb.deferred = false;
+        }
         HIP_TRY(hipEventSynchronize(nb.done));
         nb.in_flight = false;
     }
@@ -2365,6 +2380,18 @@ int nvrx_ctx_destroy(nvrx_ctx *ctx) {
     if (ctx->stamp_ev) (void)hipEventDestroy(ctx->stamp_ev);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     if (ctx->report_ev) (void)hipEventDestroy(ctx->report_ev);
+    {
+        // score scratch of the streams this context's reports ran on (its own, the resident scorer's, every user stream
+        // a report was re-homed onto): the device is idle, nothing reads it any more
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        ctx->report_streams.push_back(ctx->score_stream);
+        for (hipStream_t rs : ctx->report_streams) {
+            auto it = g_scratch_by_stream.find(reinterpret_cast<void *>(rs));
+            if (it == g_scratch_by_stream.end()) continue;
+            if (it->second.ptr) (void)hipFree(it->second.ptr);
+            g_scratch_by_stream.erase(it);
+        }
+    }
     if (ctx->score_stream) (void)hipStreamDestroy(ctx->score_stream);
     if (ctx->d_rowg) (void)hipFree(ctx->d_rowg);
     if (ctx->h_gather_err) (void)hipHostFree(ctx->h_gather_err);
@@ -2871,6 +2898,11 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     // Resident scorer: the score kernel goes to its own stream NEXT TO the statistics kernel and picks the rows' results
     // up as they are published (8-byte tagged granules), so neither kernel has a queued successor / predecessor.
     // Synchronous reports only, no exchange or the peer-window exchange (an RCCL all-gather needs the stream order).
+    if (d->R > 64) {  // (only large jobs keep score scratch per stream, score_launch)
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (std::find(ctx->report_streams.begin(), ctx->report_streams.end(), as_stream(stream)) == ctx->report_streams.end())
+            ctx->report_streams.push_back(as_stream(stream));
+    }
     const int rows_launch = (d->rows_active > 0 ? d->rows_active : ctx->rows_per_rank) * ctx->local_ranks;
     const bool peer_route = exchanging && d->allgather_fn == reinterpret_cast<void *>(&nvrx_peer_allgather) && peer_prologue_enabled();
     // When it pays (same-box A/B, r02k-m): the resident score kernel must not have to be ordered after other streams' work
@@ -2949,10 +2981,13 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         if (deferred_buf < 0) return;
         std::lock_guard<std::mutex> lk(ctx->mu);
         StageBuf &db = ctx->buf[deferred_buf];
-        if (done)
-            db.in_flight = false;
-        else
-            (void)hipEventRecord(db.done, as_stream(stream));
+        if (db.deferred) {  // (else a concurrent flush already gave the buffer its event and waited for it)
+            if (done)
+                db.in_flight = false;
+            else
+                (void)hipEventRecord(db.done, as_stream(stream));
+            db.deferred = false;
+        }
         deferred_buf = -1;
     };
     if (rc) {

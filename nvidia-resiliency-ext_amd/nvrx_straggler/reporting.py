@@ -52,8 +52,12 @@ def _load_pyread():
         for path in sorted(glob.glob(os.path.join(alt, "_nvrx_pyread*.so"))):
             spec = importlib.util.spec_from_file_location(f"{__package__}._nvrx_pyread", path)
             if spec is not None and spec.loader is not None:
-                mod = importlib.util.module_from_spec(spec)
-                spec.loader.exec_module(mod)
+                try:
+                    mod = importlib.util.module_from_spec(spec)
+                    spec.loader.exec_module(mod)
+                except (ImportError, OSError) as e:  # a stale / ABI-mismatched file there: the packaged module, or Python
+                    _LOG.warning("ignoring %s: %s", path, e)
+                    continue
                 return mod
     try:
         from . import _nvrx_pyread
@@ -120,7 +124,10 @@ def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray, selector=No
     vals = block[:, : NUM_COLUMN + 1].tolist()
     out = dict(zip(rows, map(dict, map(zip, itertools.repeat(STAT_KEYS), vals))))
     num = Statistic.NUM
-    for d, n in zip(out.values(), block[:, NUM_COLUMN].astype(np.int64).tolist()):
+    counts = block[:, NUM_COLUMN]
+    if not np.isfinite(counts).all():  # cannot come out of the statistics kernel; the C builder raises here too
+        raise ValueError("cannot convert a non-finite NUM statistic to an integer")
+    for d, n in zip(out.values(), counts.astype(np.int64).tolist()):
         d[num] = n
     return out
 
@@ -703,14 +710,24 @@ class ReportGenerator:
         # collective kernels wait for peers, so their duration says nothing about this GPU
         return {k: v for k, v in kernel_summaries.items() if not is_collective_kernel(k)}
 
+    def _shared_rank_to_node(self) -> Dict[int, str]:
+        """The mapping handed to reports: the generator's own plain dict (see ``_maybe_gather_rank_to_node``); a generator
+        whose mapping is still the initial defaultdict (nothing gathered yet) gets it converted once."""
+        r2n = self.rank_to_node
+        if type(r2n) is not dict:
+            r2n = self.rank_to_node = dict(r2n)
+        return r2n
+
     def _maybe_gather_rank_to_node(self) -> None:
         if self.rank_to_node:
             return
+        # a PLAIN dict from here on, replaced (never edited) when it changes: every report of this generator is handed this
+        # very object, and the per-plan caches of the straggler ids / flag decoder are keyed on its identity
         if self.gather_on_rank0:
             pairs = dist_utils.all_gather_object((self.rank, self.node_name), self.group)
             self.rank_to_node = dict(pairs)
         else:
-            self.rank_to_node[self.rank] = self.node_name
+            self.rank_to_node = {self.rank: self.node_name}
 
     def _update_local_min_times(self, kernel_summaries, section_summaries) -> None:
         for name, summ in kernel_summaries.items():
@@ -851,7 +868,7 @@ class ReportGenerator:
         src.scores = ws.scores[lo:hi].copy()
         src.flags = ws.flags[lo:hi].copy()
         src.stats = stats
-        report = Report._from_device(src, dict(self.rank_to_node), (time.perf_counter_ns() - t_start_ns) * 1e-6,
+        report = Report._from_device(src, self._shared_rank_to_node(), (time.perf_counter_ns() - t_start_ns) * 1e-6,
                                      self.gather_on_rank0, self.rank)
         if stats is None:
             # the caller's own summaries travel with the report, untouched
@@ -961,7 +978,7 @@ class ReportGenerator:
                     return None
                 return Report._from_device(
                     _ScoreSource(plan.view, pend),
-                    self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
+                    self._shared_rank_to_node(),
                     (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank)
         elif multi:
             rings.report_local(ws, True, rows_active=plan.rows_used)
@@ -994,7 +1011,7 @@ class ReportGenerator:
             pending = ws.host_block()
         return Report._from_device(
             _ScoreSource(plan.view, pending),
-            self.rank_to_node if type(self.rank_to_node) is dict else dict(self.rank_to_node),
+            self._shared_rank_to_node(),
             (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank)
 
     # ---- public: summaries given as dicts (reference signature) -------------------------------------

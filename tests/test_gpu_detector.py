@@ -336,7 +336,8 @@ def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
         ws_before = job.reporter._ring_plan.ws
         big = torch.randn(8192, 8192, device="cuda")
         monkeypatch.setenv("NVRX_REPORT_TIMEOUT_S", "0.02")
-        ws_before.desc_key = None  # the descriptor caches the timeout: make it pick the new one up
+        for blk in ws_before.blocks:  # every result block caches a descriptor (and the timeout in it): make both pick the new one up
+            blk.desc_key = None
         with torch.cuda.stream(be.stream):
             for _ in range(40):          # > 100 ms of work queued in front of the report
                 big = (big @ big) * 1e-4

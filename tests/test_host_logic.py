@@ -1083,3 +1083,46 @@ print("RESULT", mode, int(lib.nvrx_ktrace_ready()), int(lib.nvrx_ktrace_hidden_l
     assert int(hidden) >= 5, hidden          # libtorch_*, the BLAS / solver / MIOpen libraries ...
     assert float(gb) < 1.0, gb               # (10.7 GB without the guard)
     assert float(secs) < 20.0, secs
+
+
+def test_flag_memo_is_keyed_on_everything_the_answer_depends_on():
+    """``_nvrx_pyread.flagged`` answers an unchanged flag table from a memo; the memo must miss when the same bytes are
+    decoded for other families / names / column tables (a memo list shared across views would otherwise hand out the
+    wrong straggler sets)."""
+    from nvrx_straggler import reporting
+
+    pr = reporting._pyread
+    assert pr is not None
+    R, S = 4, 3
+    W = 2 + 2 * S
+    flags = np.zeros((R, W), dtype=np.uint8)
+    flags[2, :] = 1
+    buf = flags.tobytes()
+    ids = [reporting.StragglerId(rank=r, node="n") for r in range(R)]
+    names = ("a", "b", "c")
+    memo = [None, None]
+    both = pr.flagged(buf, 0, R, W, S, True, True, ids, names, None, memo)
+    assert both[1] == {ids[2]} and set(both[3]) == set(names)
+    again = pr.flagged(buf, 0, R, W, S, True, True, ids, names, None, memo)
+    assert again == both and again[2] is not both[2]            # a hit: equal, fresh copies
+    rel_only = pr.flagged(buf, 0, R, W, S, True, False, ids, names, None, memo)
+    assert rel_only[1] == set() and rel_only[3] == {}            # individual family off: must not come from the memo
+    assert rel_only[0] == {ids[2]} and set(rel_only[2]) == set(names)
+    other_names = ("x", "y", "z")
+    renamed = pr.flagged(buf, 0, R, W, S, True, True, ids, other_names, None, memo)
+    assert set(renamed[2]) == set(other_names)
+    permuted = pr.flagged(buf, 0, R, W, S, True, True, ids, other_names, (2, 1, 0), memo)
+    assert set(permuted[2]) == set(other_names)
+
+
+def test_python_summaries_builder_rejects_a_non_finite_count_like_the_c_builder(monkeypatch):
+    from nvrx_straggler import reporting
+
+    stats = np.ones((2, 8), dtype=np.float32)
+    stats[1, 5] = np.nan
+    rows = {"a": 0, "b": 1}
+    with pytest.raises((ValueError, OverflowError)):
+        reporting._summaries_from_rows(rows, stats)
+    monkeypatch.setattr(reporting, "_pyread", None)
+    with pytest.raises(ValueError):
+        reporting._summaries_from_rows(rows, stats)
