@@ -59,6 +59,10 @@ TOTAL_RANKS = 8
 SECTIONS = 64
 SAMPLES = 10_000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+# tools/port_vs_reference_timing.py, build container (the only place that has /root/reference), round 4: one rank x 64 sections
+# x 10 000 samples -- reference 37.12 ms (summaries 35.99 + generate_report 1.13), port 37.49 ms (37.22 + 0.27)
+PORT_VS_REFERENCE = {"ratio": 1.01, "reference_ms": 37.12, "port_ms": 37.49, "host": "build container, 8 cpus, 1 torch thread",
+                     "source": "tools/port_vs_reference_timing.py (round 4; 0.99 in round 3)"}
 
 
 def _cpu_baseline(reps: int):
@@ -130,6 +134,10 @@ def _cpu_baseline(reps: int):
         "all_gather_object_of_summaries_us": round(r["all_gather_object_us"], 1),
         "single_rank_no_collectives": single,
         "host_cpus": os.cpu_count(),
+        # the reference tree does not exist on the GPU box, so what is timed is the port; how far the port's timing is
+        # from the real reference's was measured where both exist (build container, same process, same inputs)
+        "port_vs_reference_ratio": PORT_VS_REFERENCE["ratio"],
+        "port_vs_reference": PORT_VS_REFERENCE,
     }
 
 
@@ -402,7 +410,20 @@ def _roof(kern_us, alg_bytes):
 def _n8_shape_leg(steps, warmup):
     """The per-GPU work of the 8-GPU production shape on this GPU: ONE logical rank, 64 rows x 10 000 samples (2.56 MB).
     Report latency without an exchange + the statistics kernel against the roofline at that shape."""
+    # which physical devices the ranks really run on: with --backend gloo several ranks may share one, and the line must
+    # not call that "N GPUs"
+    props = torch.cuda.get_device_properties(device_index)
+    ident = (os.uname().nodename, getattr(props, "pci_domain_id", -1), getattr(props, "pci_bus_id", -1),
+             getattr(props, "pci_device_id", device_index), str(getattr(props, "uuid", "")))
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    else:
+        idents = [ident]
+    distinct_devices = len(set(idents))
+
     import synth
+    from nvrx_straggler import ktrace as _ktrace
     from nvrx_straggler.folded import FoldedJob
 
     job = FoldedJob(total_ranks=1, section_names=[synth.section_name(s) for s in range(SECTIONS)], ring_cap=SAMPLES,
@@ -475,6 +496,45 @@ def _detector_leg(steps, warmup):
     finally:
         Detector.shutdown()
         CustomSection.max_elapseds_len = old_cap
+
+
+def _section_entry_leg(entries: int = 3000):
+    """Host cost of ONE ``Detector.detection_section`` entry (enter + exit, empty body), the figure BASELINE.md section 3
+    quotes for the reference at ~2.7 us (straggler.py:287-348: perf_counter_ns pair, deque append, CUPTI refcount):
+    ``profile_cuda=False`` (one staged host sample) and ``profile_cuda=True`` (two one-thread stamp kernels on the
+    caller's stream; their cost to that STREAM is in profiles/r04e_stamp_cost.txt: +3.5 us per entry behind a busy
+    kernel, against +7.9 us for a hipEventRecord pair)."""
+    from nvrx_straggler import Detector
+
+    Detector.initialize(scores_to_compute=["individual_perf_scores"], gather_on_rank0=False, node_name="node0")
+    try:
+        out = {}
+        for label, gpu in (("profile_cuda_false_us", False), ("profile_cuda_true_us", True)):
+            name = "entry_" + label
+            for _ in range(200):
+                with Detector.detection_section(name, profile_cuda=gpu):
+                    pass
+            torch.cuda.synchronize()
+            t = []
+            for _ in range(entries):
+                t0 = time.perf_counter_ns()
+                with Detector.detection_section(name, profile_cuda=gpu):
+                    pass
+                t.append(time.perf_counter_ns() - t0)
+                if gpu and len(t) % 256 == 0:
+                    torch.cuda.synchronize()  # keep the queue of stamp kernels short: this is the host's cost per entry
+            torch.cuda.synchronize()
+            out[label] = round(float(np.median(t)) / 1e3, 2)
+            out[label.replace("_us", "_p95_us")] = round(float(np.percentile(t, 95)) / 1e3, 2)
+            Detector.generate_report()
+        out["reference_python_us"] = 2.7
+        out["stream_us_per_gpu_timed_entry"] = 3.5
+        out["note"] = ("host time of one detection_section entry with an empty body, median of %d; reference_python_us = BASELINE.md "
+                       "section 3 (survey probe of the reference's Python path); stream_us_per_gpu_timed_entry = what the two "
+                       "stamp kernels add to a busy user stream (tools/micro/stamp_cost.cpp, profiles/r04e_stamp_cost.txt)" % entries)
+        return out
+    finally:
+        Detector.shutdown()
 
 
 def _side_leg(fn, *a, **k):
@@ -563,7 +623,20 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    # which physical devices the ranks really run on: with --backend gloo several ranks may share one, and the line must
+    # not call that "N GPUs"
+    props = torch.cuda.get_device_properties(device_index)
+    ident = (os.uname().nodename, getattr(props, "pci_domain_id", -1), getattr(props, "pci_bus_id", -1),
+             getattr(props, "pci_device_id", device_index), str(getattr(props, "uuid", "")))
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    else:
+        idents = [ident]
+    distinct_devices = len(set(idents))
+
     import synth
+    from nvrx_straggler import ktrace as _ktrace
     from nvrx_straggler.folded import FoldedJob
 
     job = FoldedJob(total_ranks=TOTAL_RANKS, section_names=[synth.section_name(s) for s in range(SECTIONS)],
@@ -687,14 +760,15 @@ def main():
             exchange = {"us_median": float(np.median(t_ex)) * 1e6,
                         "route": getattr(job.reporter._direct, "route", "torch.distributed"),
                         "selection": dict(job.reporter.exchange_info),
-                        "bytes_per_rank": int(ws.local_ranks * ws.L * 4)}
+                        "bytes_per_rank": int(ws.local_ranks * ws.L * 4),
+                        "ranks": world, "distinct_devices": distinct_devices}
         except Exception as e:  # noqa: BLE001  (deterministic on every rank: same state everywhere)
             exchange = {"error": str(e)[-200:]}
 
     # the same kernel with its rows coming from HBM: a 1 GiB sweep between reports evicts L2 and the Infinity Cache
     cold = None
     n8 = None
-    detector_leg = None
+    detector_leg = section_entry = None
     if world == 1 and not args.no_extra_legs:
         sweep = torch.zeros(1 << 28, dtype=torch.float32, device="cuda")
         cold_us, cold_n = _kernel_leg(job, min(args.steps, 30), SAMPLES, cold=True, sweep=sweep)
@@ -704,6 +778,7 @@ def main():
         cold["note"] = "1 GiB device sweep between reports: rows fetched from HBM, not from L2 / Infinity Cache"
         n8 = _side_leg(_n8_shape_leg, args.steps, args.warmup)
         detector_leg = _side_leg(_detector_leg, args.steps, args.warmup)
+        section_entry = _side_leg(_section_entry_leg)
 
     host_inputs = None
     if world == 1 and not args.no_host_inputs:
@@ -761,7 +836,8 @@ def main():
             "metric": "generate_report_latency_us",
             "value": round(us_per_report, 2),
             "unit": "us",
-            "n_gpus": world,
+            "n_gpus": distinct_devices,  # physical devices in use; == ranks on a node with one GPU per rank
+            "ranks": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(us_per_report / 1e3, 5),
@@ -773,11 +849,13 @@ def main():
             "config": {
                 "workload": f"{TOTAL_RANKS} ranks x {SECTIONS} sections x {SAMPLES} samples per report, ring capacity {SAMPLES}, "
                             "relative+individual scores, gather_on_rank0",
-                "logical_ranks_per_gpu": job.local_ranks,
+                "logical_ranks_per_gpu": job.local_ranks,  # per process (== per GPU unless ranks share a device)
+                "ranks_share_devices": distinct_devices < world,
                 "rows_per_gpu": job.local_ranks * SECTIONS,
                 "exchange": "none (single process)" if world == 1 else f"1 all-gather of {job.local_ranks}x{2 * SECTIONS + 1} f32 per rank ({getattr(job.reporter._direct, 'route', 'torch.distributed ' + args.backend)})",
                 "target_us": 50,
             },
+            "gpu_timing_mode": _ktrace.timing_mode(),  # how profile_cuda sections would be timed in these processes (kernels = the default of multi-rank jobs)
             "reports_per_s": round(1e6 / us_per_report, 1),
             "us_per_report_median": round(float(np.median(per_step)) / 1e3, 2),
             "us_per_report_p95": round(float(np.percentile(per_step, 95)) / 1e3, 2),
@@ -831,6 +909,8 @@ def main():
             out["roofline_n8_shape"] = n8
         if detector_leg is not None:
             out["detector_report"] = detector_leg
+        if section_entry is not None:
+            out["section_entry_us"] = section_entry
         if overhead is not None:
             out["per_step_overhead"] = overhead
         if overhead_async is not None:

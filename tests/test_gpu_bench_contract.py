@@ -44,8 +44,30 @@ def test_gpus_2_without_a_launcher_spawns_its_own_ranks():
     r, lines = _run(["--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2"] + FAST)
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["logical_ranks_per_gpu"] == 4 and d["config"]["rows_per_gpu"] == 256
-    assert d["exchange"]["bytes_per_rank"] == 4 * 129 * 4 and d["exchange"]["us_median"] > 0
+    import torch
+
+    # two ranks, and n_gpus says how many physical devices they really ran on (both on the one GPU of a 1-GPU box)
+    devices = min(2, torch.cuda.device_count())
+    assert d["ranks"] == 2 and d["n_gpus"] == devices and d["config"]["ranks_share_devices"] == (devices < 2)
+    assert d["config"]["logical_ranks_per_gpu"] == 4 and d["config"]["rows_per_gpu"] == 256
+    ex = d["exchange"]
+    assert ex["bytes_per_rank"] == 4 * 129 * 4 and ex["us_median"] > 0 and ex["ranks"] == 2 and ex["distinct_devices"] == devices
+    # which route the reports took and what the checked trial said: a gloo group has no RCCL communicator, so the rows
+    # travel through torch.distributed and the selection says so
+    assert "route" in ex and isinstance(ex["selection"], dict)
+    assert ex["route"] == "torch.distributed" or "ncclCommCount" in str(ex["selection"]) or "rccl_comm_ranks" in ex["selection"]
+    assert d["gpu_timing_mode"] in ("stamp", "kernels")
+
+
+@pytest.mark.gpu
+def test_one_rank_through_the_launcher_path_prints_the_same_line_shape_as_the_plain_run():
+    """`--gpus 1` is the single-process path whatever the backend flag says: same keys, same workload, no exchange leg."""
+    a, la = _run(["--gpus", "1", "--steps", "4", "--warmup", "1"] + FAST)
+    b, lb = _run(["--gpus", "1", "--backend", "gloo", "--steps", "4", "--warmup", "1"] + FAST)
+    assert a.returncode == 0 and b.returncode == 0 and len(la) == 1 and len(lb) == 1
+    da, db = json.loads(la[0]), json.loads(lb[0])
+    assert set(da) == set(db) and da["config"] == db["config"] and "exchange" not in da
+    assert da["n_gpus"] == db["n_gpus"] == 1 and da["ranks"] == 1 and da["gpu_timing_mode"] == "stamp"
 
 
 @pytest.mark.gpu
