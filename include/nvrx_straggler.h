@@ -258,6 +258,13 @@ typedef struct nvrx_peer nvrx_peer;
 int nvrx_peer_create(int device, int world, int rank, int max_floats_per_rank, nvrx_peer **out);
 int nvrx_peer_ipc_handle(nvrx_peer *peer, void *handle64 /* 64 bytes out */);
 int nvrx_peer_connect(nvrx_peer *peer, int peer_rank, const void *handle64);
+/* PCI bus id of the window's device ("0000:05:00.0"): the same string in every process, whatever HIP_VISIBLE_DEVICES. */
+int nvrx_peer_device_id(const nvrx_peer *peer, char *out, int len);
+/* Before nvrx_peer_connect: can this window's device store into the device named by peer_pci_bus_id?  0 yes (or the same
+ * device); 1 the peer's device is not visible to this process (nothing to check, the IPC mapping decides); negative with
+ * nvrx_last_error() saying why not (hipDeviceCanAccessPeer = 0).  The reference has no counterpart: its exchange is
+ * torch.distributed (reporting.py:281,397), whose transport NCCL picks. */
+int nvrx_peer_check_access(const nvrx_peer *peer, int peer_rank, const char *peer_pci_bus_id);
 /* timeout_s: how long the kernel polls for a late peer before it gives up (<= 0 keeps the default 1800 s). */
 int nvrx_peer_ready(nvrx_peer *peer, double timeout_s);
 /* ncclAllGather-compatible: (send, recv, floats per rank, dtype = 7 (f32), comm = the nvrx_peer, stream); returns 0

@@ -3099,6 +3099,37 @@ int nvrx_peer_ipc_handle(nvrx_peer *p, void *handle64) {
     return NVRX_OK;
 }
 
+int nvrx_peer_device_id(const nvrx_peer *p, char *out, int len) {
+    if (!p || !out || len < 16) return fail(NVRX_ERR_INVALID, "nvrx_peer_device_id: a buffer of at least 16 bytes is needed");
+    HIP_TRY(hipDeviceGetPCIBusId(out, len, p->device));
+    return NVRX_OK;
+}
+
+// Preconditions of a window on ANOTHER device, checked before anything is mapped: the peer's GPU (named by its PCI bus id,
+// which is the same in every process whatever HIP_VISIBLE_DEVICES says) must be reachable from this one with peer-to-peer
+// stores.  0: same device, or peer access is possible; 1: the peer's device is not visible to this process, nothing
+// could be checked (hipIpcOpenMemHandle decides); negative: the devices cannot reach each other -- with the reason.
+int nvrx_peer_check_access(const nvrx_peer *p, int peer_rank, const char *peer_pci_bus_id) {
+    if (!p || !peer_pci_bus_id) return fail(NVRX_ERR_INVALID, "null argument");
+    int peer_dev = -1;
+    if (hipDeviceGetByPCIBusId(&peer_dev, peer_pci_bus_id) != hipSuccess || peer_dev < 0) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    if (peer_dev == p->device) return NVRX_OK;
+    int can = 0;
+    hipError_t e = hipDeviceCanAccessPeer(&can, p->device, peer_dev);
+    if (e != hipSuccess)
+        return fail(NVRX_ERR_HIP, "hipDeviceCanAccessPeer(device %d -> device %d [%s], rank %d) failed: %s", p->device, peer_dev,
+                    peer_pci_bus_id, peer_rank, hipGetErrorString(e));
+    if (!can)
+        return fail(NVRX_ERR_STATE,
+                    "peer windows need peer-to-peer access between the GPUs of one node: device %d cannot access device %d [%s] "
+                    "(rank %d; hipDeviceCanAccessPeer = 0 -- no xGMI / PCIe P2P path, or it is disabled by IOMMU / ACS settings). "
+                    "Use NVRX_EXCHANGE=rccl.", p->device, peer_dev, peer_pci_bus_id, peer_rank);
+    return NVRX_OK;
+}
+
 int nvrx_peer_connect(nvrx_peer *p, int peer_rank, const void *handle64) {
     if (!p || !handle64) return fail(NVRX_ERR_INVALID, "null argument");
     if (peer_rank < 0 || peer_rank >= p->world) return fail(NVRX_ERR_INVALID, "peer rank %d out of range", peer_rank);
@@ -3107,7 +3138,15 @@ int nvrx_peer_connect(nvrx_peer *p, int peer_rank, const void *handle64) {
     hipIpcMemHandle_t h;
     memcpy(&h, handle64, sizeof(h));
     void *ptr = nullptr;
-    HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess || !ptr) {
+        (void)hipGetLastError();
+        return fail(NVRX_ERR_HIP,
+                    "hipIpcOpenMemHandle of rank %d's window failed on device %d: %s (the window is fine-grained device memory "
+                    "exported with hipIpcGetMemHandle; both processes need HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver "
+                    "only supports dmabuf IPC, and the two GPUs need a peer-to-peer path)", peer_rank, p->device,
+                    hipGetErrorString(e));
+    }
     p->mapped[(size_t)peer_rank] = static_cast<unsigned long long *>(ptr);
     p->opened[(size_t)peer_rank] = true;
     return NVRX_OK;

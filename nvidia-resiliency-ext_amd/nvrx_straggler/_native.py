@@ -78,6 +78,8 @@ SYMBOLS = [
     ("nvrx_peer_create", c_int, [c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     ("nvrx_peer_ipc_handle", c_int, [c_void_p, c_void_p]),
     ("nvrx_peer_connect", c_int, [c_void_p, c_int, c_void_p]),
+    ("nvrx_peer_device_id", c_int, [c_void_p, c_char_p, c_int]),
+    ("nvrx_peer_check_access", c_int, [c_void_p, c_int, c_char_p]),
     ("nvrx_peer_ready", c_int, [c_void_p, c_double]),
     ("nvrx_peer_allgather", c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
     ("nvrx_peer_allgather_address", c_void_p, []),

@@ -24,13 +24,17 @@ import socket
 import time
 from typing import Optional
 
+import logging
+
 import numpy as np
+
 import torch
 import torch.distributed as dist
 
 from . import _native
 
 _NCCL_FLOAT32 = 7
+_LOG = logging.getLogger(__name__)
 MAX_FLOATS_PER_RANK = 65536  # floats per rank a window slot holds: local_ranks * (2(K+S)+K+1); 8 MB of windows at 8 ranks
 
 
@@ -110,32 +114,46 @@ def create(group=None, device_index: Optional[int] = None, timeout_s: float = 18
     dev = torch.cuda.current_device() if device_index is None else int(device_index)
     peer = ctypes.c_void_p()
     handle = None
+    pci = b""
     ok = True
+    why = ""
     try:
         _native.check(lib.nvrx_peer_create(dev, world, rank, MAX_FLOATS_PER_RANK, ctypes.byref(peer)))
         buf = ctypes.create_string_buffer(64)
         _native.check(lib.nvrx_peer_ipc_handle(peer, buf))
         handle = buf.raw
-    except Exception:  # noqa: BLE001  (the decision below must stay collective)
-        ok = False
+        idbuf = ctypes.create_string_buffer(64)
+        _native.check(lib.nvrx_peer_device_id(peer, idbuf, 64))
+        pci = idbuf.value
+    except Exception as e:  # noqa: BLE001  (the decision below must stay collective)
+        ok, why = False, f"window set-up failed: {e}"
     # windows can only be shared inside one node
     infos = [None] * world
     try:
         device_id = str(torch.cuda.get_device_properties(dev).uuid)
     except Exception:  # noqa: BLE001
         device_id = f"index{dev}"
-    dist.all_gather_object(infos, (socket.gethostname(), handle if ok else None, device_id), group=group)
-    same_node = len({h for h, _, _ in infos}) == 1
-    shared_device = len({d for _, _, d in infos}) < world
-    ok = ok and same_node and all(hd is not None for _, hd, _ in infos)
+    dist.all_gather_object(infos, (socket.gethostname(), handle if ok else None, device_id, pci), group=group)
+    same_node = len({i[0] for i in infos}) == 1
+    shared_device = len({i[2] for i in infos}) < world
+    if ok and not same_node:
+        why = "the ranks of the group are on more than one node (windows are shared through HIP IPC)"
+    ok = ok and same_node and all(i[1] is not None for i in infos)
     if ok:
         try:
-            for r, (_, hd, _) in enumerate(infos):
+            # preconditions first, for every peer, before anything is mapped: a pair of GPUs without a peer-to-peer path
+            # is reported as what it is instead of as a failing (or, worse, hanging) exchange later
+            for r, info in enumerate(infos):
+                if r != rank and info[3]:
+                    _native.check(lib.nvrx_peer_check_access(peer, r, info[3]))
+            for r, info in enumerate(infos):
                 if r != rank:
-                    _native.check(lib.nvrx_peer_connect(peer, r, hd))
+                    _native.check(lib.nvrx_peer_connect(peer, r, info[1]))
             _native.check(lib.nvrx_peer_ready(peer, float(timeout_s)))
-        except Exception:  # noqa: BLE001
-            ok = False
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, str(e)
+    if why:
+        _LOG.warning("straggler report exchange: peer windows not available on rank %d: %s", rank, why)
     if not _all_ok(ok, group):  # one failure sends every rank back to the other route
         if peer.value:
             lib.nvrx_peer_destroy(peer)
@@ -149,11 +167,22 @@ def exchange_mode() -> str:
     return mode if mode in ("rccl", "peer", "auto") else "rccl"
 
 
+def trial_timeout_s() -> float:
+    """``NVRX_TRIAL_TIMEOUT_S`` (default 5): the longest ONE exchange of a route's trial may take before the route is
+    given up as not working on this machine."""
+    try:
+        v = float(os.environ.get("NVRX_TRIAL_TIMEOUT_S", "5"))
+    except ValueError:
+        v = 5.0
+    return v if v > 0 else 5.0
+
+
 def _trial(route, group, backend, reps: int = 30):
     """Time ``reps`` exchanges of a recognisable dummy row on ``route`` and check what arrived.  Collective.
-    Returns (median microseconds, table correct) for THIS rank.  Never raises: a rank that fails reports "not
+    Returns (median microseconds, table correct) for THIS rank.  Never raises and never waits past the trial timeout
+    for one exchange: a rank whose exchange fails, delivers a wrong table or does not complete in time reports "not
     correct", which the callers turn into the same decision on every rank (its peers' exchanges run into the
-    route's own bounded wait)."""
+    route's own bounded wait, or into this one)."""
     try:
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         n = 129
@@ -163,10 +192,17 @@ def _trial(route, group, backend, reps: int = 30):
         st = backend.stream_handle
         times = []
         check = getattr(route, "timed_out_epoch", None)
+        limit = trial_timeout_s()
+        done = torch.cuda.Event()
         for i in range(reps + 5):
             t0 = time.perf_counter()
             route.all_gather(send.data_ptr(), recv.data_ptr(), n, st)
-            backend.synchronize()
+            done.record(backend.stream)
+            while not done.query():  # (a spin: the exchange is a few microseconds when it works)
+                if time.perf_counter() - t0 > limit:
+                    # the exchange is stuck (a peer that never joined, a transport that does not move data): the work stays
+                    # queued on the detector's stream, the caller drops -- aborts -- the route
+                    return float("inf"), False
             if i >= 5:
                 times.append(time.perf_counter() - t0)
             if check is not None and check():
@@ -178,6 +214,15 @@ def _trial(route, group, backend, reps: int = 30):
         return float(np.median(times)) * 1e6, good
     except Exception:  # noqa: BLE001
         return float("inf"), False
+
+
+def _drop(route) -> None:
+    """Give a route up after a failed trial: ``abort`` where the route has one (an RCCL communicator whose all-gather may
+    still be waiting for a peer on the GPU is torn down with ncclCommAbort, not waited for), else ``close``."""
+    try:
+        getattr(route, "abort", route.close)()
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def choose(group, backend, rccl, peer, timeout_s: float = 1800.0):
@@ -204,7 +249,7 @@ def _choose(mode, info, group, backend, rccl, peer):
             us, good = _trial(rccl, group, backend)
             info["rccl_us"] = round(us, 2) if np.isfinite(us) else None
             if not _all_ok(good, group):
-                rccl.close()
+                _drop(rccl)
                 info["rccl_rejected"] = True
                 return None, info
         return rccl, info
@@ -215,8 +260,16 @@ def _choose(mode, info, group, backend, rccl, peer):
             if rccl is not None:
                 rccl.close()
             return peer, info
-        peer.close()
+        _drop(peer)
         info["peer_rejected"] = True
+        if rccl is not None:
+            # the fallback gets the same checked trial before any report depends on it
+            us, good = _trial(rccl, group, backend)
+            info["rccl_us"] = round(us, 2) if np.isfinite(us) else None
+            if not _all_ok(good, group):
+                _drop(rccl)
+                info["rccl_rejected"] = True
+                return None, info
         return rccl, info
     # auto: measure both, keep the faster one that was right everywhere
     r_us, r_good = _trial(rccl, group, backend)
@@ -228,7 +281,11 @@ def _choose(mode, info, group, backend, rccl, peer):
     info.update({"rccl_us": round(r_us, 2), "peer_us": round(p_us, 2), "rccl_ok": r_bad == 0.0, "peer_ok": p_bad == 0.0})
     use_peer = p_bad == 0.0 and (r_bad != 0.0 or p_us < r_us)
     if use_peer:
-        rccl.close()
+        (rccl.close if r_bad == 0.0 else lambda: _drop(rccl))()
         return peer, info
-    peer.close()
+    (peer.close if p_bad == 0.0 else lambda: _drop(peer))()
+    if r_bad != 0.0:  # neither route delivered the right table everywhere: the reports stay on torch.distributed
+        _drop(rccl)
+        info["rccl_rejected"] = info["peer_rejected"] = True
+        return None, info
     return rccl, info

@@ -52,6 +52,8 @@ def _load_rccl() -> Optional[ctypes.CDLL]:
             lib.ncclGetErrorString.restype = ctypes.c_char_p
             lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
             lib.ncclCommCount.restype = ctypes.c_int
+            lib.ncclCommAbort.argtypes = [ctypes.c_void_p]
+            lib.ncclCommAbort.restype = ctypes.c_int
         except AttributeError:
             continue
         return lib
@@ -99,6 +101,15 @@ class DirectAllGather:
         if self._comm is not None:
             try:
                 self._lib.ncclCommDestroy(self._comm)
+            finally:
+                self._comm = None
+
+    def abort(self) -> None:
+        """Tear the communicator down WITHOUT waiting for what is enqueued on it (``ncclCommAbort``): the way out when a
+        trial exchange did not complete -- ``ncclCommDestroy`` would wait for the all-gather that is waiting for a peer."""
+        if self._comm is not None:
+            try:
+                self._lib.ncclCommAbort(self._comm)
             finally:
                 self._comm = None
 

@@ -256,3 +256,26 @@ def test_ptl_callback_on_hip_backend_flags_the_slow_gpu():
         if m.startswith("rank ") and "GPU" in m:   # ROCm SMI line about a flagged reporting rank: not in the reference
             continue
         assert shape(m) in golden_shapes, (m, shape(m))
+
+
+@pytest.mark.parametrize("fault", ["error", "wrong_table", "never_completes"])
+def test_a_misbehaving_exchange_route_is_dropped_by_every_rank_together(fault):
+    """Route selection under injected failures, through the generic ``allgather_fn`` hook (the same slot ncclAllGather
+    fills on a multi-GPU node): an exchange function that fails, one that delivers a wrong table on ONE rank, one whose
+    work does not complete on ONE rank.  Every rank must land on torch.distributed together after the checked trial
+    (nobody waits past ``NVRX_TRIAL_TIMEOUT_S`` for one exchange), and the reports that follow must equal the
+    reference's (golden ``sections_2ranks_gather1`` / ``mixed_8ranks`` scenarios come from the real reference)."""
+    g = next(s for s in _SCENARIOS if s["scenario"]["name"] == "sections_2ranks_gather1")
+    sc = g["scenario"]
+    env = {"NVRX_EXCHANGE": "rccl", "NVRX_TRIAL_TIMEOUT_S": "1", "NVRX_PEER_TRIAL_TIMEOUT_S": "2", "NVRX_REPORT_TIMEOUT_S": "30"}
+    res = run_ranks(workers.route_fault_injection, sc["world_size"], timeout=300, use_oracle_backend=False, device=0, env=env,
+                    fault=fault, scenario=sc)
+    for r in range(sc["world_size"]):
+        out = res[r]
+        assert out["direct"] is False, (fault, r, out["info"])               # the route is gone on EVERY rank
+        assert out["info"].get("rccl_rejected") is True, (fault, r, out["info"])
+        assert out["state"]["calls"] >= 1                                      # it was tried ...
+        assert out["state"]["closed"] + out["state"]["aborted"] == 1           # ... and given up exactly once
+        assert out["first_report_s"] < 20.0, (fault, r, out["first_report_s"]) # nobody sat out a long wait
+        for t in range(len(sc["steps"])):
+            compare_reports(out["reports"][t], g["per_rank"][r]["reports"][t], (fault, r, t))

@@ -544,3 +544,94 @@ def ptl_callback_run(rank, world, slow_rank):
                 "sections": sorted(Detector.custom_sections)}
     finally:
         cb.teardown(trainer, module, "fit")
+
+
+def route_fault_injection(rank, world, fault, scenario):
+    """The in-stream exchange route of the reports replaced by one that misbehaves on the LAST rank only (``wrong_table``,
+    ``never_completes``) or on every rank (``error``), behind the generic ``allgather_fn`` hook of the report descriptor
+    (include/nvrx_straggler.h): a real working exchange (the peer windows of ranks sharing this GPU) wrapped in a ctypes
+    callback that corrupts the gathered table / parks seconds of work behind it / returns an error.  Every rank must drop
+    the route together after the checked trial, the reports must run on torch.distributed and be right."""
+    import ctypes
+    import os
+
+    import torch
+
+    from nvrx_straggler import backend as backend_mod
+    from nvrx_straggler import peer_exchange, rccl_direct
+    from nvrx_straggler.reporting import ReportGenerator
+
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemsetD32Async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    be = backend_mod.get_backend()
+    # how many spin cycles are a second on this box (the spin kernel's clock is not specified)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    torch.cuda._sleep(20_000_000)
+    torch.cuda.synchronize()
+    cycles_per_s = 20_000_000 / max(time.perf_counter() - t0, 1e-4)
+    state = {"calls": 0, "closed": 0, "aborted": 0}
+    last = rank == world - 1
+
+    class FaultyRoute:
+        route = f"fault-injected exchange ({fault})"
+
+        def __init__(self, inner):
+            self.inner = inner
+            proto = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                     ctypes.c_void_p)
+            self._cb = proto(self._entry)   # what nvrx_report would call between its two kernels
+            self.fn_address = ctypes.cast(self._cb, ctypes.c_void_p).value
+            self.comm_address = 0
+
+        def _entry(self, send, recv, count, dtype, comm, stream):
+            try:
+                self.all_gather(send, recv, count, stream)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 5
+
+        def all_gather(self, send_ptr, recv_ptr, count, stream_handle):
+            state["calls"] += 1
+            if fault == "error":
+                raise RuntimeError("injected: the exchange function fails")
+            self.inner.all_gather(send_ptr, recv_ptr, count, stream_handle)
+            if last and fault == "wrong_table":
+                hip.hipMemsetD32Async(recv_ptr, 0x42280000, count, stream_handle)   # 42.0f over rank 0's row of the table
+            if last and fault == "never_completes":
+                with torch.cuda.stream(be.stream):
+                    torch.cuda._sleep(int(2.5 * cycles_per_s))                        # far beyond the trial's patience
+
+        def exchange(self, ws, backend):
+            self.all_gather(ws.send_ptr, ws.table_ptr, ws.local_ranks * ws.L, backend.stream_handle)
+            return ws.table
+
+        def close(self):
+            state["closed"] += 1
+            self.inner.close()
+
+        def abort(self):
+            state["aborted"] += 1
+            self.inner.close()
+
+    def fake_create(group=None, device_index=None):
+        inner = peer_exchange.create(group, device_index, 1.5)
+        assert inner is not None, "the peer windows (the working exchange under the fault) did not come up"
+        return FaultyRoute(inner)
+
+    gen = ReportGenerator(scenario["scores_to_compute"], gather_on_rank0=scenario["gather_on_rank0"], node_name=f"node{rank}")
+    reports = []
+    t_first = None
+    with mock.patch.object(rccl_direct, "create", fake_create):
+        for i, step in enumerate(scenario["steps"]):
+            sec, ker = step[rank]
+            t0 = time.perf_counter()
+            rep = gen.generate_report(_summ(sec), _summ(ker))
+            if i == 0:
+                t_first = time.perf_counter() - t0
+            reports.append(report_to_plain(rep, scenario.get("thresholds", [0.75])))
+    info = dict(gen.exchange_info)
+    direct = gen._direct is not None
+    gen.close()
+    torch.cuda.synchronize()
+    return {"reports": reports, "info": info, "direct": direct, "state": state, "first_report_s": t_first}
