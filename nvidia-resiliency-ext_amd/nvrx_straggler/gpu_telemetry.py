@@ -98,6 +98,68 @@ def sample(device_index: int = 0) -> Dict[str, float]:
     return out
 
 
+# rsmi_dev_perf_level_t (rocm_smi.h:164-184)
+PERF_LEVEL_AUTO, PERF_LEVEL_LOW, PERF_LEVEL_HIGH, PERF_LEVEL_MANUAL = 0, 1, 2, 3
+PERF_LEVEL_STABLE_STD, PERF_LEVEL_STABLE_PEAK, PERF_LEVEL_STABLE_MIN_MCLK, PERF_LEVEL_STABLE_MIN_SCLK = 4, 5, 6, 7
+_RSMI_STATUS = {1: "invalid arguments", 2: "not supported by this device / driver", 3: "file error", 4: "permission denied (needs root and a "
+                "writable sysfs)", 5: "out of resources", 6: "internal exception", 7: "input out of bounds", 8: "initialisation error",
+                10: "busy", 0xFFFFFFFF: "refused by the driver (unknown error: read-only sysfs inside a container is the usual reason)"}
+
+
+class SmiRefused(RuntimeError):
+    """ROCm SMI would not change the device's performance state (no root, read-only sysfs, unsupported level)."""
+
+
+def perf_level(device_index: int = 0) -> int:
+    lib = _load()
+    lvl = ctypes.c_int(0)
+    lib.rsmi_dev_perf_level_get.argtypes = [ctypes.c_uint32, ctypes.POINTER(ctypes.c_int)]
+    rc = lib.rsmi_dev_perf_level_get(int(device_index), ctypes.byref(lvl))
+    if rc != 0:
+        raise SmiRefused(f"rsmi_dev_perf_level_get: {_RSMI_STATUS.get(rc & 0xFFFFFFFF, rc)}")
+    return int(lvl.value)
+
+
+def set_perf_level(device_index: int, level: int) -> None:
+    """``rsmi_dev_perf_level_set_v1``: the ROCm counterpart of ``nvidia-smi -lgc`` the reference's example suggests for
+    slowing one GPU down (examples/straggler/example.py:20).  ``PERF_LEVEL_LOW`` / ``PERF_LEVEL_STABLE_MIN_SCLK`` pin
+    the shader clock at its lowest level; ``PERF_LEVEL_AUTO`` gives the device back.  Raises ``SmiRefused`` when the
+    driver says no (it needs root and a writable sysfs: bare metal or a privileged container)."""
+    lib = _load()
+    lib.rsmi_dev_perf_level_set_v1.argtypes = [ctypes.c_uint32, ctypes.c_int]
+    rc = lib.rsmi_dev_perf_level_set_v1(int(device_index), int(level))
+    if rc != 0:
+        raise SmiRefused(f"rsmi_dev_perf_level_set_v1(device {device_index}, level {level}): {_RSMI_STATUS.get(rc & 0xFFFFFFFF, rc)}")
+
+
+class slowed_down:
+    """``with slowed_down(device):`` -- the device's shader clock held at its lowest level for the duration (tries the
+    levels that do that in turn), automatic level restored on exit.  ``SmiRefused`` if none is accepted."""
+
+    def __init__(self, device_index: int = 0):
+        self.device = int(device_index)
+        self.level = None
+
+    def __enter__(self):
+        last = None
+        for lvl in (PERF_LEVEL_LOW, PERF_LEVEL_STABLE_MIN_SCLK):
+            try:
+                set_perf_level(self.device, lvl)
+                self.level = lvl
+                return self
+            except SmiRefused as e:
+                last = e
+        raise last
+
+    def __exit__(self, *exc):
+        if self.level is not None:
+            try:
+                set_perf_level(self.device, PERF_LEVEL_AUTO)
+            except SmiRefused:
+                pass
+        return False
+
+
 def describe(device_index: int = 0) -> str:
     """One log-friendly line, or an explanation of why there is none."""
     try:

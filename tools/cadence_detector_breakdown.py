@@ -39,7 +39,10 @@ def work(n):
         y = torch.matmul(x, y)
 
 
-Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n")
+ASYNC = "--async" in sys.argv
+Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n", **({"asynchronous": True} if ASYNC else {}))
+if ASYNC:
+    wrap(Detector.reporter, "_settle_inflight", "reporter._settle_inflight (previous report)")
 wrap(Detector.cupti_manager, "harvest", "harvest")
 wrap(Detector.rings, "counts", "rings.counts")
 wrap(Detector.rings, "report_fused", "rings.report_fused (Python + C call)")
@@ -70,7 +73,8 @@ for cadence in (True, False):
         t0 = time.perf_counter_ns()
         rep = Detector.generate_report()
         t1 = time.perf_counter_ns()
-        rep.identify_stragglers()
+        if not ASYNC:
+            rep.identify_stragglers()
         t2 = time.perf_counter_ns()
         if dbg is not None:
             dbg(clk)
@@ -83,8 +87,8 @@ for cadence in (True, False):
             d["TOTAL generate_report"] = t1 - t0
             d["identify_stragglers"] = t2 - t1
             acc.append(d)
-    print("=== one report per 100 training steps (cold)" if cadence else "=== a report every step, tiny steps (warm)")
-    for k in ("TOTAL generate_report", "harvest", "rings.counts", "reporter.generate_report_from_rings", "rings.report_fused (Python + C call)",
+    print(("=== ASYNCHRONOUS " if ASYNC else "=== ") + ("one report per 100 training steps (cold)" if cadence else "a report every step, tiny steps (warm)"))
+    for k in ("TOTAL generate_report", "reporter._settle_inflight (previous report)", "harvest", "rings.counts", "reporter.generate_report_from_rings", "rings.report_fused (Python + C call)",
               "  nvrx_report (C)", "C: enter -> after event waits (order_after_stamps) + flush", "C: launch of k_row_stats",
               "C: launch of k_score1", "C: poll for the completion word", "rings.reset", "identify_stragglers"):
         v = [a.get(k, 0) for a in acc]
