@@ -134,16 +134,30 @@ def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray, selector=No
 
 class _PendingBlock:
     """Result block of a report the host has not waited for (asynchronous reports): the kernels are enqueued, the
-    pinned block fills in when they run.  ``wait()`` polls the completion word and takes the private copy; the
-    generator settles the block before the workspace is used again, a ``Report`` settles it on first read."""
+    pinned block fills in when they run.  ``complete()`` polls the completion word and leaves the data where it is;
+    ``wait()`` also takes the private copy -- when the report is first read, or (``detach``, called by the block) before
+    the block is written again, two reports later, if somebody still holds the report.  An asynchronous report that is
+    never read therefore costs its successor one poll of a word that has long been written, not a copy of the block: at
+    production cadence that copy ran cold and was half of what enqueueing the next report cost (47 of 95 us,
+    profiles/r04f_cadence_breakdown.txt)."""
 
-    __slots__ = ("backend", "ws", "blk", "seq", "blob", "lock")
+    __slots__ = ("backend", "ws", "blk", "seq", "blob", "lock", "__weakref__")
 
     def __init__(self, backend, ws, seq: int):
         self.backend, self.ws, self.seq = backend, ws, seq
         self.blk = getattr(ws, "block", None)  # the one of the workspace's result blocks this report was enqueued into
         self.blob: Optional[np.ndarray] = None
         self.lock = threading.Lock()
+        if self.blk is not None:
+            self.blk.attach(self)  # the block collects this report (if still held) before anything writes it again
+
+    def complete(self) -> int:
+        """Wait until the report has published its results; returns its ``names complete`` word (meta[0])."""
+        with self.lock:
+            if self.blob is None and self.blk is not None:
+                self.backend.wait_seq(self.ws, self.seq, block=self.blk)
+                return int(self.blk.meta[0])
+        return int(self.wait()[0:4].view(np.uint32)[0])
 
     def wait(self) -> np.ndarray:
         with self.lock:
@@ -156,6 +170,9 @@ class _PendingBlock:
                     self.blob = self.ws.host_block()
                 self.backend = self.ws = self.blk = None  # nothing of the live workspace is referenced any more
         return self.blob
+
+    def detach(self) -> None:
+        self.wait()
 
 
 _LIVE_LOCK = threading.Lock()  # a report may be read on another thread while the generator collects it
@@ -937,9 +954,9 @@ class ReportGenerator:
         if pend is None:
             return False
         self._inflight = None
-        blob = pend.wait()
+        names_word = pend.complete()  # a poll; the block is copied only if / when somebody reads or outlives it
         self._check_exchange()
-        return int(blob[0:4].view(np.uint32)[0]) != 1
+        return names_word != 1
 
     def _check_exchange(self) -> None:
         check = getattr(self._direct, "check", None)  # the peer-window route reports peers that never arrived
