@@ -355,7 +355,7 @@ def _kernel_source_sha() -> str:
 
 
 def _pmc_traffic(rows: int):
-    """HBM bytes per k_row_stats launch from the rocprofv3 PMC pass of tools/run_gpu_round.sh (separate run, --pmc
+    """HBM bytes per k_row_stats launch from the rocprofv3 PMC pass of tools/archive/run_gpu_round.sh (separate run, --pmc
     FETCH_SIZE with --kernel-trace only; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM).  The summary
     records the sha of the kernel source it was measured on: a summary of any other source is stale and reported as
     null rather than quoted."""
@@ -531,7 +531,7 @@ def _section_entry_leg(entries: int = 3000):
         out["stream_us_per_gpu_timed_entry"] = 3.5
         out["note"] = ("host time of one detection_section entry with an empty body, median of %d; reference_python_us = BASELINE.md "
                        "section 3 (survey probe of the reference's Python path); stream_us_per_gpu_timed_entry = what the two "
-                       "stamp kernels add to a busy user stream (tools/micro/stamp_cost.cpp, profiles/r04e_stamp_cost.txt)" % entries)
+                       "stamp kernels add to a busy user stream (tools/archive/micro/stamp_cost.cpp, profiles/r04e_stamp_cost.txt)" % entries)
         return out
     finally:
         Detector.shutdown()
@@ -671,7 +671,7 @@ def main():
     # pass of Python's cyclic collector (45-70 ms with torch imported) otherwise lands inside some leg by accident of
     # allocation counts and reads as +200 us per report.  It must not sit between the warm-up and the timed region: the
     # collection walks every object of the process and leaves the host's caches cold, and the first report after it
-    # took 85-110 us + 50 us for the read instead of 25 + 9 (tools/outlier_probe.py, profiles/r03a_outlier_probe.txt) --
+    # took 85-110 us + 50 us for the read instead of 25 + 9 (tools/archive/outlier_probe.py, profiles/r03a_outlier_probe.txt) --
     # that was the one ~175 us step of r02's 20-step driver run.  The collector stays enabled.
     gc.collect()
     gc.freeze()

@@ -89,7 +89,7 @@ State &st() {
 // ---- tool discovery guard ---------------------------------------------------------------------------------------
 // When rocprofiler-sdk initialises (rocprofiler_force_configure, or the HIP runtime handing over its API table) it looks
 // for tools by ELF-parsing EVERY shared library of the process' link map, and its parser reads each file front to back
-// (std::ifstream::read of the whole file; backtrace in tools/debug/readtrace.c / profiles/r04c_ktrace_start_up.txt):
+// (std::ifstream::read of the whole file; backtrace in tools/archive/debug/readtrace.c / profiles/r04c_ktrace_start_up.txt):
 // 10.7 GB of read() calls in a PyTorch process (libmagma 1.3 GB, MIOpen 0.95, rocsolver 0.76, libtorch_hip 0.42 ...).
 // From a warm page cache that is 3 s; where storage is cold it is minutes -- the "start-up stall" of rounds 1-3.  The
 // tool we want the SDK to find is handed over explicitly (rocprofiler_force_configure), so for the duration of that one

@@ -105,7 +105,7 @@ def setup(max_pending: int = 0) -> None:
     the process (``nvrx_ktrace.cpp``, "tool discovery guard").  What rounds 1-3 knew as the SDK's start-up stall is that
     search: the SDK ELF-parses EVERY loaded shared library for a ``rocprofiler_configure`` symbol and its parser reads
     each file front to back -- 10.7 GB of ``read()`` calls in a PyTorch process, 3 s from a warm page cache, 70 s in the
-    build container, 130-165 s on a GPU box with cold storage (``tools/debug/readtrace.c`` has the backtrace:
+    build container, 130-165 s on a GPU box with cold storage (``tools/archive/debug/readtrace.c`` has the backtrace:
     ``rocprofiler_set_api_table -> ... -> std::istream::read``).  Handing our tool over explicitly while the big libraries
     are hidden from that one search costs 0.1 GB of reads and 0.05 s (``profiles/r04c_ktrace_start_up.txt``).
 
