@@ -107,6 +107,31 @@ static Expect expect(const std::vector<float> &h, int rows, int n, int stride) {
     return e;
 }
 
+#ifdef NVRX_ORACLE_SPLIT
+// tools/experiments/oracle_split_patch.py: for every row the bin [base, base + 2^sh) that holds the lower median and at
+// most 48 samples, straight from the data (what a splitter-based selection would have to FIND)
+static void set_oracle(const std::vector<float> &h, int rows, int n, int stride) {
+    static std::vector<uint32_t> o(8192 * 2);
+    for (int r = 0; r < rows; r++) {
+        std::vector<uint32_t> k(n);
+        memcpy(k.data(), h.data() + (size_t)r * stride, (size_t)n * 4);   // non-negative floats: the bits order like the values
+        std::sort(k.begin(), k.end());
+        const uint32_t med = k[(n - 1) / 2];
+        uint32_t sh = 0, base = med;
+        for (uint32_t s2 = 1; s2 < 31; s2++) {
+            const uint32_t b = med & ~((1u << s2) - 1u);
+            const size_t cnt = std::lower_bound(k.begin(), k.end(), b + (1u << s2)) - std::lower_bound(k.begin(), k.end(), b);
+            if (cnt > 48) break;
+            sh = s2;
+            base = b;
+        }
+        o[(size_t)r * 2] = base;
+        o[(size_t)r * 2 + 1] = sh;
+    }
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_oracle), o.data(), (size_t)rows * 8));
+}
+#endif
+
 int main(int argc, char **argv) {
     const int rows = argc > 1 ? atoi(argv[1]) : 512;
     const int n = argc > 2 ? atoi(argv[2]) : 10000;
@@ -217,6 +242,9 @@ int main(int argc, char **argv) {
         for (int step = 0; step < 6; step++) {
             gen(h, rows, n, stride, dist, 1.0f);
             CK(hipMemcpy(d_s, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+#ifdef NVRX_ORACLE_SPLIT
+            set_oracle(h, rows, n, stride);
+#endif
             ms_seq[step] = launch();
             char what[64];
             snprintf(what, sizeof(what), "fresh draw %d (%.2f us)", step, ms_seq[step] * 1e3);
