@@ -27,7 +27,10 @@ def sub(text, old, new, count=1):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    s = open(SRC).read()
+    # the experiment is pinned to the kernel text it was measured against (the shipped kernel of rounds 2-3, before the range
+    # hint that came out of it was added)
+    s = subprocess.check_output(["git", "-C", REPO, "show", "c89d9f0:nvidia-resiliency-ext_amd/csrc/nvrx_straggler.hip"], text=True)
+    open(os.path.join(OUT, "src_ship_r03.hip"), "w").write(s)
     # the oracle: per launched row {first key of the median's bin, log2 of the bin width}
     s = sub(s, "template <int THREADS, int VPT>\n__global__ __launch_bounds__(THREADS) void k_row_stats(",
             "__device__ uint32_t g_oracle[8192][2];\n\ntemplate <int THREADS, int VPT>\n__global__ __launch_bounds__(THREADS) void k_row_stats(")
@@ -77,7 +80,8 @@ def main():
     hipcc = "/opt/rocm/bin/hipcc"
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{REPO}/include", "-Wno-unused-function", "-Wno-unused-value",
               "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
-    subprocess.check_call(common + [os.path.join(REPO, "tools", "kbench.cpp"), "-o", os.path.join(OUT, "kb_ship")])
+    subprocess.check_call(common + [f'-DNVRX_SRC="{OUT}/src_ship_r03.hip"', os.path.join(REPO, "tools", "kbench.cpp"), "-o", os.path.join(OUT, "kb_ship")])
+    subprocess.check_call(common + [os.path.join(REPO, "tools", "kbench.cpp"), "-o", os.path.join(OUT, "kb_head")])  # the tree's kernel (KB_HINT=1: with range hints)
     subprocess.check_call(common + ["-DNVRX_ORACLE_SPLIT", f'-DNVRX_SRC="{OUT}/src_oracle.hip"', os.path.join(REPO, "tools", "kbench.cpp"),
                                     "-o", os.path.join(OUT, "kb_oracle")])
     print("built", os.path.join(OUT, "kb_ship"), os.path.join(OUT, "kb_oracle"))

@@ -192,6 +192,15 @@ int main(int argc, char **argv) {
             ep.L = 129;
             ep.names_ok = 1.0f;
         }
+#ifdef NVRX_HAS_RANGE_HINT
+        // KB_HINT=1: the rows keep their range hints from launch to launch, as inside the report path
+        static uint32_t *d_hint = nullptr;
+        if (getenv("KB_HINT")) {
+            if (!d_hint) CK(hipMalloc(&d_hint, (size_t)rows * 8));
+            CK(hipMemset(d_hint, 0xFF, (size_t)rows * 8));
+            ep.hint = d_hint;
+        }
+#endif
         static hipStream_t kb_stream = nullptr;
         if (getenv("KB_STREAM") && !kb_stream) {
             if (atoi(getenv("KB_STREAM")) == 2) {
@@ -222,20 +231,22 @@ int main(int argc, char **argv) {
         int total_bad = 0;
         auto check = [&](const Expect &e, const char *what) {
             CK(hipMemcpy(st.data(), d_stats, st.size() * 4, hipMemcpyDeviceToHost));
-            int bad = 0, hits = 0, radix = 0, rebinned = 0;
+            int bad = 0, hits = 0, radix = 0, rebinned = 0, hinted_rows = 0, hint_misses = 0;
             double worst_avg = 0, worst_std = 0;
             for (int r = 0; r < rows; r++) {
                 const float *o = &st[(size_t)r * 8];
                 if (NVRX_ABLATE == 0 && o[2] != e.med[r]) bad++;
                 if (o[0] != e.mn[r] || o[1] != e.mx[r]) bad++;
-                hits += o[7] == 1.0f;  // estimate held, no refinement
+                hits += o[7] == 1.0f || o[7] == 33.0f;  // estimate (or range hint) held, no refinement
+                hinted_rows += o[7] == 33.0f;
+                hint_misses += o[7] == 66.0f;
                 radix += ((int)o[7] & 8) != 0;  // integer radix fallback
                 rebinned += ((int)o[7] & 6) != 0 && ((int)o[7] & 8) == 0;  // re-binned in the float domain, then ranked
                 worst_avg = std::max(worst_avg, fabs(o[3] - e.avg[r]) / fabs(e.avg[r]));
                 worst_std = std::max(worst_std, fabs(o[4] - e.sd[r]) / fabs(e.sd[r]));
             }
             total_bad += bad;
-            printf("  %-28s mismatches %d  fast path %d/%d rebinned %d radix %d  avg_err %.1e std_err %.1e\n", what, bad, hits, rows, rebinned, radix, worst_avg, worst_std);
+            printf("  %-28s mismatches %d  fast path %d/%d (hint held %d, missed %d) rebinned %d radix %d  avg_err %.1e std_err %.1e\n", what, bad, hits, rows, hinted_rows, hint_misses, rebinned, radix, worst_avg, worst_std);
         };
         // fresh draws of the same distribution: report 0 is cold, later ones should hit the window
         float ms_seq[6];
