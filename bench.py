@@ -189,25 +189,19 @@ def _per_step_overhead(world: int, rank: int, steps: int, blocks: int, asynchron
                 work()
 
         t_without, t_with, t_sections = [], [], []
-        for _ in range(blocks):
-            sync_all()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                work()
-            sync_all()
-            t_without.append((time.perf_counter() - t0) / steps)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step_with()
-            sync_all()
-            t_with.append((time.perf_counter() - t0) / steps)
-            if not asynchronous:
+        legs = [(t_without, work), (t_with, step_with)] + ([] if asynchronous else [(t_sections, step_sections_only)])
+        for blk in range(blocks):
+            # the legs take turns in a rotating order, so that a clock that ramps or a box that warms up over the run does
+            # not favour the leg that always comes last
+            for acc, fn in legs[blk % len(legs):] + legs[:blk % len(legs)]:
+                sync_all()
                 t0 = time.perf_counter()
                 for _ in range(steps):
-                    step_sections_only()
+                    fn()
                 sync_all()
-                t_sections.append((time.perf_counter() - t0) / steps)
-                Detector.generate_report()  # empties the rings between blocks (not timed)
+                acc.append((time.perf_counter() - t0) / steps)
+                if fn is step_sections_only:
+                    Detector.generate_report()  # empties the rings (not timed)
     finally:
         Detector.shutdown()
     a, b = float(np.median(t_without)), float(np.median(t_with))
@@ -613,7 +607,7 @@ def main():
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the PCIe-inclusive leg (samples handed over from host memory)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the N=8-shape, cold-cache and Detector-level legs")
     ap.add_argument("--overhead-steps", type=int, default=100)
-    ap.add_argument("--overhead-blocks", type=int, default=5)
+    ap.add_argument("--overhead-blocks", type=int, default=6)
     ap.add_argument("--no-cadence", action="store_true", help="skip the production-cadence leg (one report per 100 training steps)")
     ap.add_argument("--cadence-reports", type=int, default=30)
     ap.add_argument("--dump-steps", action="store_true", help="add the per-step latencies of the timed region to the JSON line")
