@@ -243,6 +243,10 @@ typedef struct nvrx_report_desc {
                                  report's statistics kernel */
 } nvrx_report_desc;
 int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *desc, void *stream);
+/* Diagnostics: host clocks of this thread's last nvrx_report, microseconds on the monotonic clock -- [0] entry, [1] stream
+ * ordering done, [2] staged samples flushed, [3] statistics kernel launched, [4] exchange enqueued, [5] score kernel
+ * launched, [6] completion word seen (synchronous reports), [7] spare.  No counterpart in the reference. */
+int nvrx_report_clocks(double *out8);
 /* sizeof(nvrx_report_desc) as this library was compiled: lets an FFI binding check its own struct layout. */
 int nvrx_report_desc_size(void);
 /* ------------------------------------------------------------------------------------------------

@@ -58,6 +58,15 @@ int fail(int code, const char *fmt, ...) {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Host clocks of the last nvrx_report of this thread (microseconds on the monotonic clock): a handful of reads per report,
+// kept on so that a report at production cadence can be taken apart where it runs (nvrx_report_clocks; tools/
+// cadence_detector_breakdown.py).  [0] entry, [1] stream ordering decided / events enqueued, [2] staged samples flushed,
+// [3] statistics kernel launched, [4] exchange enqueued, [5] score kernel launched, [6] completion word seen, [7] spare.
+thread_local double g_report_clk[8];
+inline void report_clk(int i) {
+    g_report_clk[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
@@ -2790,6 +2799,7 @@ static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K
     int uniform_n = -1;
     rc = flush_locked(ctx, st, &uniform_n, rows_active, deferred_buf);
     if (rc) return rc;
+    report_clk(2);
     Epilogue ep{};
     ep.gid = ctx->d_gid;
     // history minima only advance on a real report (d_send given), not on a statistics peek
@@ -2815,6 +2825,7 @@ static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K
                           d_stats, ep, st, ev_start, ev_stop, uniform_n);
     if (rc) return rc;
     if (pair >= 0) ctx->timing_used.push_back(pair);
+    report_clk(3);
     return NVRX_OK;
 }
 
@@ -2856,7 +2867,14 @@ static int peer_fill_args(nvrx_peer *p, const void *send, void *recv, size_t cou
 // ------------------------------------------------------------------------------------------------
 // report (everything, one call)
 // ------------------------------------------------------------------------------------------------
+int nvrx_report_clocks(double *out8) {
+    if (!out8) return fail(NVRX_ERR_INVALID, "null argument");
+    memcpy(out8, g_report_clk, sizeof(g_report_clk));
+    return NVRX_OK;
+}
+
 int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
+    report_clk(0);
     if (!ctx || !d) return fail(NVRX_ERR_INVALID, "null argument");
     if (!d->d_stats || !d->d_send || !d->d_scores || !d->d_meta) return fail(NVRX_ERR_INVALID, "null buffer in the report descriptor");
     const bool exchanging = d->allgather_fn != nullptr;
@@ -2895,6 +2913,7 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         HIP_TRY(hipEventRecord(ctx->order_ev, as_stream(d->order_after_stream)));
         HIP_TRY(hipStreamWaitEvent(as_stream(stream), ctx->order_ev, 0));
     }
+    report_clk(1);
     // Resident scorer: the score kernel goes to its own stream NEXT TO the statistics kernel and picks the rows' results
     // up as they are published (8-byte tagged granules), so neither kernel has a queued successor / predecessor.
     // Synchronous reports only, no exchange or the peer-window exchange (an RCCL all-gather needs the stream order).
@@ -2961,7 +2980,10 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
                            d->d_scores, d->d_flags, d->d_meta, d->d_done_counter, d->seq, nullptr, nullptr, 0,
                            ctx->score_stream, peer_route ? &pa : nullptr, &ga);
         if (rc2) return rc2;
+        report_clk(4);
+        report_clk(5);
         rc2 = nvrx_poll_u32(d->h_seq_word, d->seq, d->timeout_s > 0.0 ? d->timeout_s : 1e30);
+        report_clk(6);
         if (rc2) return rc2;
         if (*static_cast<volatile uint32_t *>(ctx->h_gather_err) == ctx->gran_epoch)
             return fail(NVRX_ERR_TIMEOUT, "the score kernel gave up waiting for the statistics kernel's rows (epoch %u)", ctx->gran_epoch);
@@ -3021,6 +3043,7 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
             return fail(NVRX_ERR_HIP, "all-gather of the exchange rows failed (ncclResult %d)", nrc);
         }
     }
+    report_clk(4);
     d->seq = (d->seq % 0x7FFFFFFFu) + 1u;
     rc = score_launch(exchanging ? d->d_table : d->d_send, d->R, d->K, d->S, d->do_indiv, d->do_rel, d->thresholds,
                       d->d_scores, d->d_flags, d->d_meta, d->d_done_counter, d->seq, d->d_stats, d->d_stats_dst,
@@ -3029,8 +3052,10 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         settle_deferred(false);
         return rc;
     }
+    report_clk(5);
     if (d->h_seq_word) {
         rc = nvrx_poll_u32(d->h_seq_word, d->seq, d->timeout_s > 0.0 ? d->timeout_s : 1e30);
+        report_clk(6);
         settle_deferred(rc == NVRX_OK);
         if (rc == NVRX_OK && !rehomed && as_stream(stream) == ctx->default_stream) {
             // the completion word was stored by the last kernel of this report on the context's own in-order stream:

@@ -74,6 +74,7 @@ SYMBOLS = [
     ("nvrx_stamp_end", c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
     ("nvrx_report_local", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("nvrx_report", c_int, [c_void_p, POINTER(ReportDesc), c_void_p]),
+    ("nvrx_report_clocks", c_int, [POINTER(c_double)]),
     ("nvrx_report_desc_size", c_int, []),
     ("nvrx_peer_create", c_int, [c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     ("nvrx_peer_ipc_handle", c_int, [c_void_p, c_void_p]),

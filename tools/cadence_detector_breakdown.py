@@ -51,8 +51,6 @@ wrap(Detector.rings, "reset", "rings.reset")
 wrap(Detector.reporter, "generate_report_from_rings", "reporter.generate_report_from_rings")
 import ctypes  # noqa: E402
 
-dbg = getattr(ctypes.CDLL(os.path.join(os.environ["NVRX_LIB_DIR"], "libnvrx_straggler_hip.so")), "nvrx_debug_clocks", None) \
-    if os.environ.get("NVRX_LIB_DIR") else None
 clk = (ctypes.c_double * 8)()
 rows = []
 for cadence in (True, False):
@@ -76,12 +74,13 @@ for cadence in (True, False):
         if not ASYNC:
             rep.identify_stragglers()
         t2 = time.perf_counter_ns()
-        if dbg is not None:
-            dbg(clk)
-            marks["C: enter -> after event waits (order_after_stamps) + flush"] = int((clk[5] - clk[0]) * 1e3)
-            marks["C: launch of k_row_stats"] = int((clk[2] - clk[5]) * 1e3)
-            marks["C: launch of k_score1"] = int((clk[3] - clk[2]) * 1e3)
-            marks["C: poll for the completion word"] = int((clk[4] - clk[3]) * 1e3)
+        Detector.rings.lib.nvrx_report_clocks(clk)
+        marks["C: entry -> stream ordering done (event record / wait pairs)"] = int((clk[1] - clk[0]) * 1e3)
+        marks["C: -> staged samples flushed (k_scatter launch)"] = int((clk[2] - clk[1]) * 1e3)
+        marks["C: -> k_row_stats launched"] = int((clk[3] - clk[2]) * 1e3)
+        marks["C: -> score kernel launched"] = int((clk[5] - clk[3]) * 1e3)
+        if not ASYNC:
+            marks["C: -> completion word seen (poll)"] = int((clk[6] - clk[5]) * 1e3)
         if i >= 4:
             d = dict(marks)
             d["TOTAL generate_report"] = t1 - t0
@@ -89,8 +88,9 @@ for cadence in (True, False):
             acc.append(d)
     print(("=== ASYNCHRONOUS " if ASYNC else "=== ") + ("one report per 100 training steps (cold)" if cadence else "a report every step, tiny steps (warm)"))
     for k in ("TOTAL generate_report", "reporter._settle_inflight (previous report)", "harvest", "rings.counts", "reporter.generate_report_from_rings", "rings.report_fused (Python + C call)",
-              "  nvrx_report (C)", "C: enter -> after event waits (order_after_stamps) + flush", "C: launch of k_row_stats",
-              "C: launch of k_score1", "C: poll for the completion word", "rings.reset", "identify_stragglers"):
+              "  nvrx_report (C)", "C: entry -> stream ordering done (event record / wait pairs)",
+              "C: -> staged samples flushed (k_scatter launch)", "C: -> k_row_stats launched", "C: -> score kernel launched",
+              "C: -> completion word seen (poll)", "rings.reset", "identify_stragglers"):
         v = [a.get(k, 0) for a in acc]
         print(f"  {k:44s} median {np.median(v)/1e3:7.1f} us   p95 {np.percentile(v,95)/1e3:7.1f}")
 Detector.shutdown()
