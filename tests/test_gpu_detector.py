@@ -397,3 +397,49 @@ def test_resident_scorer_never_reads_a_stale_row(monkeypatch):
             assert st[Statistic.NUM] == n and st[Statistic.MED] == med32[0, i % S], (i, n, st)
     finally:
         job.close()
+
+
+def test_asynchronous_reports_read_late_or_never_keep_their_own_values():
+    """An asynchronous report nobody reads is not copied when the next one is enqueued (a poll of its completion word);
+    its result block is written again two reports later, and a report that is STILL HELD then must have been copied out
+    by the block first.  Sixty reports over rows whose medians change every report: every third one is held and read five
+    reports late (its block has been rewritten twice by then), every fourth is read at once, the rest never -- every value
+    read must be the one of ITS report."""
+    from nvrx_straggler import Statistic
+    from nvrx_straggler.folded import FoldedJob
+
+    names = [synth.section_name(s) for s in range(4)]
+    job = FoldedJob(total_ranks=2, section_names=names, ring_cap=256, node_name="n")
+    job.reporter.asynchronous = True
+    rng = np.random.default_rng(11)
+    base = [rng.uniform(5.0, 6.0, (4, 200)).astype(np.float32) for _ in range(2)]
+
+    def expected(t):
+        x = base[0] * np.float32(1.0 + 0.25 * t)
+        return [float(np.sort(x[s])[(200 - 1) // 2]) for s in range(4)]
+
+    held = {}
+    checked = 0
+    try:
+        for t in range(60):
+            for r in range(2):
+                job.load(r, base[r] * np.float32(1.0 + 0.25 * t))
+            rep = job.report()
+            assert rep is not None
+            if t % 3 == 0:
+                held[t] = rep
+            elif t % 4 == 0:
+                got = [rep.local_section_summaries[n][Statistic.MED] for n in names]
+                assert got == expected(t), (t, got)
+                checked += 1
+            for u in [u for u in held if t - u >= 5]:
+                late = held.pop(u)
+                got = [late.local_section_summaries[n][Statistic.MED] for n in names]
+                assert got == expected(u), (u, t, got, expected(u))
+                # scores of a two-rank job with different data per rank: rank 0's relative score is med0/min(med0, med1) <= 1
+                assert set(late.section_relative_perf_scores[names[0]]) == {0, 1}
+                assert late.identify_stragglers()["straggler_gpus_relative"] == set()
+                checked += 1
+        assert checked >= 25
+    finally:
+        job.close()
