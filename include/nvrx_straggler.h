@@ -237,7 +237,9 @@ typedef struct nvrx_report_desc {
                                  stream order); used for synchronous reports without an exchange or with the peer-window
                                  exchange that have no other stream's work to wait for (NVRX_RESIDENT_SCORER=0|1|2: never /
                                  that rule / always).  The statistics rows then land under their own completion word d_meta[5]. */
-    int32_t reserved;
+    int32_t prev_settled;     /* nonzero: the caller has seen this context's previous asynchronous report complete (it polled
+                                 that report's completion word): ring writers need not wait for it any more, and an
+                                 asynchronous report that comes rarely enough may be enqueued on the one stream it follows */
     int32_t guard_rings;      /* asynchronous reports (h_seq_word == NULL, the caller polls later): nonzero makes later
                                  device-side ring writers on other streams (nvrx_stamp_end) wait, on the device, for this
                                  report's statistics kernel */

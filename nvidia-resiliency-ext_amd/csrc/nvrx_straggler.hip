@@ -1023,11 +1023,15 @@ struct StagedSample {
     float value;
 };
 
+// Completion ticket: the launch's last workgroup stores `ticket` into `done_word` (pinned host memory) -- the host knows
+// from that word alone that the pinned staging buffers have been read and may be filled again, so a flush records no
+// event (a cold hipEventRecord was ~20 us of a report at production cadence, profiles/r04q).
 __global__ void k_scatter(const uint32_t *__restrict__ h_counts, const StagedSample *__restrict__ h_entries,
                           int n_entries, float *__restrict__ samples, int row_stride,
                           uint32_t *__restrict__ d_counts, int rows, const uint8_t *__restrict__ h_kinds,
                           uint8_t *__restrict__ d_kinds, const int32_t *__restrict__ h_gid,
-                          int32_t *__restrict__ d_gid) {
+                          int32_t *__restrict__ d_gid, uint32_t *__restrict__ done_cnt, uint32_t *done_word,
+                          uint32_t ticket) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_entries) {
         const StagedSample e = h_entries[i];
@@ -1038,6 +1042,16 @@ __global__ void k_scatter(const uint32_t *__restrict__ h_counts, const StagedSam
         if (h_kinds) {
             d_kinds[i] = h_kinds[i];
             d_gid[i] = h_gid[i];
+        }
+    }
+    if (done_word) {
+        __syncthreads();  // every load of this workgroup from the staging buffers has returned (its value was stored)
+        if (threadIdx.x == 0) {
+            const uint32_t arrived = __hip_atomic_fetch_add(done_cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrived == gridDim.x - 1u) {
+                __hip_atomic_store(done_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the buffer's next launch comes after the host saw the ticket
+                __hip_atomic_store(done_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -1893,12 +1907,13 @@ struct EventPair {
 struct StageBuf {
     uint32_t *h_counts = nullptr;     // [rows]
     StagedSample *h_entries = nullptr;  // [stage_cap]
-    hipEvent_t done = nullptr;
+    // released by the scatter's completion ticket (k_scatter): *h_done == ticket once the launch that read this buffer is
+    // through -- no event is recorded for a flush, whatever stream it ran on
+    volatile uint32_t *h_done = nullptr;  // pinned word
+    uint32_t *d_done = nullptr;           // ... as the kernel addresses it
+    uint32_t *d_cnt = nullptr;            // device word: workgroups of the launch that have finished
+    uint32_t ticket = 0;
     bool in_flight = false;
-    // a re-homed report left the "scatter done" event out (its completion word releases the buffer): until it has, the
-    // buffer must not be handed to a concurrent pusher on the strength of a stale event
-    bool deferred = false;
-    hipStream_t deferred_stream = nullptr;
 };
 
 struct nvrx_ctx {
@@ -1953,8 +1968,11 @@ struct nvrx_ctx {
     // bulk appends (nvrx_ring_push_pairs): a pinned entry buffer of its own, grown on demand
     StagedSample *h_bulk = nullptr;
     size_t bulk_cap = 0;
-    hipEvent_t bulk_done = nullptr;
+    volatile uint32_t *bulk_word = nullptr;  // the ticket word / value that releases h_bulk (see StageBuf)
+    uint32_t bulk_ticket = 0;
     bool bulk_in_flight = false;
+    uint32_t *h_stage_done = nullptr, *d_stage_done = nullptr;  // pinned [NBUF] ticket words (host / device address)
+    uint32_t *d_stage_cnt = nullptr;                            // device [NBUF] arrival counters of the scatters
     std::vector<uint32_t> bulk_cnt, bulk_seen;
 
     // device-side region timing (k_stamp_begin / k_stamp_end)
@@ -1986,8 +2004,23 @@ struct nvrx_ctx {
     // forced by a full buffer, device-side appends, bulk appends, history resets, asynchronous reports); cleared when
     // a synchronous report on the context's own stream has completed
     bool side_work = true;
+    // Side work is counted.  An asynchronous report on the context's own stream remembers the count it was enqueued behind;
+    // when the caller tells the next report that it has SEEN that report complete (desc.prev_settled), everything up to
+    // that count is known to be done -- the way a job that only ever reports asynchronously gets to re-home.
+    uint64_t reports_rehomed = 0;
+    int last_rehome_verdict = 0;  // 1 re-homed; 0 not a candidate (mode / cadence); -1 streams; -2 side work; -3 async in flight; -4 timing
+    uint64_t side_gen = 1, async_gen = 0;
+    bool async_on_ctx = false;            // an asynchronous report may still be running on the context's own stream
+    double last_report_us = 0.0;          // monotonic clock of the previous nvrx_report's entry
+    double async_rehome_gap_us = 5000.0;  // NVRX_ASYNC_REHOME_GAP_US: asynchronous reports at least this far apart are re-homed (0 = never)
     hipEvent_t report_ev = nullptr;
     uint64_t report_epoch = 0;  // bumped by every guarded report
+    // the stream the last guarded (asynchronous) report's statistics kernel runs on; whether report_ev has been recorded
+    // behind it yet (a re-homed report records it only if a ring writer on ANOTHER stream turns up); and the epoch up to
+    // which the caller has seen the guarded reports complete (nothing has to wait for those any more)
+    hipStream_t guard_stream = nullptr;
+    bool guard_recorded = true;
+    uint64_t guard_done_epoch = 0;
     struct StreamEpoch {
         hipStream_t stream;
         uint64_t epoch;
@@ -2001,6 +2034,38 @@ namespace {
 
 int ctx_set_device(const nvrx_ctx *ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
+    return NVRX_OK;
+}
+
+inline void mark_side_work(nvrx_ctx *ctx) {
+    ctx->side_work = true;
+    ctx->side_gen++;
+}
+
+// A device-side ring writer on stream `st` (a stamp kernel, a scatter, a device append) must not overtake the statistics
+// kernel of an asynchronous report that may still be reading the rings.  Nothing to do when the caller has seen that
+// report complete, or when the writer is on the very stream the report runs on (stream order); else the writer's stream
+// waits, on the device, for report_ev -- which a re-homed report records only now, behind whatever its stream has
+// been given since (conservative, and rare: it takes a writer on a second stream).
+int guard_ring_writer(nvrx_ctx *ctx, hipStream_t st) {
+    if (!ctx->report_epoch) return NVRX_OK;
+    nvrx_ctx::StreamEpoch *se = nullptr;
+    for (auto &e : ctx->stream_epochs)
+        if (e.stream == st) se = &e;
+    if (!se) {
+        ctx->stream_epochs.push_back({st, 0});
+        se = &ctx->stream_epochs.back();
+    }
+    if (se->epoch < ctx->report_epoch) {
+        if (ctx->guard_done_epoch < ctx->report_epoch && st != ctx->guard_stream) {
+            if (!ctx->guard_recorded) {
+                HIP_TRY(hipEventRecord(ctx->report_ev, ctx->guard_stream));
+                ctx->guard_recorded = true;
+            }
+            HIP_TRY(hipStreamWaitEvent(st, ctx->report_ev, 0));
+        }
+        se->epoch = ctx->report_epoch;
+    }
     return NVRX_OK;
 }
 
@@ -2024,10 +2089,17 @@ int order_after_stamps(nvrx_ctx *ctx, hipStream_t stream, hipStream_t also = nul
 // `rows_active` rows per rank about to be launched holds the same number of samples, that number is
 // returned through it and NOTHING is launched -- k_row_stats takes it as a kernel argument instead of
 // reading d_counts (which stays marked dirty until a later flush uploads it).
-// `deferred_buf` (optional, re-homed synchronous reports only): the staging buffer's "scatter done" event is NOT recorded;
-// the buffer's index is returned instead and the caller releases it when the report's own completion word has arrived
-// (the scatter runs in front of it on the same stream).
-int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, int rows_active = 0, int *deferred_buf = nullptr) {
+// A staging buffer is free again when the scatter that read it has stored its ticket (k_scatter): usually long ago; else
+// the host spins on the pinned word (cold paths only: new row metadata, or a pusher a whole rotation ahead of the GPU).
+int wait_stage_buffer(StageBuf &b) {
+    if (!b.in_flight) return NVRX_OK;
+    int rc = nvrx_poll_u32(const_cast<const uint32_t *>(b.h_done), b.ticket, 1800.0);
+    if (rc) return rc;
+    b.in_flight = false;
+    return NVRX_OK;
+}
+
+int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, int rows_active = 0) {
     if (uniform_n) *uniform_n = -1;
     if (!ctx->stamp_streams.empty()) {
         int rc = order_after_stamps(ctx, stream);
@@ -2049,55 +2121,41 @@ int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, in
             return NVRX_OK;
         }
     }
+    {
+        int grc = guard_ring_writer(ctx, stream);  // the scatter writes ring slots
+        if (grc) return grc;
+    }
     StageBuf &b = ctx->buf[ctx->cur];
     for (int r = 0; r < ctx->rows; r++)
         b.h_counts[r] = (uint32_t)std::min<uint64_t>(ctx->total[r], (uint64_t)ctx->ring_cap);
     const int work = std::max(ctx->n_staged, ctx->rows);
     const int threads = 256;
     const int blocks = (work + threads - 1) / threads;
+    b.ticket = (b.ticket % 0x7FFFFFFFu) + 1u;
     hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(threads), 0, stream, b.h_counts, b.h_entries, ctx->n_staged,
                        ctx->d_samples, ctx->row_stride, ctx->d_counts, ctx->rows,
                        ctx->meta_dirty ? ctx->h_kinds : nullptr, ctx->d_kinds,
-                       ctx->meta_dirty ? ctx->h_gid : nullptr, ctx->d_gid);
+                       ctx->meta_dirty ? ctx->h_gid : nullptr, ctx->d_gid, b.d_cnt, b.d_done, b.ticket);
     HIP_TRY(hipGetLastError());
-    if (deferred_buf && !ctx->meta_dirty) {
-        *deferred_buf = ctx->cur;
-        b.deferred = true;
-        b.deferred_stream = stream;
-    } else {
-        HIP_TRY(hipEventRecord(b.done, stream));
-    }
     b.in_flight = true;
     if (ctx->meta_dirty) {
         // h_kinds/h_gid are read by the kernel just launched: do not let the host modify them until
         // it has run.  Metadata changes are cold (new names only), so a blocking wait is fine.
-        HIP_TRY(hipEventSynchronize(b.done));
-        b.in_flight = false;
+        int wrc = wait_stage_buffer(b);
+        if (wrc) return wrc;
     }
     ctx->meta_dirty = false;
     ctx->counts_dirty = false;
     ctx->n_staged = 0;
     ctx->cur = (ctx->cur + 1) % nvrx_ctx::NBUF;
-    StageBuf &nb = ctx->buf[ctx->cur];
-    if (nb.in_flight) {
-        if (nb.deferred) {
-            // rotated all the way round onto the buffer of a re-homed report that has not completed yet (a concurrent
-            // pusher filled the other buffers meanwhile): nb.done belongs to an EARLIER flush, so give the buffer its
-            // event now, behind the scatter that still reads it
-            HIP_TRY(hipEventRecord(nb.done, nb.deferred_stream));
-            nb.deferred = false;
-        }
-        HIP_TRY(hipEventSynchronize(nb.done));
-        nb.in_flight = false;
-    }
-    return NVRX_OK;
+    return wait_stage_buffer(ctx->buf[ctx->cur]);  // (a pusher a whole rotation ahead of the GPU waits here)
 }
 
 inline int push_locked(nvrx_ctx *ctx, int row, float value) {
     if (ctx->n_staged == ctx->stage_cap) {
         int rc = flush_locked(ctx, ctx->default_stream);
         if (rc) return rc;
-        ctx->side_work = true;
+        mark_side_work(ctx);
     }
     const uint32_t slot = (uint32_t)(ctx->total[row] % (uint64_t)ctx->ring_cap);
     StagedSample &e = ctx->buf[ctx->cur].h_entries[ctx->n_staged++];
@@ -2296,6 +2354,8 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     {
         const char *e = getenv("NVRX_REPORT_REHOME");
         ctx->rehome_mode = (e && atoi(e) == 0) ? 0 : 1;
+        const char *g = getenv("NVRX_ASYNC_REHOME_GAP_US");
+        if (g && *g) ctx->async_rehome_gap_us = atof(g);
     }
 
 #define CTX_TRY(expr)                                                                         \
@@ -2325,13 +2385,24 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_gid), (size_t)ctx->rows * sizeof(int32_t), hipHostMallocDefault));
     memset(ctx->h_kinds, 0, (size_t)ctx->rows);
     for (int r = 0; r < ctx->rows; r++) ctx->h_gid[r] = -1;
-    for (StageBuf &b : ctx->buf) {
-        CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&b.h_counts), (size_t)ctx->rows * sizeof(uint32_t), hipHostMallocDefault));
-        CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&b.h_entries), (size_t)ctx->stage_cap * sizeof(StagedSample), hipHostMallocDefault));
-        CTX_TRY(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+    // completion tickets of the scatters: one pinned word (64 bytes apart) and one device counter per staging buffer
+    CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage_done), (size_t)nvrx_ctx::NBUF * 64, hipHostMallocMapped));
+    memset(ctx->h_stage_done, 0, (size_t)nvrx_ctx::NBUF * 64);
+    CTX_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->d_stage_done), ctx->h_stage_done, 0));
+    CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stage_cnt), (size_t)nvrx_ctx::NBUF * sizeof(uint32_t)));
+    CTX_TRY(hipMemset(ctx->d_stage_cnt, 0, (size_t)nvrx_ctx::NBUF * sizeof(uint32_t)));
+    {
+        int bi = 0;
+        for (StageBuf &b : ctx->buf) {
+            CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&b.h_counts), (size_t)ctx->rows * sizeof(uint32_t), hipHostMallocDefault));
+            CTX_TRY(hipHostMalloc(reinterpret_cast<void **>(&b.h_entries), (size_t)ctx->stage_cap * sizeof(StagedSample), hipHostMallocDefault));
+            b.h_done = ctx->h_stage_done + (size_t)bi * 16;
+            b.d_done = ctx->d_stage_done + (size_t)bi * 16;
+            b.d_cnt = ctx->d_stage_cnt + bi;
+            bi++;
+        }
     }
     CTX_TRY(hipEventCreateWithFlags(&ctx->copy_done, hipEventDisableTiming));
-    CTX_TRY(hipEventCreateWithFlags(&ctx->bulk_done, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->stamp_ev, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
     CTX_TRY(hipEventCreateWithFlags(&ctx->report_ev, hipEventDisableTiming));
@@ -2369,13 +2440,13 @@ int nvrx_ctx_destroy(nvrx_ctx *ctx) {
     if (ctx->d_gid) (void)hipFree(ctx->d_gid);
     if (ctx->d_hist_min) (void)hipFree(ctx->d_hist_min);
     if (ctx->h_bulk) (void)hipHostFree(ctx->h_bulk);
-    if (ctx->bulk_done) (void)hipEventDestroy(ctx->bulk_done);
+    if (ctx->h_stage_done) (void)hipHostFree(ctx->h_stage_done);
+    if (ctx->d_stage_cnt) (void)hipFree(ctx->d_stage_cnt);
     if (ctx->h_kinds) (void)hipHostFree(ctx->h_kinds);
     if (ctx->h_gid) (void)hipHostFree(ctx->h_gid);
     for (StageBuf &b : ctx->buf) {
         if (b.h_counts) (void)hipHostFree(b.h_counts);
         if (b.h_entries) (void)hipHostFree(b.h_entries);
-        if (b.done) (void)hipEventDestroy(b.done);
     }
     for (EventPair &p : ctx->pool) {
         (void)hipEventDestroy(p.start);
@@ -2424,6 +2495,8 @@ int nvrx_ctx_info(const nvrx_ctx *ctx, int what) {
         case 2: return ctx->ring_cap;
         case 3: return ctx->row_stride;
         case 4: return ctx->device;
+        case 5: return (int)ctx->reports_rehomed;   // reports that were enqueued on the stream they had to follow (diagnostics)
+        case 6: return ctx->last_rehome_verdict;    // why the last report was / was not re-homed: see nvrx_report
         default: return fail(NVRX_ERR_INVALID, "unknown info selector %d", what);
     }
 }
@@ -2474,7 +2547,7 @@ int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values
     if (!ctx || (n > 0 && (!rows || !values)) || n < 0) return fail(NVRX_ERR_INVALID, "bad arguments");
     if (n == 0) return NVRX_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->side_work = true;  // (a later report is only re-homed onto another stream once this is known to be done)
+    mark_side_work(ctx);  // (a later report is only re-homed onto another stream once this is known to be done)
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
     hipStream_t st = ctx->default_stream;
@@ -2488,7 +2561,8 @@ int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values
         ctx->bulk_cnt[(size_t)r]++;
     }
     if (ctx->bulk_in_flight) {  // the previous call's scatter still reads the entry buffer
-        HIP_TRY(hipEventSynchronize(ctx->bulk_done));
+        int wrc = nvrx_poll_u32(const_cast<const uint32_t *>(ctx->bulk_word), ctx->bulk_ticket, 1800.0);
+        if (wrc) return wrc;
         ctx->bulk_in_flight = false;
     }
     if (ctx->bulk_cap < (size_t)n) {
@@ -2517,27 +2591,27 @@ int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values
     for (int r = 0; r < ctx->rows; r++)
         b.h_counts[r] = (uint32_t)std::min<uint64_t>(ctx->total[(size_t)r], cap);
     const int work = std::max(m, ctx->rows);
+    {
+        int grc = guard_ring_writer(ctx, st);  // the scatter writes ring slots
+        if (grc) return grc;
+    }
+    b.ticket = (b.ticket % 0x7FFFFFFFu) + 1u;
     hipLaunchKernelGGL(k_scatter, dim3((work + 255) / 256), dim3(256), 0, st, b.h_counts, ctx->h_bulk, m, ctx->d_samples,
                        ctx->row_stride, ctx->d_counts, ctx->rows, ctx->meta_dirty ? ctx->h_kinds : nullptr, ctx->d_kinds,
-                       ctx->meta_dirty ? ctx->h_gid : nullptr, ctx->d_gid);
+                       ctx->meta_dirty ? ctx->h_gid : nullptr, ctx->d_gid, b.d_cnt, b.d_done, b.ticket);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b.done, st));
-    HIP_TRY(hipEventRecord(ctx->bulk_done, st));
     b.in_flight = true;
-    ctx->bulk_in_flight = true;
+    ctx->bulk_in_flight = true;  // the entry buffer is released by the same ticket as this call's staging buffer
+    ctx->bulk_word = b.h_done;
+    ctx->bulk_ticket = b.ticket;
     if (ctx->meta_dirty) {
-        HIP_TRY(hipEventSynchronize(b.done));
-        b.in_flight = false;
+        int wrc = wait_stage_buffer(b);
+        if (wrc) return wrc;
     }
     ctx->meta_dirty = false;
     ctx->counts_dirty = false;
     ctx->cur = (ctx->cur + 1) % nvrx_ctx::NBUF;
-    StageBuf &nb = ctx->buf[ctx->cur];
-    if (nb.in_flight) {
-        HIP_TRY(hipEventSynchronize(nb.done));
-        nb.in_flight = false;
-    }
-    return NVRX_OK;
+    return wait_stage_buffer(ctx->buf[ctx->cur]);
 }
 
 int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, void *stream) {
@@ -2546,11 +2620,13 @@ int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, 
     if (n < 0 || (n > 0 && !d_values)) return fail(NVRX_ERR_INVALID, "bad d_values/n");
     if (n == 0) return NVRX_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->side_work = true;  // (a later report is only re-homed onto another stream once this is known to be done)
+    mark_side_work(ctx);  // (a later report is only re-homed onto another stream once this is known to be done)
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
     hipStream_t st = as_stream(stream);
     rc = flush_locked(ctx, st);  // earlier staged samples must land first
+    if (rc) return rc;
+    rc = guard_ring_writer(ctx, st);  // the copies below write ring slots
     if (rc) return rc;
     const int cap = ctx->ring_cap;
     // only the newest `cap` samples can survive
@@ -2626,7 +2702,7 @@ int nvrx_ring_reset(nvrx_ctx *ctx) {
 int nvrx_history_reset(nvrx_ctx *ctx, void *stream) {
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->side_work = true;  // (a later report is only re-homed onto another stream once this is known to be done)
+    mark_side_work(ctx);  // (a later report is only re-homed onto another stream once this is known to be done)
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
     hipLaunchKernelGGL(k_fill_f32, dim3((ctx->rows + 255) / 256), dim3(256), 0, as_stream(stream), ctx->d_hist_min,
@@ -2638,7 +2714,7 @@ int nvrx_history_reset(nvrx_ctx *ctx, void *stream) {
 int nvrx_ring_flush(nvrx_ctx *ctx, void *stream) {
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->side_work = true;  // (a later report is only re-homed onto another stream once this is known to be done)
+    mark_side_work(ctx);  // (a later report is only re-homed onto another stream once this is known to be done)
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
     return flush_locked(ctx, as_stream(stream));
@@ -2747,19 +2823,10 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
         }
         ctx->counts_dirty = true;
         hipStream_t st = as_stream(stream);
-        if (ctx->report_epoch) {
+        {
             // an asynchronous report may still be reading the rings: this stream's ring writes follow its statistics kernel
-            nvrx_ctx::StreamEpoch *se = nullptr;
-            for (auto &e : ctx->stream_epochs)
-                if (e.stream == st) se = &e;
-            if (!se) {
-                ctx->stream_epochs.push_back({st, 0});
-                se = &ctx->stream_epochs.back();
-            }
-            if (se->epoch < ctx->report_epoch) {
-                HIP_TRY(hipStreamWaitEvent(st, ctx->report_ev, 0));
-                se->epoch = ctx->report_epoch;
-            }
+            int grc = guard_ring_writer(ctx, st);
+            if (grc) return grc;
         }
         hipLaunchKernelGGL(k_stamp_end, dim3(1), dim3(1), 0, st, ctx->d_stamps + slot, ctx->us_per_tick, dst_gpu, dst_cpu,
                            cpu_value);
@@ -2775,19 +2842,19 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
 // report (local half)
 // ------------------------------------------------------------------------------------------------
 static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
-                             void *stream, unsigned long long *rowg, uint32_t epoch, int *deferred_buf = nullptr);
+                             void *stream, unsigned long long *rowg, uint32_t epoch);
 
 int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
                       void *stream) {
     if (ctx) {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        ctx->side_work = true;  // the caller decides when this stream is waited for: no re-homing until that is known
+        mark_side_work(ctx);  // the caller decides when this stream is waited for: no re-homing until that is known
     }
     return report_local_impl(ctx, d_stats, d_send, K, S, names_ok, rows_active, stream, nullptr, 0);
 }
 
 static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S, int names_ok, int rows_active,
-                             void *stream, unsigned long long *rowg, uint32_t epoch, int *deferred_buf) {
+                             void *stream, unsigned long long *rowg, uint32_t epoch) {
     hipStream_t st = as_stream(stream);
     if (!ctx || !d_stats) return fail(NVRX_ERR_INVALID, "null argument");
     if (K < 0 || S < 0) return fail(NVRX_ERR_INVALID, "bad K/S");
@@ -2797,7 +2864,7 @@ static int report_local_impl(nvrx_ctx *ctx, float *d_stats, float *d_send, int K
     int rc = ctx_set_device(ctx);
     if (rc) return rc;
     int uniform_n = -1;
-    rc = flush_locked(ctx, st, &uniform_n, rows_active, deferred_buf);
+    rc = flush_locked(ctx, st, &uniform_n, rows_active);
     if (rc) return rc;
     report_clk(2);
     Epilogue ep{};
@@ -2889,8 +2956,28 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     // warm.  Not for asynchronous reports (they are meant to run BESIDE the next step; re-homed they measured 2.7 % per
     // step instead of 2.0-2.4 % and no gain at cadence), not while work of ours may still be running on the context's
     // own stream (side_work), NVRX_REPORT_REHOME=0 turns it off.
+    // Asynchronous reports are re-homed too when they are rare (round 4): one that stays on the detector's own stream needs
+    // an event record + stream-wait pair to follow the training stream's stamps, and at production cadence those two
+    // cold calls were 45-52 us of the 51-116 us an enqueue cost (profiles/r04o).  Re-homed, the report's kernels (~20 us of
+    // GPU time) sit in the training stream once per interval instead of beside it -- which is why reports closer together
+    // than NVRX_ASYNC_REHOME_GAP_US (default 5000) stay where they were: a report EVERY step is cheaper beside the step.
+    const bool is_async = d->h_seq_word == nullptr;
+    bool async_gap_ok = false;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        const double now_us = g_report_clk[0];
+        async_gap_ok = ctx->async_rehome_gap_us > 0.0 && ctx->last_report_us > 0.0 && now_us - ctx->last_report_us >= ctx->async_rehome_gap_us;
+        ctx->last_report_us = now_us;
+        if (d->prev_settled) {
+            // the caller has seen this context's previous (asynchronous) report complete: nothing has to be guarded against
+            // it any more, and what was enqueued on the context's stream in front of it is done as well
+            ctx->guard_done_epoch = ctx->report_epoch;
+            if (ctx->async_on_ctx && ctx->async_gen == ctx->side_gen) ctx->side_work = false;
+            ctx->async_on_ctx = false;
+        }
+    }
     bool rehomed = false;
-    if (d->h_seq_word && !d->guard_rings && ctx->rehome_mode) {
+    if (ctx->rehome_mode && ((!is_async && !d->guard_rings) || (is_async && d->guard_rings && async_gap_ok))) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         hipStream_t only = nullptr;
         int distinct = 0;
@@ -2902,11 +2989,15 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         };
         for (hipStream_t s : ctx->stamp_streams) see(s);
         if (d->order_after_enabled) see(as_stream(d->order_after_stream));
-        if (distinct == 1 && only != as_stream(stream) && !ctx->side_work && !ctx->timing) {
+        ctx->last_rehome_verdict = !(distinct == 1 && only != as_stream(stream)) ? -1 : ctx->side_work ? -2 : ctx->async_on_ctx ? -3 : ctx->timing ? -4 : 1;
+        if (ctx->last_rehome_verdict == 1) {
             stream = only;
             rehomed = true;
             ctx->stamp_streams.clear();
+            ctx->reports_rehomed++;
         }
+    } else {
+        ctx->last_rehome_verdict = 0;
     }
     if (!rehomed && d->order_after_enabled && d->order_after_stream != stream) {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -2991,34 +3082,21 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
             // every row's granules were consumed: the statistics kernel, last on the context's in-order stream, is done
             std::lock_guard<std::mutex> lk(ctx->mu);
             ctx->side_work = false;
+            ctx->async_on_ctx = false;
         }
         return NVRX_OK;
     }
-    int deferred_buf = -1;
-    int rc = report_local_impl(ctx, d->d_stats, d->d_send, d->K, d->S, d->names_ok, d->rows_active, stream, nullptr, 0,
-                               rehomed ? &deferred_buf : nullptr);
-    // the staging buffer whose "scatter done" event was not recorded: released by the completion word, or -- on any
-    // failure below -- given its event after all
-    auto settle_deferred = [&](bool done) {
-        if (deferred_buf < 0) return;
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        StageBuf &db = ctx->buf[deferred_buf];
-        if (db.deferred) {  // (else a concurrent flush already gave the buffer its event and waited for it)
-            if (done)
-                db.in_flight = false;
-            else
-                (void)hipEventRecord(db.done, as_stream(stream));
-            db.deferred = false;
-        }
-        deferred_buf = -1;
-    };
-    if (rc) {
-        settle_deferred(false);
-        return rc;
-    }
+    int rc = report_local_impl(ctx, d->d_stats, d->d_send, d->K, d->S, d->names_ok, d->rows_active, stream, nullptr, 0);
+    if (rc) return rc;
     if (d->guard_rings) {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        HIP_TRY(hipEventRecord(ctx->report_ev, as_stream(stream)));
+        ctx->guard_stream = as_stream(stream);
+        if (rehomed) {
+            ctx->guard_recorded = false;  // writers on this very stream follow by stream order; anybody else records it (guard_ring_writer)
+        } else {
+            HIP_TRY(hipEventRecord(ctx->report_ev, as_stream(stream)));
+            ctx->guard_recorded = true;
+        }
         ctx->report_epoch++;
     }
     PeerArgs pa{};
@@ -3027,10 +3105,7 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         score_fits_single_wg(d->R, d->K, d->S, d->d_scores, d->d_flags) && peer_prologue_enabled()) {
         // peer windows + a table the single-workgroup score kernel takes: the exchange runs as that kernel's prologue
         rc = peer_fill_args(static_cast<nvrx_peer *>(d->comm), d->d_send, d->d_table, (size_t)d->send_count, &pa);
-        if (rc) {
-            settle_deferred(false);
-            return rc;
-        }
+        if (rc) return rc;
         prologue = true;
     } else if (exchanging) {
         // ncclAllGather(sendbuff, recvbuff, sendcount, ncclFloat32 = 7, comm, stream), enqueued between the two
@@ -3039,7 +3114,6 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         const int nrc = reinterpret_cast<AllGatherFn>(d->allgather_fn)(d->d_send, d->d_table, (size_t)d->send_count, 7,
                                                                        d->comm, stream);
         if (nrc != 0) {
-            settle_deferred(false);
             return fail(NVRX_ERR_HIP, "all-gather of the exchange rows failed (ncclResult %d)", nrc);
         }
     }
@@ -3048,26 +3122,24 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     rc = score_launch(exchanging ? d->d_table : d->d_send, d->R, d->K, d->S, d->do_indiv, d->do_rel, d->thresholds,
                       d->d_scores, d->d_flags, d->d_meta, d->d_done_counter, d->seq, d->d_stats, d->d_stats_dst,
                       d->stats_rows, stream, prologue ? &pa : nullptr);
-    if (rc) {
-        settle_deferred(false);
-        return rc;
-    }
+    if (rc) return rc;
     report_clk(5);
     if (d->h_seq_word) {
         rc = nvrx_poll_u32(d->h_seq_word, d->seq, d->timeout_s > 0.0 ? d->timeout_s : 1e30);
         report_clk(6);
-        settle_deferred(rc == NVRX_OK);
         if (rc == NVRX_OK && !rehomed && as_stream(stream) == ctx->default_stream) {
             // the completion word was stored by the last kernel of this report on the context's own in-order stream:
             // everything of ours enqueued there before it has finished
             std::lock_guard<std::mutex> lk(ctx->mu);
             ctx->side_work = false;
+            ctx->async_on_ctx = false;
         }
         return rc;
     }
-    {
+    if (!rehomed) {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        ctx->side_work = true;  // an asynchronous report is in flight on this stream
+        ctx->async_on_ctx = true;  // an asynchronous report is in flight on the context's own stream,
+        ctx->async_gen = ctx->side_gen;  // behind all the side work counted so far
     }
     return NVRX_OK;
 }

@@ -39,7 +39,7 @@ class ReportDesc(ctypes.Structure):
         ("d_done_counter", c_void_p),
         ("allgather_fn", c_void_p), ("comm", c_void_p), ("send_count", c_int32), ("seq", c_uint32),
         ("h_seq_word", c_void_p), ("timeout_s", c_double),
-        ("order_after_stream", c_void_p), ("order_after_enabled", c_int32), ("resident", c_int32), ("reserved", c_int32), ("guard_rings", c_int32),
+        ("order_after_stream", c_void_p), ("order_after_enabled", c_int32), ("resident", c_int32), ("prev_settled", c_int32), ("guard_rings", c_int32),
     ]
 
 

@@ -562,6 +562,10 @@ class HipRings:
             d.timeout_s = report_timeout_s()
             d.h_seq_word = blk.h_seq if wait else None
             d.guard_rings = 0 if wait else 1
+            # an asynchronous generator polls its previous report's completion word before it comes here
+            # (ReportGenerator._settle_inflight): the library may then stop guarding the rings against that report and,
+            # when reports are rare, enqueue this one on the stream it has to follow
+            d.prev_settled = 0 if wait else 1
             # resident score kernel on a stream of its own: the library decides among the eligible shapes (no exchange or
             # peer windows, table fits one workgroup); off when ranks share a device
             d.resident = 1 if (wait and resident) else 0

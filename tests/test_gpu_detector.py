@@ -254,8 +254,11 @@ def test_config2_loop_folded_on_one_gpu_matches_reference():
         job.close()
 
 
-def test_asynchronous_reports_do_not_race_with_device_stamps():
-    """Asynchronous report t is only enqueued when generate_report returns; the stamp kernels of window t+1 (user
+@pytest.mark.parametrize("rehome_gap_us", [None, "1"])
+def test_asynchronous_reports_do_not_race_with_device_stamps(monkeypatch, rehome_gap_us):
+    """(``rehome_gap_us`` "1": every eligible asynchronous report is enqueued on the stamps' own stream, the round-4 route
+    of reports at production cadence; None: they stay on the detector's stream, as reports a millisecond apart do.)
+    Asynchronous report t is only enqueued when generate_report returns; the stamp kernels of window t+1 (user
     stream) write ring slots that report t's statistics kernel (detector stream) may not have read yet.  The library
     orders them on the device.  Provoked here by parking a long kernel in front of every report: each window's CPU
     samples all carry the window index, so a sample of window t+1 inside report t would show up as MAX > t."""
@@ -263,6 +266,8 @@ def test_asynchronous_reports_do_not_race_with_device_stamps():
     from nvrx_straggler.backend import get_backend
 
     be = get_backend()
+    if rehome_gap_us is not None:
+        monkeypatch.setenv("NVRX_ASYNC_REHOME_GAP_US", rehome_gap_us)  # read when the rings' context is created
     Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n", asynchronous=True)
     try:
         with Detector.detection_section("s", profile_cuda=True):
@@ -443,3 +448,44 @@ def test_asynchronous_reports_read_late_or_never_keep_their_own_values():
         assert checked >= 25
     finally:
         job.close()
+
+
+def test_asynchronous_rehomed_reports_guard_ring_writers_on_other_streams(monkeypatch):
+    """An asynchronous report that is enqueued ON the stream its stamps ran on (reports at production cadence, forced here
+    by a 1 us gap) records no event of its own; the stamp kernels of the NEXT window, launched on ANOTHER stream, must
+    still not overtake its statistics kernel -- the guard records the event lazily, behind the report, when such a writer
+    turns up.  Windows alternate between two user streams, a ~3 ms kernel is parked in front of every report on the
+    stream it will run on; a sample of window t+1 inside report t would show up as MAX > t."""
+    from nvrx_straggler import Detector, Statistic
+
+    monkeypatch.setenv("NVRX_ASYNC_REHOME_GAP_US", "1")
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n", asynchronous=True)
+    try:
+        with Detector.detection_section("s", profile_cuda=True):
+            pass
+        Detector.generate_report()
+        rings = Detector.rings
+        sec = Detector.custom_sections["s"]
+        gpu_row = rings.kernel_row_names["hipevent::s"]
+        big = torch.randn(8192, 8192, device="cuda")
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        prev, seen = None, 0
+        for t in range(1, 30):
+            st = streams[t % 2]
+            with torch.cuda.stream(st):
+                (big @ big).sum()            # ~3 ms: the report of this window queues behind it on this stream
+                for _ in range(3):
+                    rings.stamp_begin(gpu_row, st.cuda_stream)
+                    rings.stamp_end(gpu_row, st.cuda_stream, sec.row, float(t))
+                rep = Detector.generate_report()  # returns at once; re-homed onto `st`
+            if prev is not None:
+                s = prev.local_section_summaries["s"]
+                assert s[Statistic.NUM] == 3 and s[Statistic.MIN] == s[Statistic.MAX] == float(t - 1), (t, s)
+                assert prev.local_kernel_summaries["hipevent::s"][Statistic.NUM] == 3
+                seen += 1
+            prev = rep
+        torch.cuda.synchronize()
+        assert seen == 28 and prev.local_section_summaries["s"][Statistic.MAX] == 29.0
+    finally:
+        Detector.shutdown()

@@ -267,7 +267,7 @@ def test_a_misbehaving_exchange_route_is_dropped_by_every_rank_together(fault):
     reference's (golden ``sections_2ranks_gather1`` / ``mixed_8ranks`` scenarios come from the real reference)."""
     g = next(s for s in _SCENARIOS if s["scenario"]["name"] == "sections_2ranks_gather1")
     sc = g["scenario"]
-    env = {"NVRX_EXCHANGE": "rccl", "NVRX_TRIAL_TIMEOUT_S": "1", "NVRX_PEER_TRIAL_TIMEOUT_S": "2", "NVRX_REPORT_TIMEOUT_S": "30"}
+    env = {"NVRX_EXCHANGE": "rccl", "NVRX_TRIAL_TIMEOUT_S": "0.5", "NVRX_PEER_TRIAL_TIMEOUT_S": "2", "NVRX_REPORT_TIMEOUT_S": "30"}
     res = run_ranks(workers.route_fault_injection, sc["world_size"], timeout=300, use_oracle_backend=False, device=0, env=env,
                     fault=fault, scenario=sc)
     for r in range(sc["world_size"]):

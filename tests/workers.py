@@ -565,11 +565,12 @@ def route_fault_injection(rank, world, fault, scenario):
     hip.hipMemsetD32Async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
     be = backend_mod.get_backend()
     # how many spin cycles are a second on this box (the spin kernel's clock is not specified)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    torch.cuda._sleep(20_000_000)
-    torch.cuda.synchronize()
-    cycles_per_s = 20_000_000 / max(time.perf_counter() - t0, 1e-4)
+    for n_spin in (2_000_000, 20_000_000, 40_000_000):   # (the last, longest one is measured with the clocks up)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        torch.cuda._sleep(n_spin)
+        torch.cuda.synchronize()
+        cycles_per_s = n_spin / max(time.perf_counter() - t0, 1e-4)
     state = {"calls": 0, "closed": 0, "aborted": 0}
     last = rank == world - 1
 
@@ -600,7 +601,7 @@ def route_fault_injection(rank, world, fault, scenario):
                 hip.hipMemsetD32Async(recv_ptr, 0x42280000, count, stream_handle)   # 42.0f over rank 0's row of the table
             if last and fault == "never_completes":
                 with torch.cuda.stream(be.stream):
-                    torch.cuda._sleep(int(2.5 * cycles_per_s))                        # far beyond the trial's patience
+                    torch.cuda._sleep(int(4.0 * cycles_per_s))                        # seconds: far beyond the trial's patience (0.5 s)
 
         def exchange(self, ws, backend):
             self.all_gather(ws.send_ptr, ws.table_ptr, ws.local_ranks * ws.L, backend.stream_handle)

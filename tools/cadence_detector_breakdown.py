@@ -53,6 +53,7 @@ import ctypes  # noqa: E402
 
 clk = (ctypes.c_double * 8)()
 rows = []
+verdicts = {}
 for cadence in (True, False):
     acc = []
     for i in range(24 if cadence else 60):
@@ -75,6 +76,7 @@ for cadence in (True, False):
             rep.identify_stragglers()
         t2 = time.perf_counter_ns()
         Detector.rings.lib.nvrx_report_clocks(clk)
+        verdicts[Detector.rings.lib.nvrx_ctx_info(Detector.rings.ctx, 6)] = verdicts.get(Detector.rings.lib.nvrx_ctx_info(Detector.rings.ctx, 6), 0) + 1
         marks["C: entry -> stream ordering done (event record / wait pairs)"] = int((clk[1] - clk[0]) * 1e3)
         marks["C: -> staged samples flushed (k_scatter launch)"] = int((clk[2] - clk[1]) * 1e3)
         marks["C: -> k_row_stats launched"] = int((clk[3] - clk[2]) * 1e3)
@@ -93,4 +95,5 @@ for cadence in (True, False):
               "C: -> completion word seen (poll)", "rings.reset", "identify_stragglers"):
         v = [a.get(k, 0) for a in acc]
         print(f"  {k:44s} median {np.median(v)/1e3:7.1f} us   p95 {np.percentile(v,95)/1e3:7.1f}")
+print("re-home verdicts of the reports (1 re-homed, 0 not a candidate, -1 streams, -2 side work, -3 async in flight):", verdicts)
 Detector.shutdown()
