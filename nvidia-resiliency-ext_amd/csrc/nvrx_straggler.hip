@@ -2059,7 +2059,15 @@ int guard_ring_writer(nvrx_ctx *ctx, hipStream_t st) {
     if (se->epoch < ctx->report_epoch) {
         if (ctx->guard_done_epoch < ctx->report_epoch && st != ctx->guard_stream) {
             if (!ctx->guard_recorded) {
-                HIP_TRY(hipEventRecord(ctx->report_ev, ctx->guard_stream));
+                if (hipEventRecord(ctx->report_ev, ctx->guard_stream) != hipSuccess) {
+                    // the stream the report was enqueued on is gone (a user stream destroyed since): wait for the device
+                    // once instead -- whatever was enqueued on that stream is then done
+                    (void)hipGetLastError();
+                    HIP_TRY(hipDeviceSynchronize());
+                    ctx->guard_done_epoch = ctx->report_epoch;
+                    se->epoch = ctx->report_epoch;
+                    return NVRX_OK;
+                }
                 ctx->guard_recorded = true;
             }
             HIP_TRY(hipStreamWaitEvent(st, ctx->report_ev, 0));
@@ -2255,6 +2263,7 @@ static int score_launch(const float *d_table, int R, int K, int S, int do_indiv,
             hipLaunchKernelGGL(k_score1<SCORE1_RESIDENT_THREADS>, dim3(1), dim3(SCORE1_RESIDENT_THREADS), lds1, st, a,
                                score_fence_enabled(), pa ? *pa : none, *ga);
         } else {
+            report_clk(7);  // (diagnostics: argument set-up ends / the launch call begins)
             hipLaunchKernelGGL(k_score1<SCORE1_THREADS>, dim3(1), dim3(SCORE1_THREADS), lds1, st, a, score_fence_enabled(),
                                pa ? *pa : none, nog);
         }

@@ -81,6 +81,7 @@ for cadence in (True, False):
         marks["C: -> staged samples flushed (k_scatter launch)"] = int((clk[2] - clk[1]) * 1e3)
         marks["C: -> k_row_stats launched"] = int((clk[3] - clk[2]) * 1e3)
         marks["C: -> score kernel launched"] = int((clk[5] - clk[3]) * 1e3)
+        marks["C:    of which the launch call itself"] = int((clk[5] - clk[7]) * 1e3) if clk[7] > clk[3] else 0
         if not ASYNC:
             marks["C: -> completion word seen (poll)"] = int((clk[6] - clk[5]) * 1e3)
         if i >= 4:
@@ -92,7 +93,7 @@ for cadence in (True, False):
     for k in ("TOTAL generate_report", "reporter._settle_inflight (previous report)", "harvest", "rings.counts", "reporter.generate_report_from_rings", "rings.report_fused (Python + C call)",
               "  nvrx_report (C)", "C: entry -> stream ordering done (event record / wait pairs)",
               "C: -> staged samples flushed (k_scatter launch)", "C: -> k_row_stats launched", "C: -> score kernel launched",
-              "C: -> completion word seen (poll)", "rings.reset", "identify_stragglers"):
+              "C:    of which the launch call itself", "C: -> completion word seen (poll)", "rings.reset", "identify_stragglers"):
         v = [a.get(k, 0) for a in acc]
         print(f"  {k:44s} median {np.median(v)/1e3:7.1f} us   p95 {np.percentile(v,95)/1e3:7.1f}")
 print("re-home verdicts of the reports (1 re-homed, 0 not a candidate, -1 streams, -2 side work, -3 async in flight):", verdicts)
