@@ -423,18 +423,6 @@ def _roof(kern_us, alg_bytes):
 def _n8_shape_leg(steps, warmup):
     """The per-GPU work of the 8-GPU production shape on this GPU: ONE logical rank, 64 rows x 10 000 samples (2.56 MB).
     Report latency without an exchange + the statistics kernel against the roofline at that shape."""
-    # which physical devices the ranks really run on: with --backend gloo several ranks may share one, and the line must
-    # not call that "N GPUs"
-    props = torch.cuda.get_device_properties(device_index)
-    ident = (os.uname().nodename, getattr(props, "pci_domain_id", -1), getattr(props, "pci_bus_id", -1),
-             getattr(props, "pci_device_id", device_index), str(getattr(props, "uuid", "")))
-    if world > 1:
-        idents = [None] * world
-        dist.all_gather_object(idents, ident)
-    else:
-        idents = [ident]
-    distinct_devices = len(set(idents))
-
     import synth
     from nvrx_straggler import ktrace as _ktrace
     from nvrx_straggler.folded import FoldedJob

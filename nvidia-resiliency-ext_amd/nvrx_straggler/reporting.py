@@ -377,7 +377,21 @@ class _ScoreSource:
             v._flag_args = (rank_to_node, off, args)
         pend = self.pending
         out = None
-        if self.scores is None and type(pend) is _LiveBlock:
+        if self.scores is None and type(pend) is _PendingBlock:
+            # an asynchronous report read late: its flags are decoded in place as well -- the report's own lock keeps the
+            # block from collecting it (``detach``), and until it has, nothing is enqueued that writes the block again
+            with pend.lock:
+                blk = pend.blk
+                live = getattr(blk, "_host", None) if (pend.blob is None and blk is not None) else None
+                if live is not None:
+                    pend.backend.wait_seq(pend.ws, pend.seq, block=blk)
+                    try:
+                        out = _pyread.flagged(live, off, *args)
+                    except (BufferError, TypeError):
+                        out = None
+        if out is not None:
+            pass
+        elif self.scores is None and type(pend) is _LiveBlock:
             with _LIVE_LOCK:
                 # the result block itself, nothing copied: under the lock the generator cannot collect this report
                 # (``detach`` takes it too), and until it has, nothing is enqueued that writes the block again

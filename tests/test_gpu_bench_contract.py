@@ -23,9 +23,13 @@ def _run(args, env=None, timeout=240):
 
 @pytest.mark.gpu
 def test_single_gpu_line_has_the_contract_fields_and_the_round3_legs():
-    r, lines = _run(["--gpus", "1", "--steps", "6", "--warmup", "2", "--dump-steps"] + FAST)
+    r, lines = _run(["--gpus", "1", "--steps", "6", "--warmup", "2", "--dump-steps"] + [f for f in FAST if f != "--no-extra-legs"])
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
     d = json.loads(lines[0])
+    # a side leg that fails reports its exception as its value instead of taking the line down: none may have
+    broken = {k: v["error"] for k, v in d.items() if isinstance(v, dict) and "error" in v}
+    assert not broken, broken
+    assert d["roofline_n8_shape"]["report_us"] > 0 and d["detector_report"]["us_median"] > 0 and d["section_entry_us"]["profile_cuda_true_us"] > 0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in d, k
