@@ -55,14 +55,16 @@ class Model(nn.Module):
 
 
 def train(args) -> None:
+    # the order of the reference's example (examples/straggler/example.py:60-66): the detector first, the GPU afterwards --
+    # the detector's device side is created at the first section, on the device that is current then
+    straggler.Detector.initialize(gather_on_rank0=True)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device_index = 0 if args.share_gpu else local_rank
-    torch.cuda.set_device(device_index)
-    device = torch.device("cuda", device_index)
     if world > 1:
         dist.init_process_group("gloo" if args.share_gpu else "nccl")
-    straggler.Detector.initialize(gather_on_rank0=True)
+    torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
     torch.manual_seed(42 + rank)
     model = Model(args.width).to(device)
     net = DDP(model, device_ids=None if args.share_gpu else [device_index]) if world > 1 else model

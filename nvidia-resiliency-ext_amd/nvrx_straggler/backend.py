@@ -67,6 +67,20 @@ def set_backend(backend) -> None:
         _backend = backend
 
 
+_NO_DEVICE = ("nvrx_straggler: no HIP device is visible (torch.cuda.is_available() is False). "
+              "The MI355X straggler-scoring path has no CPU fallback.")
+
+
+def require_engine() -> None:
+    """Fail NOW where the engine cannot run (library not built, no HIP device) -- without creating it: the engine binds to
+    the device that is current when it is first used, which a script may select only after ``Detector.initialize``."""
+    if _backend is not None:
+        return
+    _native.load()
+    if not torch.cuda.is_available():
+        raise RuntimeError(_NO_DEVICE)
+
+
 def get_backend():
     """The active backend; creates the HIP engine on first use and fails loudly if it cannot."""
     global _backend
@@ -282,10 +296,7 @@ class HipBackend:
     def __init__(self, device: Optional[int] = None):
         self.lib = _native.load()
         if not torch.cuda.is_available():
-            raise RuntimeError(
-                "nvrx_straggler: no HIP device is visible (torch.cuda.is_available() is False). "
-                "The MI355X straggler-scoring path has no CPU fallback."
-            )
+            raise RuntimeError(_NO_DEVICE)
         index = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", index)
         # the report pipeline runs on its own stream so it never serialises with the training stream

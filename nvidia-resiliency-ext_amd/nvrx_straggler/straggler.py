@@ -114,7 +114,35 @@ class CustomSection:
         self.cpu_elapsed_times = _ElapsedRing(rings, self.row)
 
 
-class Detector:
+class _DeviceSideOnDemand(type):
+    """``Detector.rings`` and ``Detector.cupti_manager`` -- everything that lives on a GPU -- come into being the first
+    time they are touched, on the device that is current THEN.  The reference's own example initialises the detector
+    before it selects its GPU (examples/straggler/example.py:60-66: ``Detector.initialize()``, then
+    ``init_process_group``, then ``torch.cuda.set_device(local_rank)``); CUPTI does not care, device memory does: rings
+    created inside ``initialize`` would sit on GPU 0 in every rank of such a script."""
+
+    @property
+    def rings(cls):
+        if cls._rings is None and cls.initialized:
+            cls._create_device_side()
+        return cls._rings
+
+    @rings.setter
+    def rings(cls, value):
+        cls._rings = value
+
+    @property
+    def cupti_manager(cls):
+        if cls._cupti_manager is None and cls.initialized:
+            cls._create_device_side()
+        return cls._cupti_manager
+
+    @cupti_manager.setter
+    def cupti_manager(cls, value):
+        cls._cupti_manager = value
+
+
+class Detector(metaclass=_DeviceSideOnDemand):
     """Straggler detector; class-level singleton, not meant to be instantiated.
 
     Class attributes after ``initialize``: ``scores_to_compute``, ``gather_on_rank0``,
@@ -129,12 +157,14 @@ class Detector:
     gather_on_rank0: bool
     profiling_interval: int
     report_time_interval: float
-    # state
-    rings: Any = None  # device ring buffers: one row per section / GPU-timed region
+    # state (``rings``: device ring buffers, one row per section / GPU-timed region; ``cupti_manager``: the profiler that
+    # feeds the GPU-time rows -- both created on first use, see _DeviceSideOnDemand)
+    _rings: Any = None
+    _cupti_manager: Optional[CuptiManager] = None
+    _device_side_args: Any = None
     custom_sections: Dict[str, CustomSection]
     original_callables: Optional[Dict[CallableId, Any]]
     # collaborators
-    cupti_manager: Optional[CuptiManager]
     reporter: ReportGenerator
     report_interval_tracker: ReportIntervalTracker
     # which rows held samples at the last report, and the name -> row tables derived from that
@@ -171,20 +201,21 @@ class Detector:
                 False = the reference's synchronous behaviour.
         """
         assert not cls.initialized
+        _backend_mod.require_engine()  # no silent CPU path: a box that cannot run the engine says so here
         everything = str(scores_to_compute) == "all"
         cls.scores_to_compute = ["relative_perf_scores", "individual_perf_scores"] if everything else scores_to_compute
         cls.gather_on_rank0, cls.profiling_interval = gather_on_rank0, profiling_interval
         cls.report_time_interval = report_time_interval
         cls.custom_sections, cls.original_callables, cls._occupied_key = {}, {}, None
 
-        # device side: the rings every section / GPU-timed region records into, and the profiler that feeds them
+        # device side -- the rings every section / GPU-timed region records into and the profiler that feeds them --
+        # is created on first use, on the device that is current then (_DeviceSideOnDemand)
         capacity = int(CustomSection.max_elapseds_len)
         per_kernel = _ktrace.timing_mode() == "kernels"
         if per_kernel and int(max_rows) == 256:
             max_rows = 4096  # one row per distinct kernel key; 4096 x 8192 f32 = 128 MB of 288 GB
-        cls.rings = _backend_mod.get_backend().make_rings(1, int(max_rows), capacity)
-        cls.cupti_manager = CuptiManager(statsMaxLenPerKernel=capacity, rings=cls.rings)
-        cls.cupti_manager.initialize()
+        cls._rings = cls._cupti_manager = None
+        cls._device_side_args = (int(max_rows), capacity)
 
         # host side: who scores, and when
         if asynchronous is None:
@@ -196,12 +227,27 @@ class Detector:
         cls.initialized = True
 
     @classmethod
+    def _create_device_side(cls) -> None:
+        if cls._rings is not None:
+            return
+        max_rows, capacity = cls._device_side_args
+        rings = _backend_mod.get_backend().make_rings(1, max_rows, capacity)
+        try:
+            manager = CuptiManager(statsMaxLenPerKernel=capacity, rings=rings)
+            manager.initialize()
+        except BaseException:
+            rings.close()
+            raise
+        cls._rings, cls._cupti_manager = rings, manager
+
+    @classmethod
     def shutdown(cls):
         """Undo ``initialize``: wrapped callables get their originals back, profiler, rings and exchange route close."""
-        manager, cls.cupti_manager = cls.cupti_manager, None
-        manager.shutdown()
+        manager, cls._cupti_manager = cls._cupti_manager, None
+        if manager is not None:
+            manager.shutdown()
         cls.restore_original_callables()
-        rings, cls.rings = cls.rings, None
+        rings, cls._rings = cls._rings, None
         if rings is not None:
             rings.close()
         reporter = getattr(cls, "reporter", None)

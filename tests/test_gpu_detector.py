@@ -489,3 +489,44 @@ def test_asynchronous_rehomed_reports_guard_ring_writers_on_other_streams(monkey
         assert seen == 28 and prev.local_section_summaries["s"][Statistic.MAX] == 29.0
     finally:
         Detector.shutdown()
+
+
+def test_initialize_before_the_gpu_is_selected_binds_nothing():
+    """The reference's example order (examples/straggler/example.py:60-66): ``Detector.initialize()`` first, the device
+    afterwards.  In a fresh interpreter: after ``initialize`` no engine exists and PyTorch's CUDA state is untouched; the
+    rings appear with the first section, on the device that is current then."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, os, sys
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO]
+import torch
+from nvrx_straggler import Detector, backend
+Detector.initialize(gather_on_rank0=True)
+out = {"engine_after_initialize": backend._backend is not None, "cuda_initialised_after_initialize": bool(torch.cuda.is_initialized()),
+       "rings_after_initialize": Detector._rings is not None}
+torch.cuda.set_device(torch.cuda.device_count() - 1)      # the LAST visible device: whatever the box has
+x = torch.randn(256, 256, device="cuda")
+for _ in range(3):
+    with Detector.detection_section("fwd", profile_cuda=True):
+        y = x @ x
+rep = Detector.generate_report()
+out["ring_device"] = int(backend.get_backend().device.index)
+out["current_device"] = int(torch.cuda.current_device())
+out["keys"] = sorted(rep.local_kernel_summaries)
+out["num"] = int(list(rep.local_section_summaries["fwd"].values())[-1])
+Detector.shutdown()
+print("RESULT " + json.dumps(out))
+'''
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "NVRX_GPU_TIMING")}
+    p = subprocess.run([sys.executable, "-c", f"REPO = {repo!r}\n" + code], capture_output=True, text=True, timeout=180, env=env)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["engine_after_initialize"] is False and out["rings_after_initialize"] is False
+    assert out["cuda_initialised_after_initialize"] is False
+    assert out["ring_device"] == out["current_device"]
+    assert out["keys"] == ["hipevent::fwd"] and out["num"] == 3

@@ -1126,3 +1126,44 @@ def test_python_summaries_builder_rejects_a_non_finite_count_like_the_c_builder(
     monkeypatch.setattr(reporting, "_pyread", None)
     with pytest.raises(ValueError):
         reporting._summaries_from_rows(rows, stats)
+
+
+def test_detector_binds_its_device_side_at_first_use_not_at_initialize():
+    """The reference's own example initialises the detector BEFORE it selects its GPU (examples/straggler/example.py:60-66:
+    ``Detector.initialize()``, ``init_process_group``, ``torch.cuda.set_device(local_rank)``).  CUPTI does not care; device
+    memory does -- rings created inside ``initialize`` would sit on GPU 0 in every rank of such a script.  So
+    ``initialize`` only checks that the engine CAN run; rings and profiler come into being at the first section / report /
+    attribute access, on the device that is current then; a detector that was never used shuts down without having
+    created anything."""
+    from nvrx_straggler import Detector, backend
+    from oracle_backend import OracleBackend
+
+    be = OracleBackend()
+    made = []
+    real = be.make_rings
+
+    def counting(*a, **k):
+        made.append(real(*a, **k))
+        return made[-1]
+
+    be.make_rings = counting
+    backend.set_backend(be)
+    try:
+        Detector.initialize(scores_to_compute="all", gather_on_rank0=False, node_name="n0")
+        assert made == [] and Detector._rings is None and Detector._cupti_manager is None   # nothing is bound yet
+        Detector.shutdown()                                                                  # ... and nothing to undo
+        assert made == []
+        Detector.initialize(scores_to_compute="all", gather_on_rank0=False, node_name="n0")
+        with Detector.detection_section("first", profile_cuda=False):
+            pass
+        assert len(made) == 1 and Detector.rings is made[0] and Detector.cupti_manager is not None
+        rep = Detector.generate_report()
+        assert list(rep.local_section_summaries) == ["first"] and len(made) == 1
+        Detector.shutdown()
+        assert Detector._rings is None
+        Detector.initialize(scores_to_compute="all", gather_on_rank0=False, node_name="n0")
+        assert Detector.rings is not None and len(made) == 2    # touching the attribute is a first use as well
+    finally:
+        if Detector.initialized:
+            Detector.shutdown()
+        backend.set_backend(None)
