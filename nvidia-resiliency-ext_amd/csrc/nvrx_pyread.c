@@ -12,6 +12,7 @@
  *   sections(names, ranks, buf, offset, n_rows, width, first_col, cols[, second_col]) -> {name: {rank: float}} (or a pair of them)
  *   ranks(ranks, buf, offset, n_rows, width, col) -> {rank: float}
  *   summaries(names, stat_keys, stats, rows) -> {name: {stat_key: float, ..., stat_keys[5]: int}}
+ *   inplace([on]) -> bool          is the in-place fill of cloned dicts active (CPython 3.10 only; see below)
  *   copy_sets(d) -> {key: set(value) for key, value in d.items()}      (fresh sets for every caller of identify_stragglers)
  *   flagged(buf, offset, rows, width, S, has_rel, has_indiv, ids, names, cols, memo) -> (gpu_rel, gpu_indiv, sec_rel, sec_indiv)
  *       the sets identify_stragglers returns, straight from the score kernel's flag bytes ([rows][2+2S] u8 at buf+offset):
@@ -34,6 +35,112 @@
 
 #define MAX_STACK_HASHES 256
 
+/* ---- filling a cloned dict in place (CPython 3.10 only, verified before every use) ---------------------------------
+ * Every inner dict of a report has the same keys: the ranks of the table, or the six Statistic members.  The fastest way
+ * the public API offers to make one is a presized dict + one insert per entry (~20 ns each: hash, probe, entry write,
+ * bookkeeping) -- 1 424 of them per report.  A clone of a TEMPLATE dict (PyDict_Copy of a dict without deletions copies
+ * the key table with one memcpy) already has the keys in place, in insertion order, in the first n entry slots; what is
+ * left is to put the values there.  That store goes through CPython 3.10's dict layout (Objects/dict-common.h,
+ * Objects/dictobject.c: struct _dictkeysobject / PyDictKeyEntry), which is private, so it is fenced three ways:
+ *   - compiled only for 3.10 (the layout changed in 3.11);
+ *   - a self-test at import builds, clones, fills and reads back a dict through the public API -- any disagreement
+ *     turns the path off for the process (NVRX_PYREAD_INPLACE=0 does the same by hand);
+ *   - before EVERY fill the clone is checked: combined table, n entries used, and the key pointer found in each of the
+ *     first n entry slots is the very key object expected there.  A layout that differs cannot pass that by accident;
+ *     a clone that fails it is filled through PyDict_SetItem instead.
+ * Values stored are floats / ints (never containers), the same as the template's None: the clone's GC state (untracked)
+ * stays right.  54 % of the time of a section mapping goes away (tools/report_read_bench.py). */
+#if PY_VERSION_HEX >= 0x030A0000 && PY_VERSION_HEX < 0x030B0000 && !defined(PYPY_VERSION)
+#define NVRX_INPLACE_POSSIBLE 1
+typedef struct {
+    Py_hash_t me_hash;
+    PyObject *me_key;
+    PyObject *me_value;
+} nvrx_dict_entry310;
+typedef struct {
+    Py_ssize_t dk_refcnt;
+    Py_ssize_t dk_size;
+    void *dk_lookup;
+    Py_ssize_t dk_usable;
+    Py_ssize_t dk_nentries;
+    char dk_indices[];
+} nvrx_dict_keys310;
+
+/* the first entry slot of a combined-table dict, or NULL when d is not one with exactly n live entries in slots 0..n-1 */
+static nvrx_dict_entry310 *inplace_entries(PyObject *d, Py_ssize_t n) {
+    PyDictObject *mp = (PyDictObject *)d;
+    if (!PyDict_CheckExact(d) || mp->ma_values != NULL || mp->ma_used != n || mp->ma_keys == NULL) return NULL;
+    nvrx_dict_keys310 *k = (nvrx_dict_keys310 *)mp->ma_keys;
+    if (k->dk_nentries != n || k->dk_size < 8 || (k->dk_size & (k->dk_size - 1)) != 0) return NULL;
+    const Py_ssize_t ix = k->dk_size <= 0xff ? 1 : k->dk_size <= 0xffff ? 2 : k->dk_size <= 0xffffffffLL ? 4 : 8;
+    return (nvrx_dict_entry310 *)(&k->dk_indices[k->dk_size * ix]);
+}
+#else
+#define NVRX_INPLACE_POSSIBLE 0
+#endif
+
+static int g_inplace = 0; /* set by the self-test at import */
+
+/* {key: None for key in keys}: the template an inner dict is cloned from */
+static PyObject *template_dict(PyObject *keys) {
+    const Py_ssize_t n = PyTuple_GET_SIZE(keys);
+    PyObject *t = NEW_DICT(n);
+    if (!t) return NULL;
+    for (Py_ssize_t i = 0; i < n; i++)
+        if (PyDict_SetItem(t, PyTuple_GET_ITEM(keys, i), Py_None) < 0) {
+            Py_DECREF(t);
+            return NULL;
+        }
+    if (PyDict_GET_SIZE(t) != n) {  /* (duplicate keys: no template) */
+        Py_DECREF(t);
+        PyErr_SetString(PyExc_ValueError, "nvrx_pyread: duplicate keys");
+        return NULL;
+    }
+    return t;
+}
+
+/* A new dict {keys[i]: values[i]} -- values are NEW references, all of them consumed whatever happens.  tmpl (may be NULL)
+ * is template_dict(keys); hashes (may be NULL) the keys' hashes. */
+static PyObject *dict_from(PyObject *keys, PyObject **values, Py_ssize_t n, PyObject *tmpl, const Py_hash_t *hashes) {
+    PyObject *d = NULL;
+    Py_ssize_t i = 0;
+    for (Py_ssize_t j = 0; j < n; j++)
+        if (!values[j]) goto fail;  /* an allocation failed upstream */
+#if NVRX_INPLACE_POSSIBLE
+    if (g_inplace && tmpl) {
+        d = PyDict_Copy(tmpl);
+        if (!d) goto fail;
+        nvrx_dict_entry310 *e = inplace_entries(d, n);
+        int ok = e != NULL;
+        for (Py_ssize_t j = 0; ok && j < n; j++) ok = e[j].me_key == PyTuple_GET_ITEM(keys, j) && e[j].me_value == Py_None;
+        if (ok) {
+            for (Py_ssize_t j = 0; j < n; j++) {
+                e[j].me_value = values[j];  /* the reference moves into the dict */
+                Py_DECREF(Py_None);
+            }
+            return d;
+        }
+        Py_CLEAR(d);  /* not the layout this was written for: the public way */
+    }
+#endif
+    d = NEW_DICT(n);
+    if (!d) goto fail;
+    for (; i < n; i++) {
+        const int rc = hashes ? SET_KNOWN(d, PyTuple_GET_ITEM(keys, i), values[i], hashes[i]) : PyDict_SetItem(d, PyTuple_GET_ITEM(keys, i), values[i]);
+        Py_DECREF(values[i]);
+        if (rc < 0) {
+            i++;
+            goto fail;
+        }
+    }
+    return d;
+fail:
+    for (; i < n; i++) Py_XDECREF(values[i]);
+    Py_XDECREF(d);
+    if (!PyErr_Occurred()) PyErr_NoMemory();
+    return NULL;
+}
+
 /* hashes of a tuple's items into out (heap-allocated beyond MAX_STACK_HASHES); NULL + exception on an unhashable key */
 static Py_hash_t *tuple_hashes(PyObject *t, Py_hash_t *stack) {
     const Py_ssize_t n = PyTuple_GET_SIZE(t);
@@ -54,33 +161,27 @@ static Py_hash_t *tuple_hashes(PyObject *t, Py_hash_t *stack) {
 
 /* one {name: {rank: float}} mapping over columns first_col + c of the [n_rows][width] f32 block p */
 static PyObject *section_mapping(const float *p, int n_rows, int width, int first_col, PyObject *names, PyObject *ranks,
-                                 const long *col, const Py_hash_t *name_hash, const Py_hash_t *rank_hash) {
+                                 const long *col, const Py_hash_t *name_hash, const Py_hash_t *rank_hash, PyObject *rank_tmpl) {
     const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
+    PyObject *stack_vals[64];
+    PyObject **vals = n_rows <= 64 ? stack_vals : PyMem_Malloc((size_t)n_rows * sizeof(PyObject *));
+    if (!vals) return PyErr_NoMemory();
     PyObject *out = NEW_DICT(n_names);
-    if (!out) return NULL;
+    if (!out) goto done;
     for (Py_ssize_t i = 0; i < n_names; i++) {
         const float *q = p + first_col + (col ? col[i] : i);
-        PyObject *d = NEW_DICT(n_rows);
-        if (!d) goto fail;
-        for (int r = 0; r < n_rows; r++) {
-            PyObject *f = PyFloat_FromDouble((double)q[(Py_ssize_t)r * width]);
-            if (!f || SET_KNOWN(d, PyTuple_GET_ITEM(ranks, r), f, rank_hash[r]) < 0) {
-                Py_XDECREF(f);
-                Py_DECREF(d);
-                goto fail;
-            }
-            Py_DECREF(f);
-        }
-        if (SET_KNOWN(out, PyTuple_GET_ITEM(names, i), d, name_hash[i]) < 0) {
-            Py_DECREF(d);
-            goto fail;
+        for (int r = 0; r < n_rows; r++) vals[r] = PyFloat_FromDouble((double)q[(Py_ssize_t)r * width]);
+        PyObject *d = dict_from(ranks, vals, n_rows, rank_tmpl, rank_hash);
+        if (!d || SET_KNOWN(out, PyTuple_GET_ITEM(names, i), d, name_hash[i]) < 0) {
+            Py_XDECREF(d);
+            Py_CLEAR(out);
+            goto done;
         }
         Py_DECREF(d);
     }
+done:
+    if (vals != stack_vals) PyMem_Free(vals);
     return out;
-fail:
-    Py_DECREF(out);
-    return NULL;
 }
 
 /* sections(names, ranks, buf, offset, n_rows, width, first_col, cols[, second_col]) -> mapping, or a pair of mappings when
@@ -94,7 +195,7 @@ static PyObject *pyread_sections(PyObject *self, PyObject *args) {
     if (!PyArg_ParseTuple(args, "O!O!y*niiiO|i", &PyTuple_Type, &names, &PyTuple_Type, &ranks, &view, &offset, &n_rows, &width, &first_col,
                           &cols, &second_col))
         return NULL;
-    PyObject *out = NULL, *a = NULL, *b = NULL;
+    PyObject *out = NULL, *a = NULL, *b = NULL, *rank_tmpl = NULL;
     Py_hash_t nh_stack[MAX_STACK_HASHES], rh_stack[MAX_STACK_HASHES], *nh = NULL, *rh = NULL;
     long col_stack[MAX_STACK_HASHES], *col = NULL;
     const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
@@ -125,10 +226,14 @@ static PyObject *pyread_sections(PyObject *self, PyObject *args) {
     }
     if (!(nh = tuple_hashes(names, nh_stack)) || !(rh = tuple_hashes(ranks, rh_stack))) goto done;
     const float *p = (const float *)((const char *)view.buf + offset);
-    a = section_mapping(p, n_rows, width, first_col, names, ranks, col, nh, rh);
+    if (g_inplace && n_rows > 0) {
+        rank_tmpl = template_dict(ranks);
+        if (!rank_tmpl) PyErr_Clear();  /* (e.g. duplicate ranks: the dicts are built entry by entry) */
+    }
+    a = section_mapping(p, n_rows, width, first_col, names, ranks, col, nh, rh, rank_tmpl);
     if (!a) goto done;
     if (second_col >= 0) {
-        b = section_mapping(p, n_rows, width, second_col, names, ranks, col, nh, rh);
+        b = section_mapping(p, n_rows, width, second_col, names, ranks, col, nh, rh, rank_tmpl);
         if (!b) goto done;
         out = PyTuple_Pack(2, a, b);
     } else {
@@ -138,6 +243,7 @@ static PyObject *pyread_sections(PyObject *self, PyObject *args) {
 done:
     Py_XDECREF(a);
     Py_XDECREF(b);
+    Py_XDECREF(rank_tmpl);
     if (nh && nh != nh_stack) PyMem_Free(nh);
     if (rh && rh != rh_stack) PyMem_Free(rh);
     if (col && col != col_stack) PyMem_Free(col);
@@ -179,7 +285,7 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
     PyObject *names, *keys, *rows;
     Py_buffer view;
     if (!PyArg_ParseTuple(args, "O!O!y*O!", &PyTuple_Type, &names, &PyTuple_Type, &keys, &view, &PyTuple_Type, &rows)) return NULL;
-    PyObject *out = NULL;
+    PyObject *out = NULL, *key_tmpl = NULL;
     Py_hash_t kh[6];
     const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
     const Py_ssize_t total_rows = view.len / (Py_ssize_t)(8 * sizeof(float));
@@ -193,6 +299,10 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
     }
     out = NEW_DICT(n_names);
     if (!out) goto done;
+    if (g_inplace) {
+        key_tmpl = template_dict(keys);
+        if (!key_tmpl) PyErr_Clear();
+    }
     const float *p = (const float *)view.buf;
     for (Py_ssize_t i = 0; i < n_names; i++) {
         const long row = PyLong_AsLong(PyTuple_GET_ITEM(rows, i));
@@ -202,20 +312,13 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
             goto fail;
         }
         const float *v = p + row * 8;
-        PyObject *d = NEW_DICT(6);
+        PyObject *vals[6];
+        /* NUM (column 5) is an integer in the reference's summaries (straggler.py:194); a NUM that is not a finite number
+         * cannot come out of the statistics kernel: ValueError / OverflowError from PyLong_FromDouble, the same exceptions
+         * the Python builder raises */
+        for (int k = 0; k < 6; k++) vals[k] = k == 5 ? PyLong_FromDouble((double)v[k]) : PyFloat_FromDouble((double)v[k]);
+        PyObject *d = dict_from(keys, vals, 6, key_tmpl, kh);
         if (!d) goto fail;
-        for (int k = 0; k < 6; k++) {
-            /* NUM (column 5) is an integer in the reference's summaries (straggler.py:194); a NUM that is not a finite
-             * number cannot come out of the statistics kernel: ValueError / OverflowError from PyLong_FromDouble, the
-             * same exceptions the Python builder raises */
-            PyObject *x = k == 5 ? PyLong_FromDouble((double)v[k]) : PyFloat_FromDouble((double)v[k]);
-            if (!x || SET_KNOWN(d, PyTuple_GET_ITEM(keys, k), x, kh[k]) < 0) {
-                Py_XDECREF(x);
-                Py_DECREF(d);
-                goto fail;
-            }
-            Py_DECREF(x);
-        }
         if (PyDict_SetItem(out, PyTuple_GET_ITEM(names, i), d) < 0) {
             Py_DECREF(d);
             goto fail;
@@ -226,6 +329,7 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
 fail:
     Py_CLEAR(out);
 done:
+    Py_XDECREF(key_tmpl);
     PyBuffer_Release(&view);
     return out;
 }
@@ -382,7 +486,75 @@ done:
     return result;
 }
 
+/* Self-test of the in-place fill (import time): a dict of eight int keys and one of six str keys, cloned, filled and read
+ * back through the public API, then used as a normal dict (insert, delete, compare).  1 = every check agreed. */
+static int inplace_self_test(void) {
+#if NVRX_INPLACE_POSSIBLE
+    int ok = 0;
+    PyObject *keys = NULL, *tmpl = NULL, *d = NULL, *ref = NULL, *vals[8];
+    const int saved = g_inplace;
+    for (int pass = 0; pass < 2; pass++) {
+        const Py_ssize_t n = pass ? 6 : 8;
+        keys = PyTuple_New(n);
+        if (!keys) goto out;
+        for (Py_ssize_t i = 0; i < n; i++) {
+            PyObject *k = pass ? PyUnicode_FromFormat("key%zd", i) : PyLong_FromSsize_t(i * 1000003 + 7);
+            if (!k) goto out;
+            PyTuple_SET_ITEM(keys, i, k);
+        }
+        tmpl = template_dict(keys);
+        ref = PyDict_New();
+        if (!tmpl || !ref) goto out;
+        for (Py_ssize_t i = 0; i < n; i++) {
+            vals[i] = PyFloat_FromDouble(0.5 + (double)i);
+            if (!vals[i] || PyDict_SetItem(ref, PyTuple_GET_ITEM(keys, i), vals[i]) < 0) goto out;
+        }
+        g_inplace = 1;
+        if (inplace_entries(tmpl, n) == NULL) goto out;  /* the template itself must look as expected */
+        d = dict_from(keys, vals, n, tmpl, NULL);        /* consumes vals */
+        if (!d || PyDict_GET_SIZE(d) != n || PyObject_RichCompareBool(d, ref, Py_EQ) != 1) goto out;
+        Py_ssize_t pos = 0, seen = 0;
+        PyObject *k, *v;
+        while (PyDict_Next(d, &pos, &k, &v)) {           /* insertion order, the very objects */
+            if (k != PyTuple_GET_ITEM(keys, seen) || v != PyDict_GetItem(ref, k)) goto out;
+            seen++;
+        }
+        if (seen != n) goto out;
+        for (Py_ssize_t i = 0; i < n; i++)                /* the template is untouched */
+            if (PyDict_GetItem(tmpl, PyTuple_GET_ITEM(keys, i)) != Py_None) goto out;
+        /* ... and the filled clone behaves: grows, shrinks, compares */
+        if (PyDict_SetItemString(d, "extra", Py_True) < 0 || PyDict_GET_SIZE(d) != n + 1) goto out;
+        if (PyDict_DelItemString(d, "extra") < 0 || PyObject_RichCompareBool(d, ref, Py_EQ) != 1) goto out;
+        if (PyDict_DelItem(d, PyTuple_GET_ITEM(keys, 0)) < 0 || PyDict_GET_SIZE(d) != n - 1) goto out;
+        Py_CLEAR(keys);
+        Py_CLEAR(tmpl);
+        Py_CLEAR(d);
+        Py_CLEAR(ref);
+    }
+    ok = 1;
+out:
+    if (PyErr_Occurred()) PyErr_Clear();
+    Py_XDECREF(keys);
+    Py_XDECREF(tmpl);
+    Py_XDECREF(d);
+    Py_XDECREF(ref);
+    g_inplace = saved;
+    return ok;
+#else
+    return 0;
+#endif
+}
+
+static PyObject *pyread_inplace(PyObject *self, PyObject *args) {
+    int want = -1;
+    if (!PyArg_ParseTuple(args, "|i", &want)) return NULL;
+    if (want == 0) g_inplace = 0;
+    if (want > 0) g_inplace = inplace_self_test();
+    return PyBool_FromLong(g_inplace);
+}
+
 static PyMethodDef pyread_methods[] = {
+    {"inplace", pyread_inplace, METH_VARARGS, "inplace([on]) -> bool: is the in-place fill of cloned dicts active (0 turns it off, 1 re-runs the self-test)"},
     {"flagged", pyread_flagged, METH_VARARGS, "the sets of identify_stragglers from the score kernel's flag bytes"},
     {"sections", pyread_sections, METH_VARARGS, "section -> {rank -> score} from an f32 score block (one or both score families)"},
     {"ranks", pyread_ranks, METH_VARARGS, "rank -> score: one column of an f32 score block"},
@@ -394,4 +566,10 @@ static PyMethodDef pyread_methods[] = {
 static struct PyModuleDef pyread_module = {PyModuleDef_HEAD_INIT, "_nvrx_pyread", "dict builders of the straggler Report", -1,
                                            pyread_methods};
 
-PyMODINIT_FUNC PyInit__nvrx_pyread(void) { return PyModule_Create(&pyread_module); }
+PyMODINIT_FUNC PyInit__nvrx_pyread(void) {
+    PyObject *m = PyModule_Create(&pyread_module);
+    if (!m) return NULL;
+    const char *e = getenv("NVRX_PYREAD_INPLACE");
+    g_inplace = (e && e[0] == '0') ? 0 : inplace_self_test();
+    return m;
+}

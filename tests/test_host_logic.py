@@ -1167,3 +1167,61 @@ def test_detector_binds_its_device_side_at_first_use_not_at_initialize():
         if Detector.initialized:
             Detector.shutdown()
         backend.set_backend(None)
+
+
+def test_inplace_filled_dicts_are_ordinary_dicts():
+    """``_nvrx_pyread`` fills CLONED dicts in place where it can (CPython 3.10: a clone of a template dict already holds
+    the keys; the values are stored straight into its entries -- private layout, checked by a self-test at import and
+    before every fill).  What comes out must be indistinguishable from the dicts built insert by insert: same contents
+    and order, picklable / deep-copyable / JSON-serialisable, free to grow, shrink and be collected."""
+    import copy
+    import gc
+    import json
+
+    from nvrx_straggler import Statistic, reporting
+    from nvrx_straggler.statistics import STAT_KEYS
+
+    pr = reporting._pyread
+    assert pr is not None
+    was = pr.inplace()
+    rng = np.random.default_rng(5)
+    R, S = 8, 64
+    W = 2 + 2 * S
+    scores = rng.uniform(0.5, 1.0, (R, W)).astype(np.float32)
+    stats = rng.uniform(1.0, 2.0, (S, 8)).astype(np.float32)
+    stats[:, 5] = rng.integers(1, 10000, S)
+    names = tuple(f"section_{i:03d}" for i in range(S))
+    ranks = tuple(range(R))
+    rows = tuple(range(S))
+    try:
+        pr.inplace(0)
+        plain = (pr.sections(names, ranks, scores, 0, R, W, 2, None, 2 + S), pr.summaries(names, STAT_KEYS, stats, rows))
+        if not pr.inplace(1):
+            pytest.skip("the in-place fill is not available on this interpreter (it is compiled for CPython 3.10 only)")
+        fast = (pr.sections(names, ranks, scores, 0, R, W, 2, None, 2 + S), pr.summaries(names, STAT_KEYS, stats, rows))
+        assert fast == plain
+        for a, b in ((fast[0][0], plain[0][0]), (fast[0][1], plain[0][1]), (fast[1], plain[1])):
+            assert list(a) == list(b)
+            for k in a:
+                assert type(a[k]) is dict and list(a[k]) == list(b[k]) and [type(v) for v in a[k].values()] == [type(v) for v in b[k].values()]
+        assert type(fast[1][names[0]][Statistic.NUM]) is int
+        assert pickle.loads(pickle.dumps(fast)) == plain and copy.deepcopy(fast) == plain
+        assert json.loads(json.dumps(fast[0][0])) == json.loads(json.dumps(plain[0][0]))
+        inner = fast[0][0][names[3]]
+        inner[99] = 1.5                       # grows (a resize of the cloned key table) ...
+        for r in range(4):
+            del inner[r]                      # ... shrinks ...
+        inner.update({r: 0.25 for r in range(100, 140)})
+        assert len(inner) == 45 and inner[7] == plain[0][0][names[3]][7] and inner[120] == 0.25
+        inner["self"] = inner                 # ... and a cycle through it is collectable
+        del inner, fast
+        gc.collect()
+        many = [pr.sections(names, ranks, scores, 0, R, W, 2, None) for _ in range(200)]   # clones of one template per call
+        assert all(m == plain[0][0] for m in many[::37])
+        del many
+        gc.collect()
+        # keys that cannot share a template (duplicates) still come out right, the public way
+        dup = pr.sections(("a", "b"), (0, 0, 1), scores[:3], 0, 3, W, 2, None)
+        assert dup == {"a": {0: float(scores[1, 2]), 1: float(scores[2, 2])}, "b": {0: float(scores[1, 3]), 1: float(scores[2, 3])}}
+    finally:
+        pr.inplace(1 if was else 0)
