@@ -101,7 +101,7 @@ static PyObject *template_dict(PyObject *keys) {
 
 /* A new dict {keys[i]: values[i]} -- values are NEW references, all of them consumed whatever happens.  tmpl (may be NULL)
  * is template_dict(keys); hashes (may be NULL) the keys' hashes. */
-static PyObject *dict_from(PyObject *keys, PyObject **values, Py_ssize_t n, PyObject *tmpl, const Py_hash_t *hashes) {
+static PyObject *dict_from(PyObject *keys, PyObject **values, Py_ssize_t n, PyObject *tmpl, const Py_hash_t *hashes, int values_are_containers) {
     PyObject *d = NULL;
     Py_ssize_t i = 0;
     for (Py_ssize_t j = 0; j < n; j++)
@@ -118,6 +118,9 @@ static PyObject *dict_from(PyObject *keys, PyObject **values, Py_ssize_t n, PyOb
                 e[j].me_value = values[j];  /* the reference moves into the dict */
                 Py_DECREF(Py_None);
             }
+            /* a dict that holds containers must be known to the collector (PyDict_SetItem does this when it stores one;
+             * the clone of a template of Nones starts out untracked) */
+            if (values_are_containers && !PyObject_GC_IsTracked(d)) PyObject_GC_Track(d);
             return d;
         }
         Py_CLEAR(d);  /* not the layout this was written for: the public way */
@@ -159,28 +162,33 @@ static Py_hash_t *tuple_hashes(PyObject *t, Py_hash_t *stack) {
     return h;
 }
 
-/* one {name: {rank: float}} mapping over columns first_col + c of the [n_rows][width] f32 block p */
+/* one {name: {rank: float}} mapping over columns first_col + c of the [n_rows][width] f32 block p; name_tmpl (may be NULL):
+ * {name: None for name in names}, kept by the caller across reports -- the outer dict is then a filled clone as well */
 static PyObject *section_mapping(const float *p, int n_rows, int width, int first_col, PyObject *names, PyObject *ranks,
-                                 const long *col, const Py_hash_t *name_hash, const Py_hash_t *rank_hash, PyObject *rank_tmpl) {
+                                 const long *col, const Py_hash_t *name_hash, const Py_hash_t *rank_hash, PyObject *rank_tmpl,
+                                 PyObject *name_tmpl) {
     const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
-    PyObject *stack_vals[64];
+    PyObject *stack_vals[64], *stack_inner[MAX_STACK_HASHES];
     PyObject **vals = n_rows <= 64 ? stack_vals : PyMem_Malloc((size_t)n_rows * sizeof(PyObject *));
-    if (!vals) return PyErr_NoMemory();
-    PyObject *out = NEW_DICT(n_names);
-    if (!out) goto done;
+    PyObject **inner = n_names <= MAX_STACK_HASHES ? stack_inner : PyMem_Malloc((size_t)n_names * sizeof(PyObject *));
+    PyObject *out = NULL;
+    if (!vals || !inner) {
+        PyErr_NoMemory();
+        goto done;
+    }
     for (Py_ssize_t i = 0; i < n_names; i++) {
         const float *q = p + first_col + (col ? col[i] : i);
         for (int r = 0; r < n_rows; r++) vals[r] = PyFloat_FromDouble((double)q[(Py_ssize_t)r * width]);
-        PyObject *d = dict_from(ranks, vals, n_rows, rank_tmpl, rank_hash);
-        if (!d || SET_KNOWN(out, PyTuple_GET_ITEM(names, i), d, name_hash[i]) < 0) {
-            Py_XDECREF(d);
-            Py_CLEAR(out);
+        inner[i] = dict_from(ranks, vals, n_rows, rank_tmpl, rank_hash, 0);
+        if (!inner[i]) {
+            for (Py_ssize_t j = 0; j < i; j++) Py_DECREF(inner[j]);
             goto done;
         }
-        Py_DECREF(d);
     }
+    out = dict_from(names, inner, n_names, name_tmpl, name_hash, 1);  /* consumes the inner dicts */
 done:
-    if (vals != stack_vals) PyMem_Free(vals);
+    if (vals && vals != stack_vals) PyMem_Free(vals);
+    if (inner && inner != stack_inner) PyMem_Free(inner);
     return out;
 }
 
@@ -192,9 +200,11 @@ static PyObject *pyread_sections(PyObject *self, PyObject *args) {
     Py_buffer view;
     Py_ssize_t offset;
     int n_rows, width, first_col, second_col = -1;
-    if (!PyArg_ParseTuple(args, "O!O!y*niiiO|i", &PyTuple_Type, &names, &PyTuple_Type, &ranks, &view, &offset, &n_rows, &width, &first_col,
-                          &cols, &second_col))
+    PyObject *name_tmpl = Py_None;
+    if (!PyArg_ParseTuple(args, "O!O!y*niiiO|iO", &PyTuple_Type, &names, &PyTuple_Type, &ranks, &view, &offset, &n_rows, &width, &first_col,
+                          &cols, &second_col, &name_tmpl))
         return NULL;
+    if (name_tmpl == Py_None || !PyDict_CheckExact(name_tmpl)) name_tmpl = NULL;
     PyObject *out = NULL, *a = NULL, *b = NULL, *rank_tmpl = NULL;
     Py_hash_t nh_stack[MAX_STACK_HASHES], rh_stack[MAX_STACK_HASHES], *nh = NULL, *rh = NULL;
     long col_stack[MAX_STACK_HASHES], *col = NULL;
@@ -230,10 +240,10 @@ static PyObject *pyread_sections(PyObject *self, PyObject *args) {
         rank_tmpl = template_dict(ranks);
         if (!rank_tmpl) PyErr_Clear();  /* (e.g. duplicate ranks: the dicts are built entry by entry) */
     }
-    a = section_mapping(p, n_rows, width, first_col, names, ranks, col, nh, rh, rank_tmpl);
+    a = section_mapping(p, n_rows, width, first_col, names, ranks, col, nh, rh, rank_tmpl, name_tmpl);
     if (!a) goto done;
     if (second_col >= 0) {
-        b = section_mapping(p, n_rows, width, second_col, names, ranks, col, nh, rh, rank_tmpl);
+        b = section_mapping(p, n_rows, width, second_col, names, ranks, col, nh, rh, rank_tmpl, name_tmpl);
         if (!b) goto done;
         out = PyTuple_Pack(2, a, b);
     } else {
@@ -284,8 +294,10 @@ done:
 static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
     PyObject *names, *keys, *rows;
     Py_buffer view;
-    if (!PyArg_ParseTuple(args, "O!O!y*O!", &PyTuple_Type, &names, &PyTuple_Type, &keys, &view, &PyTuple_Type, &rows)) return NULL;
-    PyObject *out = NULL, *key_tmpl = NULL;
+    PyObject *name_tmpl = Py_None;
+    if (!PyArg_ParseTuple(args, "O!O!y*O!|O", &PyTuple_Type, &names, &PyTuple_Type, &keys, &view, &PyTuple_Type, &rows, &name_tmpl)) return NULL;
+    if (name_tmpl == Py_None || !PyDict_CheckExact(name_tmpl)) name_tmpl = NULL;
+    PyObject *out = NULL, *key_tmpl = NULL, *stack_inner[MAX_STACK_HASHES], **inner = NULL;
     Py_hash_t kh[6];
     const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
     const Py_ssize_t total_rows = view.len / (Py_ssize_t)(8 * sizeof(float));
@@ -297,15 +309,19 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
         kh[k] = PyObject_Hash(PyTuple_GET_ITEM(keys, k));
         if (kh[k] == -1 && PyErr_Occurred()) goto done;
     }
-    out = NEW_DICT(n_names);
-    if (!out) goto done;
     if (g_inplace) {
         key_tmpl = template_dict(keys);
         if (!key_tmpl) PyErr_Clear();
     }
+    inner = n_names <= MAX_STACK_HASHES ? stack_inner : PyMem_Malloc((size_t)n_names * sizeof(PyObject *));
+    if (!inner) {
+        PyErr_NoMemory();
+        goto done;
+    }
     const float *p = (const float *)view.buf;
-    for (Py_ssize_t i = 0; i < n_names; i++) {
-        const long row = PyLong_AsLong(PyTuple_GET_ITEM(rows, i));
+    Py_ssize_t built = 0;
+    for (; built < n_names; built++) {
+        const long row = PyLong_AsLong(PyTuple_GET_ITEM(rows, built));
         if (row == -1 && PyErr_Occurred()) goto fail;
         if (row < 0 || row >= total_rows) {
             PyErr_SetString(PyExc_ValueError, "nvrx_pyread.summaries: row out of range");
@@ -317,18 +333,15 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
          * cannot come out of the statistics kernel: ValueError / OverflowError from PyLong_FromDouble, the same exceptions
          * the Python builder raises */
         for (int k = 0; k < 6; k++) vals[k] = k == 5 ? PyLong_FromDouble((double)v[k]) : PyFloat_FromDouble((double)v[k]);
-        PyObject *d = dict_from(keys, vals, 6, key_tmpl, kh);
-        if (!d) goto fail;
-        if (PyDict_SetItem(out, PyTuple_GET_ITEM(names, i), d) < 0) {
-            Py_DECREF(d);
-            goto fail;
-        }
-        Py_DECREF(d);
+        inner[built] = dict_from(keys, vals, 6, key_tmpl, kh, 0);
+        if (!inner[built]) goto fail;
     }
+    out = dict_from(names, inner, n_names, name_tmpl, NULL, 1);  /* consumes the inner dicts */
     goto done;
 fail:
-    Py_CLEAR(out);
+    for (Py_ssize_t j = 0; j < built; j++) Py_DECREF(inner[j]);
 done:
+    if (inner && inner != stack_inner) PyMem_Free(inner);
     Py_XDECREF(key_tmpl);
     PyBuffer_Release(&view);
     return out;
@@ -511,7 +524,7 @@ static int inplace_self_test(void) {
         }
         g_inplace = 1;
         if (inplace_entries(tmpl, n) == NULL) goto out;  /* the template itself must look as expected */
-        d = dict_from(keys, vals, n, tmpl, NULL);        /* consumes vals */
+        d = dict_from(keys, vals, n, tmpl, NULL, 0);     /* consumes vals */
         if (!d || PyDict_GET_SIZE(d) != n || PyObject_RichCompareBool(d, ref, Py_EQ) != 1) goto out;
         Py_ssize_t pos = 0, seen = 0;
         PyObject *k, *v;

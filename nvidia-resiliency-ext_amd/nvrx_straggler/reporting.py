@@ -111,7 +111,7 @@ def _row_selector(rows: Mapping[str, int]):
     return np.asarray(idx, dtype=np.intp)
 
 
-def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray, selector=None) -> Dict[str, Dict[Statistic, Any]]:
+def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray, selector=None, name_template=None) -> Dict[str, Dict[Statistic, Any]]:
     """``name -> {Statistic: value}`` from device statistics rows (``_get_section_summaries``' result shape,
     straggler.py:185-195), NUM as an integer as in the reference (straggler.py:194).  Built by ``_nvrx_pyread`` when it
     is there; else one C-level conversion of the whole block and one ``dict(zip(keys, row))`` per name (``Statistic``
@@ -119,7 +119,7 @@ def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray, selector=No
     if not rows:
         return {}
     if _pyread is not None and stats.dtype == np.float32 and stats.flags.c_contiguous and stats.shape[1] == 8:
-        return _pyread.summaries(tuple(rows), STAT_KEYS, stats, tuple(rows.values()))
+        return _pyread.summaries(tuple(rows), STAT_KEYS, stats, tuple(rows.values()), name_template)
     block = stats[_row_selector(rows) if selector is None else selector]
     vals = block[:, : NUM_COLUMN + 1].tolist()
     out = dict(zip(rows, map(dict, map(zip, itertools.repeat(STAT_KEYS), vals))))
@@ -277,6 +277,17 @@ class _View:
     def col_tuple(self):
         self.rank_tuple()
         return self._tuples[2]
+
+    def name_template(self, which: str = "names"):
+        """``{name: None}`` over the view's section names (``names``) or over the names of its section / kernel rows:
+        ``_nvrx_pyread`` clones it for the outer dict of a mapping instead of inserting the names one by one (the template
+        itself is never handed out and never modified)."""
+        try:
+            return self._memo[("tmpl", which)]
+        except (AttributeError, KeyError):
+            src = self.names if which == "names" else getattr(self, which)
+            t = self.memo()[("tmpl", which)] = dict.fromkeys(src)
+            return t
 
     def col_index(self):
         """Score-table column of every name of ``names``, in that order (None: the identity)."""
@@ -436,14 +447,16 @@ class _ScoreSource:
             other = "section_individual_perf_scores" if rel else "section_relative_perf_scores"
             if fast and stash is not None and other not in stash and (v.has_indiv if rel else v.has_rel):
                 mine, sibling = _pyread.sections(v.names_tuple(), v.rank_tuple(), sc, 0, sc.shape[0], sc.shape[1],
-                                                 2 + S if rel else 2, v.col_tuple(), 2 if rel else 2 + S)
+                                                 2 + S if rel else 2, v.col_tuple(), 2 if rel else 2 + S, v.name_template())
                 stash[other] = sibling
                 return mine
             return self._sections(2 + S if rel else 2)
         if field == "local_section_summaries":
-            return _summaries_from_rows(v.section_rows, self.statistics(), v.selector("section_rows")) if v.section_rows else {}
+            return (_summaries_from_rows(v.section_rows, self.statistics(), v.selector("section_rows"), v.name_template("section_rows"))
+                    if v.section_rows else {})
         if field == "local_kernel_summaries":
-            return _summaries_from_rows(v.kernel_rows, self.statistics(), v.selector("kernel_rows")) if v.kernel_rows else {}
+            return (_summaries_from_rows(v.kernel_rows, self.statistics(), v.selector("kernel_rows"), v.name_template("kernel_rows"))
+                    if v.kernel_rows else {})
         raise AttributeError(field)
 
     def _sections(self, first_col: int) -> Dict[str, Dict[int, float]]:
@@ -454,7 +467,8 @@ class _ScoreSource:
         sc = self.scores
         idx = v.col_index()
         if _pyread is not None and sc.dtype == np.float32 and sc.flags.c_contiguous:
-            return _pyread.sections(v.names_tuple(), v.rank_tuple(), sc, 0, sc.shape[0], sc.shape[1], first_col, v.col_tuple())
+            return _pyread.sections(v.names_tuple(), v.rank_tuple(), sc, 0, sc.shape[0], sc.shape[1], first_col, v.col_tuple(), -1,
+                                    v.name_template())
         block = sc[:, first_col : first_col + v.S].T
         if idx is not None:
             block = block[idx]

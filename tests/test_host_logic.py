@@ -1200,6 +1200,16 @@ def test_inplace_filled_dicts_are_ordinary_dicts():
             pytest.skip("the in-place fill is not available on this interpreter (it is compiled for CPython 3.10 only)")
         fast = (pr.sections(names, ranks, scores, 0, R, W, 2, None, 2 + S), pr.summaries(names, STAT_KEYS, stats, rows))
         assert fast == plain
+        # with the caller's name template the OUTER dicts are filled clones too -- and, holding dicts, known to the collector
+        tmpl = dict.fromkeys(names)
+        outer = (pr.sections(names, ranks, scores, 0, R, W, 2, None, 2 + S, tmpl), pr.summaries(names, STAT_KEYS, stats, rows, tmpl))
+        assert outer == plain and all(v is None for v in tmpl.values()) and list(outer[1]) == list(names)
+        assert gc.is_tracked(outer[0][0]) and gc.is_tracked(outer[0][1]) and gc.is_tracked(outer[1])
+        # inner dicts are tracked exactly when a dict built insert by insert would be (int -> float: no; enum member -> number: yes)
+        assert gc.is_tracked(outer[0][0][names[0]]) == gc.is_tracked(plain[0][0][names[0]]) == False  # noqa: E712
+        assert gc.is_tracked(outer[1][names[0]]) == gc.is_tracked(plain[1][names[0]])
+        stale = dict.fromkeys(names[:-1])                     # a template that does not fit is ignored, not trusted
+        assert pr.summaries(names, STAT_KEYS, stats, rows, stale) == plain[1]
         for a, b in ((fast[0][0], plain[0][0]), (fast[0][1], plain[0][1]), (fast[1], plain[1])):
             assert list(a) == list(b)
             for k in a:
