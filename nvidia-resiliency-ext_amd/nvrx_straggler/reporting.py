@@ -343,11 +343,28 @@ class _ScoreSource:
             self.stats = blob[off_t : off_t + stats_rows * 32].view(np.float32).reshape(stats_rows, 8)
 
     def statistics(self) -> np.ndarray:
-        self.ensure()
         st = self.stats
+        if st is None:
+            pend = self.pending
+            if self.scores is None and type(pend) is _LiveBlock:
+                st = pend  # (a live block hands its statistics rows out on their own: no cut of the head needed for them)
+            else:
+                self.ensure()
+                st = self.stats
         if type(st) is _LiveBlock:
             st = self.stats = st.stats()
         return st
+
+    def raw_scores(self):
+        """``(buffer, byte offset, rows, width)`` of this report's score rows for ``_nvrx_pyread`` -- for a live block its
+        ``bytes`` copy of the head, addressed by offset: no numpy view is cut for a report whose mappings are built in C."""
+        if self.scores is None and type(self.pending) is _LiveBlock:
+            off_s, _, _, _, W, lo, hi, _ = self.view.layout
+            return self.pending.head_bytes(), off_s + lo * W * 4, hi - lo, W
+        sc = self.ensure().scores
+        if sc.dtype == np.float32 and sc.flags.c_contiguous:
+            return sc, 0, sc.shape[0], sc.shape[1]
+        return None
 
     def ensure(self) -> "_ScoreSource":
         if self.scores is None:
@@ -428,17 +445,20 @@ class _ScoreSource:
     def build(self, field: str, stash: Optional[dict] = None):
         """One of the six mappings as a plain dict.  ``stash``: the report's ``__dict__`` -- a call that can build a
         sibling in the same pass (both section-score families share names, ranks and hashes) leaves it there."""
-        self.ensure()
         v = self.view
         S = v.S
-        sc = self.scores
-        fast = _pyread is not None and sc.dtype == np.float32 and sc.flags.c_contiguous
+        raw = self.raw_scores() if _pyread is not None else None
+        fast = raw is not None
+        if fast:
+            buf, off, nrows, W = raw
+        else:
+            sc = self.ensure().scores
         if field == "gpu_relative_perf_scores" or field == "gpu_individual_perf_scores":
             col = 1 if field == "gpu_relative_perf_scores" else 0
             if not (v.has_rel if col else v.has_indiv):
                 return {}
             if fast:
-                return _pyread.ranks(v.rank_tuple(), sc, 0, sc.shape[0], sc.shape[1], col)
+                return _pyread.ranks(v.rank_tuple(), buf, off, nrows, W, col)
             return dict(zip(v.ranks, sc[:, col].tolist()))
         if field == "section_relative_perf_scores" or field == "section_individual_perf_scores":
             rel = field == "section_relative_perf_scores"
@@ -446,10 +466,13 @@ class _ScoreSource:
                 return {}
             other = "section_individual_perf_scores" if rel else "section_relative_perf_scores"
             if fast and stash is not None and other not in stash and (v.has_indiv if rel else v.has_rel):
-                mine, sibling = _pyread.sections(v.names_tuple(), v.rank_tuple(), sc, 0, sc.shape[0], sc.shape[1],
+                mine, sibling = _pyread.sections(v.names_tuple(), v.rank_tuple(), buf, off, nrows, W,
                                                  2 + S if rel else 2, v.col_tuple(), 2 if rel else 2 + S, v.name_template())
                 stash[other] = sibling
                 return mine
+            if fast:
+                return _pyread.sections(v.names_tuple(), v.rank_tuple(), buf, off, nrows, W, 2 + S if rel else 2, v.col_tuple(), -1,
+                                        v.name_template())
             return self._sections(2 + S if rel else 2)
         if field == "local_section_summaries":
             return (_summaries_from_rows(v.section_rows, self.statistics(), v.selector("section_rows"), v.name_template("section_rows"))
