@@ -1235,3 +1235,57 @@ def test_inplace_filled_dicts_are_ordinary_dicts():
         assert dup == {"a": {0: float(scores[1, 2]), 1: float(scores[2, 2])}, "b": {0: float(scores[1, 3]), 1: float(scores[2, 3])}}
     finally:
         pr.inplace(1 if was else 0)
+
+
+@pytest.mark.parametrize("R,S", [(1, 1), (3, 7), (70, 5), (9, 300), (70, 300)])
+def test_c_builders_beyond_their_stack_buffers(R, S):
+    """``_nvrx_pyread`` keeps its per-call scratch (values of one inner dict, hashes, column table) on the stack up to 64
+    ranks / 256 names and on the heap beyond: both sides of both limits must give what the Python builders give, with the
+    in-place fill on and off, for the identity column order and a permuted one."""
+    from nvrx_straggler import reporting
+    from nvrx_straggler.statistics import STAT_KEYS
+
+    pr = reporting._pyread
+    assert pr is not None
+    was = pr.inplace()
+    rng = np.random.default_rng(R * 1000 + S)
+    W = 2 + 2 * S
+    scores = rng.uniform(0.1, 1.0, (R, W)).astype(np.float32)
+    scores[rng.integers(0, R), rng.integers(0, W)] = np.nan
+    stats = rng.uniform(1.0, 9.0, (S, 8)).astype(np.float32)
+    stats[:, 5] = rng.integers(1, 60000, S)
+    names = tuple(f"s{i}" for i in range(S))
+    ranks = tuple(range(100, 100 + R))
+    perm = tuple(int(i) for i in rng.permutation(S))
+    rows = tuple(int(i) for i in rng.permutation(S))
+
+    def expect_sections(first, cols):
+        return {n: {ranks[r]: float(scores[r, first + (cols[i] if cols else i)]) for r in range(R)} for i, n in enumerate(names)}
+
+    def same(a, b):
+        assert list(a) == list(b)
+        for k in a:
+            assert list(a[k]) == list(b[k])
+            for kk in a[k]:
+                x, y = a[k][kk], b[k][kk]
+                assert type(x) is type(y) and (x == y or (x != x and y != y)), (k, kk, x, y)
+
+    try:
+        for on in (0, 1):
+            pr.inplace(on)
+            for cols in (None, perm):
+                one = pr.sections(names, ranks, scores, 0, R, W, 2, cols)
+                same(one, expect_sections(2, cols))
+                a, b = pr.sections(names, ranks, scores, 0, R, W, 2, cols, 2 + S, dict.fromkeys(names))
+                same(a, expect_sections(2, cols))
+                same(b, expect_sections(2 + S, cols))
+            got = pr.summaries(names, STAT_KEYS, stats, rows, dict.fromkeys(names))
+            exp = {n: {k: (int(stats[rows[i], j]) if j == 5 else float(stats[rows[i], j])) for j, k in enumerate(STAT_KEYS)} for i, n in enumerate(names)}
+            same(got, exp)
+            col0 = pr.ranks(ranks, scores, 0, R, W, 1)
+            assert list(col0) == list(ranks) and all((col0[ranks[r]] == float(scores[r, 1])) or scores[r, 1] != scores[r, 1] for r in range(R))
+            # an offset into a larger buffer (the live result block is addressed this way)
+            blob = b"\x00" * 64 + scores.tobytes()
+            same(pr.sections(names, ranks, blob, 64, R, W, 2, None), expect_sections(2, None))
+    finally:
+        pr.inplace(1 if was else 0)
