@@ -279,3 +279,22 @@ def test_a_misbehaving_exchange_route_is_dropped_by_every_rank_together(fault):
         assert out["first_report_s"] < 20.0, (fault, r, out["first_report_s"]) # nobody sat out a long wait
         for t in range(len(sc["steps"])):
             compare_reports(out["reports"][t], g["per_rank"][r]["reports"][t], (fault, r, t))
+
+
+def test_auto_selection_keeps_the_route_that_is_right_when_the_other_one_is_not():
+    """``NVRX_EXCHANGE=auto`` times and CHECKS both in-stream routes and keeps the faster one that delivered the right table on
+    every rank.  Here the RCCL slot holds an exchange that corrupts the table on one rank, next to working peer windows:
+    every rank must end up on the windows (not on the faster-looking broken route, not on torch.distributed), and the
+    reports must be the reference's."""
+    g = next(s for s in _SCENARIOS if s["scenario"]["name"] == "sections_2ranks_gather1")
+    sc = g["scenario"]
+    env = {"NVRX_EXCHANGE": "auto", "NVRX_TRIAL_TIMEOUT_S": "2", "NVRX_PEER_TRIAL_TIMEOUT_S": "2", "NVRX_REPORT_TIMEOUT_S": "30"}
+    res = run_ranks(workers.route_fault_injection, sc["world_size"], timeout=300, use_oracle_backend=False, device=0, env=env,
+                    fault="wrong_table", scenario=sc)
+    for r in range(sc["world_size"]):
+        out = res[r]
+        assert out["direct"] is True and "peer" in out["info"].get("route", "").lower() or "window" in out["info"].get("route", "").lower(), (r, out["info"])
+        assert out["info"].get("rccl_ok") is False and out["info"].get("peer_ok") is True, (r, out["info"])
+        assert out["state"]["closed"] + out["state"]["aborted"] == 1          # the broken route was given up
+        for t in range(len(sc["steps"])):
+            compare_reports(out["reports"][t], g["per_rank"][r]["reports"][t], ("auto", r, t))
