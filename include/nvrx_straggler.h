@@ -129,7 +129,8 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
 int nvrx_ctx_destroy(nvrx_ctx *ctx);
 /* Stream used for flushes triggered implicitly by a full staging buffer (default: null stream). */
 int nvrx_ctx_set_stream(nvrx_ctx *ctx, void *stream);
-/* Geometry queries: 0 local_ranks, 1 rows_per_rank, 2 ring_cap, 3 row_stride, 4 device. */
+/* Geometry queries: 0 local_ranks, 1 rows_per_rank, 2 ring_cap, 3 row_stride, 4 device; diagnostics: 5 reports re-homed,
+ * 6 verdict of the last re-homing decision, 7 GPU-timed regions skipped because their stream was being captured. */
 int nvrx_ctx_info(const nvrx_ctx *ctx, int what);
 
 /* Row metadata: kind (NVRX_KIND_*) and position `gid` in the exchange table (-1 = not exchanged).
@@ -182,7 +183,12 @@ int nvrx_event_harvest(nvrx_ctx *ctx, int wait);
  * elapsed MICROSECONDS (CuptiProfiler.cpp:191) to `row`'s ring and, when cpu_row >= 0, also appends the
  * host-measured `cpu_value` to `cpu_row`'s ring (the section's wall time, straggler.py:343), so a profiled
  * section entry costs no pinned-memory staging.  Reports are ordered after these kernels on the device;
- * the host never waits for them.  Regions on one row nest LIFO. */
+ * the host never waits for them.  Regions on one row nest LIFO.
+ * A region whose stream is being captured into a hipGraph (hipStreamIsCapturing) records nothing -- a captured timestamp
+ * would replay into one fixed ring slot, and the reference sees no kernel during a capture either: begin AND the matching
+ * end return NVRX_REGION_SKIPPED (> 0), nothing is enqueued, cpu_value is NOT taken (the caller pushes it itself).  The
+ * same holds for nvrx_event_begin / nvrx_event_end.  nvrx_ctx_info(ctx, 7) counts such regions. */
+#define NVRX_REGION_SKIPPED 1
 int nvrx_stamp_begin(nvrx_ctx *ctx, int row, void *stream);
 int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *stream);
 

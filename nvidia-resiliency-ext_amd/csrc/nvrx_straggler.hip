@@ -1986,6 +1986,8 @@ struct nvrx_ctx {
     };
     std::vector<OpenStamp> open_stamps;
     std::vector<hipStream_t> stamp_streams;  // user streams with stamp kernels the rings have not been ordered after
+    std::vector<int> skipped_regions;        // rows of regions opened on a capturing stream: closed without a sample
+    unsigned regions_skipped = 0;
     std::vector<hipStream_t> report_streams;  // every stream a report of this context launched its score kernel on (scratch ownership)
     hipEvent_t stamp_ev = nullptr;
     hipEvent_t order_ev = nullptr;  // nvrx_report: report stream ordered after the caller's stream
@@ -2506,6 +2508,7 @@ int nvrx_ctx_info(const nvrx_ctx *ctx, int what) {
         case 4: return ctx->device;
         case 5: return (int)ctx->reports_rehomed;   // reports that were enqueued on the stream they had to follow (diagnostics)
         case 6: return ctx->last_rehome_verdict;    // why the last report was / was not re-homed: see nvrx_report
+        case 7: return (int)ctx->regions_skipped;   // GPU-timed regions that got no sample because their stream was being captured
         default: return fail(NVRX_ERR_INVALID, "unknown info selector %d", what);
     }
 }
@@ -2748,10 +2751,38 @@ int nvrx_ring_read(nvrx_ctx *ctx, int row, float *out, int n, void *stream) {
 // ------------------------------------------------------------------------------------------------
 // hipEvent region timing
 // ------------------------------------------------------------------------------------------------
+// A stream that is being captured into a hipGraph runs nothing now: a timestamp launched on it would land in the graph
+// with this entry's ring slot baked in, and the host would count a sample no kernel has written.  Such an entry gets no GPU
+// time (the reference records none either: no kernel executes while a capture is open, CuptiProfiler.cpp:168-207 sees only
+// the replays), the caller keeps the section's wall time on the host path.  (A query the runtime refuses -- the legacy
+// stream while another stream captures in global mode -- counts as "not capturing" and its error is not left behind.)
+static bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+static bool take_skipped_region(nvrx_ctx *ctx, int row) {
+    for (int i = (int)ctx->skipped_regions.size() - 1; i >= 0; i--)
+        if (ctx->skipped_regions[(size_t)i] == row) {
+            ctx->skipped_regions.erase(ctx->skipped_regions.begin() + i);
+            return true;
+        }
+    return false;
+}
+
 int nvrx_event_begin(nvrx_ctx *ctx, int row, void *stream) {
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (stream_is_capturing(as_stream(stream))) {
+        ctx->skipped_regions.push_back(row);
+        ctx->regions_skipped++;
+        return NVRX_REGION_SKIPPED;
+    }
     int idx = -1;
     int rc = get_pair(ctx->pool, ctx->free_pairs, &idx);
     if (rc) return rc;
@@ -2763,10 +2794,16 @@ int nvrx_event_begin(nvrx_ctx *ctx, int row, void *stream) {
 int nvrx_event_end(nvrx_ctx *ctx, int row, void *stream) {
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (take_skipped_region(ctx, row)) return NVRX_REGION_SKIPPED;
     for (int i = (int)ctx->open.size() - 1; i >= 0; i--) {
         if (ctx->open[(size_t)i].row == row) {
             const nvrx_ctx::Open o = ctx->open[(size_t)i];
             ctx->open.erase(ctx->open.begin() + i);
+            if (stream_is_capturing(as_stream(stream))) {  // opened before the capture began: the pair cannot be closed now
+                ctx->free_pairs.push_back(o.pair);
+                ctx->regions_skipped++;
+                return NVRX_REGION_SKIPPED;
+            }
             HIP_TRY(hipEventRecord(ctx->pool[(size_t)o.pair].end, as_stream(stream)));
             ctx->pending.push_back(o);
             return NVRX_OK;
@@ -2806,6 +2843,11 @@ int nvrx_stamp_begin(nvrx_ctx *ctx, int row, void *stream) {
     if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
     std::lock_guard<std::mutex> lk(ctx->mu);
     if ((int)ctx->open_stamps.size() >= nvrx_ctx::NSTAMP / 2) return fail(NVRX_ERR_STATE, "too many open GPU-timed regions");
+    if (stream_is_capturing(as_stream(stream))) {
+        ctx->skipped_regions.push_back(row);
+        ctx->regions_skipped++;
+        return NVRX_REGION_SKIPPED;
+    }
     const int slot = ctx->stamp_next;
     ctx->stamp_next = (ctx->stamp_next + 1) % nvrx_ctx::NSTAMP;
     hipLaunchKernelGGL(k_stamp_begin, dim3(1), dim3(1), 0, as_stream(stream), ctx->d_stamps + slot);
@@ -2818,10 +2860,15 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     if (cpu_row >= ctx->rows) return fail(NVRX_ERR_INVALID, "cpu_row %d out of range [0,%d)", cpu_row, ctx->rows);
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (take_skipped_region(ctx, row)) return NVRX_REGION_SKIPPED;
     for (int i = (int)ctx->open_stamps.size() - 1; i >= 0; i--) {
         if (ctx->open_stamps[(size_t)i].row != row) continue;
         const int slot = ctx->open_stamps[(size_t)i].slot;
         ctx->open_stamps.erase(ctx->open_stamps.begin() + i);
+        if (stream_is_capturing(as_stream(stream))) {  // opened before the capture began: no sample, nothing enqueued
+            ctx->regions_skipped++;
+            return NVRX_REGION_SKIPPED;
+        }
         const uint64_t cap = (uint64_t)ctx->ring_cap;
         float *dst_gpu = ctx->d_samples + (size_t)row * (size_t)ctx->row_stride + (size_t)(ctx->total[(size_t)row] % cap);
         ctx->total[(size_t)row]++;

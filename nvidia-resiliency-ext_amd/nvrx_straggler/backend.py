@@ -518,26 +518,35 @@ class HipRings:
         return out
 
     # ---- GPU region timing -----------------------------------------------------------------------
-    def event_begin(self, row: int, stream_handle: int, lr: int = 0) -> None:
-        _native.check(self.lib.nvrx_event_begin(self.ctx, lr * self.rows_per_rank + row, stream_handle))
+    # (begin / end of a GPU-timed region return False when the region records nothing: its stream is being captured
+    #  into a hipGraph -- include/nvrx_straggler.h, NVRX_REGION_SKIPPED)
+    def event_begin(self, row: int, stream_handle: int, lr: int = 0) -> bool:
+        return _native.check(self.lib.nvrx_event_begin(self.ctx, lr * self.rows_per_rank + row, stream_handle)) == 0
 
-    def event_end(self, row: int, stream_handle: int, lr: int = 0) -> None:
-        _native.check(self.lib.nvrx_event_end(self.ctx, lr * self.rows_per_rank + row, stream_handle))
+    def event_end(self, row: int, stream_handle: int, lr: int = 0) -> bool:
+        return _native.check(self.lib.nvrx_event_end(self.ctx, lr * self.rows_per_rank + row, stream_handle)) == 0
 
     def harvest(self, wait: bool) -> int:
         return _native.check(self.lib.nvrx_event_harvest(self.ctx, int(wait)))
 
     # device-side timing: the elapsed time is written into the ring by a kernel on the user's stream
-    def stamp_begin(self, row: int, stream_handle: int, lr: int = 0) -> None:
+    def stamp_begin(self, row: int, stream_handle: int, lr: int = 0) -> bool:
         rc = self.lib.nvrx_stamp_begin(self.ctx, lr * self.rows_per_rank + row, stream_handle)
         if rc < 0:
             _native.check(rc)
+        return rc == 0
 
-    def stamp_end(self, row: int, stream_handle: int, cpu_row: int = -1, cpu_value: float = 0.0, lr: int = 0) -> None:
+    def stamp_end(self, row: int, stream_handle: int, cpu_row: int = -1, cpu_value: float = 0.0, lr: int = 0) -> bool:
         base = lr * self.rows_per_rank
         rc = self.lib.nvrx_stamp_end(self.ctx, base + row, base + cpu_row if cpu_row >= 0 else -1, cpu_value, stream_handle)
         if rc < 0:
             _native.check(rc)
+        return rc == 0
+
+    @property
+    def regions_skipped(self) -> int:
+        """GPU-timed regions that recorded nothing because their stream was being captured into a hipGraph."""
+        return int(self.lib.nvrx_ctx_info(self.ctx, 7))
 
     # ---- report ----------------------------------------------------------------------------------
     def report_local(self, ws: Workspace, names_ok: bool, rows_active: int = 0) -> None:

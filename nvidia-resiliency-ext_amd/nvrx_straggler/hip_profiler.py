@@ -151,8 +151,8 @@ class CuptiProfiler:
             return False
         took = False
         if self._stamps:
-            self._rings.stamp_end(self._active_row, self._stream_handle(), cpu_row, cpu_value)
-            took = cpu_row >= 0
+            # (False: the stream is being captured into a hipGraph -- nothing was enqueued, the caller keeps its sample)
+            took = self._rings.stamp_end(self._active_row, self._stream_handle(), cpu_row, cpu_value) and cpu_row >= 0
         else:
             self._rings.event_end(self._active_row, self._stream_handle())
         self._active_row = None

@@ -530,3 +530,45 @@ print("RESULT " + json.dumps(out))
     assert out["cuda_initialised_after_initialize"] is False
     assert out["ring_device"] == out["current_device"]
     assert out["keys"] == ["hipevent::fwd"] and out["num"] == 3
+
+
+@pytest.mark.parametrize("mode", ["stamp", "event"])
+def test_a_section_entered_while_its_stream_is_captured_records_no_gpu_sample(monkeypatch, mode):
+    """``detection_section(profile_cuda=True)`` inside ``torch.cuda.graph``: nothing runs while a stream is captured, so the
+    entry gets no GPU sample (the reference's activity records hold no kernel of a capture either,
+    cupti_src/CuptiProfiler.cpp:168-207) -- no timestamp lands in the graph (a replay would write one fixed ring slot, and the
+    host would have counted a sample nobody wrote), the section's wall time is kept, the graph replays unharmed, and the
+    sections around the replays are timed as usual."""
+    from nvrx_straggler import Detector, Statistic
+
+    monkeypatch.setenv("NVRX_GPU_TIMING", mode)
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=False, node_name="n0")
+    try:
+        x = torch.randn(512, 512, device="cuda")
+        out = torch.zeros(512, 512, device="cuda")
+        for _ in range(3):                                       # eager entries: rows exist, libraries are warm
+            with Detector.detection_section("fwd", profile_cuda=True):
+                out.copy_(x @ x)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            with Detector.detection_section("fwd", profile_cuda=True):
+                out.copy_(x @ x)
+        assert Detector.rings.regions_skipped == 1
+        out.zero_()
+        for _ in range(4):
+            with Detector.detection_section("replay", profile_cuda=True):
+                g.replay()
+        torch.cuda.synchronize()
+        assert torch.allclose(out, x @ x, rtol=1e-3, atol=1e-3)   # the captured work is the user's, nothing of ours is in it
+        rep = Detector.generate_report()
+        assert rep.local_section_summaries["fwd"][Statistic.NUM] == 4          # 3 eager + the captured entry's wall time
+        assert rep.local_section_summaries["replay"][Statistic.NUM] == 4
+        ks = rep.local_kernel_summaries
+        assert ks["hipevent::fwd"][Statistic.NUM] == 3                         # the captured entry has no GPU time
+        assert ks["hipevent::replay"][Statistic.NUM] == 4 and ks["hipevent::replay"][Statistic.MIN] > 0.0
+        assert ks["hipevent::fwd"][Statistic.MIN] > 0.0
+        assert rep.gpu_relative_perf_scores[0] == pytest.approx(1.0)
+        assert rep.identify_stragglers()["straggler_gpus_relative"] == set()
+    finally:
+        Detector.shutdown()
