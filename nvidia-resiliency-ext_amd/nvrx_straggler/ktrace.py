@@ -142,6 +142,27 @@ def _hip_is_up() -> bool:
         return False
 
 
+# what launchers export for "processes in this job": torchrun / torch.distributed.run and whoever follows it, then srun,
+# Open MPI's mpirun, and PMI-based launchers (MPICH, Intel MPI, Cray) -- a DDP script started by those reads its rank
+# from the same variables before it calls init_process_group
+_JOB_SIZE_VARS = ("WORLD_SIZE", "SLURM_NTASKS", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE")
+
+
+def _job_size() -> tuple:
+    """(processes in this job as far as the environment tells, the variable that said so)."""
+    for var in _JOB_SIZE_VARS:
+        raw = os.environ.get(var, "").strip()
+        if not raw:
+            continue
+        try:
+            n = int(raw)
+        except ValueError:
+            continue
+        if var == "WORLD_SIZE" or n > 1:
+            return n, var
+    return 1, ""
+
+
 def timing_mode() -> str:
     """How ``profile_cuda=True`` sections measure GPU time in this process: ``stamp`` | ``event`` | ``kernels``.
 
@@ -149,7 +170,7 @@ def timing_mode() -> str:
     ``import nvrx_straggler``:
 
     * a process of a multi-rank job (``WORLD_SIZE`` > 1 in the environment, what ``torchrun`` and every launcher that
-      follows its convention exports) gets ``kernels`` -- the reference's data model (CuptiProfiler.cpp:168-207): the GPU
+      follows its convention exports; without it srun's, mpirun's or a PMI launcher's job size) gets ``kernels`` -- the reference's data model (CuptiProfiler.cpp:168-207): the GPU
       score is the kernel-weighted mean over real kernels and RCCL's ``ncclDev*`` kernels, whose duration is peer-wait
       time, are left out (reporting.py:330-336).  One row per REGION cannot do that: a step that ends in a collective
       lasts as long as the slowest rank's on every rank and a slow GPU scores 1.0 (tests/test_host_logic.py,
@@ -170,10 +191,7 @@ def timing_mode() -> str:
         elif want == "kernels":
             _mode = "kernels"  # asked for by name: errors of the registration surface when the profiler is built
         else:
-            try:
-                world = int(os.environ.get("WORLD_SIZE", "1") or "1")
-            except ValueError:
-                world = 1
+            world, said_by = _job_size()
             if world <= 1:
                 _mode, _mode_note = "stamp", "single-process job"
             elif not os.path.exists("/dev/kfd"):
@@ -182,7 +200,7 @@ def timing_mode() -> str:
                 _mode, _mode_note = "stamp", ("multi-rank job, but the HIP runtime was initialised before nvrx_straggler was "
                                               "imported: rocprofiler-sdk accepts tools only before that")
             else:
-                _mode, _mode_note = "kernels", f"multi-rank job (WORLD_SIZE={world})"
+                _mode, _mode_note = "kernels", f"multi-rank job ({said_by}={world})"
     if _mode == "kernels":
         try:
             setup()

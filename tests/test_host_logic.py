@@ -1019,7 +1019,7 @@ def test_gpu_timing_mode_defaults(monkeypatch):
     monkeypatch.setattr(ktrace.os.path, "exists", lambda p: True if p == "/dev/kfd" else real_exists(p))
 
     def mode(env):
-        for k in ("NVRX_GPU_TIMING", "WORLD_SIZE"):
+        for k in ("NVRX_GPU_TIMING",) + ktrace._JOB_SIZE_VARS:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1032,6 +1032,12 @@ def test_gpu_timing_mode_defaults(monkeypatch):
         assert mode({"WORLD_SIZE": "1"}) == ("stamp", [])
         assert mode({"WORLD_SIZE": "8"}) == ("kernels", ["setup"])
         assert "WORLD_SIZE=8" in ktrace.mode_note()
+        # launchers that do not follow torchrun's convention: srun, mpirun, PMI -- WORLD_SIZE, where present, has the word
+        assert mode({"SLURM_NTASKS": "16"}) == ("kernels", ["setup"]) and "SLURM_NTASKS=16" in ktrace.mode_note()
+        assert mode({"OMPI_COMM_WORLD_SIZE": "4"}) == ("kernels", ["setup"])
+        assert mode({"PMI_SIZE": "2"}) == ("kernels", ["setup"])
+        assert mode({"SLURM_NTASKS": "1", "PMI_SIZE": "x"}) == ("stamp", [])
+        assert mode({"WORLD_SIZE": "1", "SLURM_NTASKS": "16"}) == ("stamp", [])
         assert mode({"WORLD_SIZE": "8", "NVRX_GPU_TIMING": "stamp"}) == ("stamp", [])
         assert mode({"WORLD_SIZE": "8", "NVRX_GPU_TIMING": "event"}) == ("event", [])
         assert mode({"NVRX_GPU_TIMING": "kernels"}) == ("kernels", ["setup"])
