@@ -3024,6 +3024,7 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         const double now_us = g_report_clk[0];
         async_gap_ok = ctx->async_rehome_gap_us > 0.0 && ctx->last_report_us > 0.0 && now_us - ctx->last_report_us >= ctx->async_rehome_gap_us;
         ctx->last_report_us = now_us;
+        ctx->last_rehome_verdict = 0;  // (not a candidate, unless the block below says otherwise)
         if (d->prev_settled) {
             // the caller has seen this context's previous (asynchronous) report complete: nothing has to be guarded against
             // it any more, and what was enqueued on the context's stream in front of it is done as well
@@ -3052,8 +3053,6 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
             ctx->stamp_streams.clear();
             ctx->reports_rehomed++;
         }
-    } else {
-        ctx->last_rehome_verdict = 0;
     }
     if (!rehomed && d->order_after_enabled && d->order_after_stream != stream) {
         std::lock_guard<std::mutex> lk(ctx->mu);
