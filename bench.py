@@ -857,6 +857,9 @@ def main():
                 "target_us": 50,
             },
             "gpu_timing_mode": _ktrace.timing_mode(),  # how profile_cuda sections would be timed in these processes (kernels = the default of multi-rank jobs)
+            # why: this script selects its device BEFORE it imports the package (the headline path has no sections), so even
+            # at N > 1 the per-step-overhead leg runs on region stamps; a job that imports nvrx_straggler first gets `kernels`
+            "gpu_timing_mode_note": _ktrace.mode_note(),
             "reports_per_s": round(1e6 / us_per_report, 1),
             "us_per_report_median": round(float(np.median(per_step)) / 1e3, 2),
             "us_per_report_p95": round(float(np.percentile(per_step, 95)) / 1e3, 2),
