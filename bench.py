@@ -30,7 +30,7 @@ Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
                   step; % = (t_with - t_without) / t_without, A/B blocks alternating in one process.
   host_inputs  -- the PCIe-inclusive figure (never `value`): the same report when the 8 x 64 x 10 000 samples start in
                   pageable HOST memory and are handed over per logical rank ([64, 10000] f32 arrays -> one H2D copy +
-                  64 device-to-device ring appends each) before the report runs; N=1 only, a few repetitions.
+                  one strided device-to-device append of the whole matrix each) before the report runs; N=1 only, a few repetitions.
   cpu_baseline -- the reference's CPU path restated in Python (oracle/, kind "port"), timed on this host: the whole job
                   as 8 gloo processes (one per rank, 8 cores): per report torch.tensor(deque) + 5 torch reductions per
                   section, the flag / MIN all-reduces, scores, gather to rank 0; the all_gather_object of the summary
@@ -797,7 +797,7 @@ def main():
             nbytes = job.local_ranks * SECTIONS * SAMPLES * 4
             us = float(np.median(t_host[1:])) * 1e6
             host_inputs = {"us_per_report": round(us, 1), "host_bytes": nbytes, "gb_per_s": round(nbytes / us / 1e3, 2),
-                           "note": "samples start in pageable host memory; H2D + ring appends + report; not the headline value"}
+                           "note": "samples start in pageable host memory; per logical rank one H2D copy + one strided append of the [64, 10000] matrix, then the report; not the headline value"}
         except Exception as e:  # noqa: BLE001  (a side leg: see _side_leg)
             host_inputs = {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
 

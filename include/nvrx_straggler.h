@@ -149,6 +149,10 @@ int nvrx_ring_push_many(nvrx_ctx *ctx, int row, const float *values, int n);
 int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values, int n);
 /* Append n samples that already live in device memory (device-to-device, wraps as needed). */
 int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, void *stream);
+/* The same for n_rows consecutive rows at once: row first_row + r gets the n samples at d_values + r * ld (ld >= n).  Rows
+ * that stand at the same ring position are written with one strided device copy per ring segment.  This is how a whole
+ * [sections][samples] matrix (the reference's per-section deques, straggler.py:80-83) is handed over in one call. */
+int nvrx_ring_push_device_rows(nvrx_ctx *ctx, int first_row, int n_rows, const float *d_values, int n, int ld, void *stream);
 /* Declare that `row` currently holds n valid samples in its device ring (no data movement). */
 int nvrx_ring_set_count(nvrx_ctx *ctx, int row, int n);
 /* Same for every row of the context at once (benchmark re-arm of resident data). */

@@ -2661,6 +2661,50 @@ int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, 
     return NVRX_OK;
 }
 
+// A [n_rows][ld] device matrix appended to n_rows consecutive rows at once.  Rows whose write position is the same (the
+// usual case: rings filled together) take ONE strided copy per ring segment -- two when the append wraps -- instead of a
+// copy per row; otherwise the rows go one by one, as nvrx_ring_push_device does.
+int nvrx_ring_push_device_rows(nvrx_ctx *ctx, int first_row, int n_rows, const float *d_values, int n, int ld, void *stream) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (n_rows < 0 || first_row < 0 || first_row + n_rows > ctx->rows)
+        return fail(NVRX_ERR_INVALID, "rows [%d,%d) outside [0,%d)", first_row, first_row + n_rows, ctx->rows);
+    if (n < 0 || ld < n || (n > 0 && n_rows > 0 && !d_values)) return fail(NVRX_ERR_INVALID, "bad d_values/n/ld");
+    if (n == 0 || n_rows == 0) return NVRX_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    mark_side_work(ctx);
+    int rc = ctx_set_device(ctx);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    rc = flush_locked(ctx, st);  // earlier staged samples must land first
+    if (rc) return rc;
+    rc = guard_ring_writer(ctx, st);
+    if (rc) return rc;
+    const uint64_t cap = (uint64_t)ctx->ring_cap;
+    const uint64_t first = (uint64_t)n > cap ? (uint64_t)n - cap : 0;  // only the newest `cap` samples can survive
+    bool together = true;
+    for (int r = 1; r < n_rows && together; r++)
+        together = ctx->total[(size_t)(first_row + r)] % cap == ctx->total[(size_t)first_row] % cap;
+    for (int r = 0; r < (together ? 1 : n_rows); r++) {
+        const int row = first_row + r;
+        uint64_t pos = ctx->total[(size_t)row] + first;
+        int left = n - (int)first;
+        const float *src = d_values + (size_t)r * (size_t)ld + first;
+        float *base = ctx->d_samples + (size_t)row * (size_t)ctx->row_stride;
+        while (left > 0) {
+            const int slot = (int)(pos % cap);
+            const int chunk = std::min(left, (int)cap - slot);
+            HIP_TRY(hipMemcpy2DAsync(base + slot, (size_t)ctx->row_stride * sizeof(float), src, (size_t)ld * sizeof(float),
+                                     (size_t)chunk * sizeof(float), together ? (size_t)n_rows : 1, hipMemcpyDeviceToDevice, st));
+            src += chunk;
+            pos += (uint64_t)chunk;
+            left -= chunk;
+        }
+    }
+    for (int r = 0; r < n_rows; r++) ctx->total[(size_t)(first_row + r)] += (uint64_t)n;
+    ctx->counts_dirty = true;
+    return NVRX_OK;
+}
+
 int nvrx_ring_set_count(nvrx_ctx *ctx, int row, int n) {
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);

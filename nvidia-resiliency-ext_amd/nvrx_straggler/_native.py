@@ -59,6 +59,7 @@ SYMBOLS = [
     ("nvrx_ring_push_many", c_int, [c_void_p, c_int, c_void_p, c_int]),
     ("nvrx_ring_push_pairs", c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     ("nvrx_ring_push_device", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    ("nvrx_ring_push_device_rows", c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     ("nvrx_ring_set_count", c_int, [c_void_p, c_int, c_int]),
     ("nvrx_ring_set_count_all", c_int, [c_void_p, c_int]),
     ("nvrx_ring_count", c_int, [c_void_p, c_int]),

@@ -484,6 +484,14 @@ class HipRings:
         _native.check(self.lib.nvrx_ring_push_device(self.ctx, lr * self.rows_per_rank + row, values.data_ptr(),
                                                      values.numel(), self.backend.stream_handle))
 
+    def push_device_rows(self, first_row: int, values: torch.Tensor, lr: int = 0) -> None:
+        """``values[r]`` appended to row ``first_row + r`` for every r: one call, one strided copy when the rows stand at
+        the same ring position."""
+        assert values.dtype == torch.float32 and values.is_cuda and values.dim() == 2 and values.stride(1) == 1
+        _native.check(self.lib.nvrx_ring_push_device_rows(self.ctx, lr * self.rows_per_rank + first_row, values.shape[0],
+                                                          values.data_ptr(), values.shape[1], values.stride(0),
+                                                          self.backend.stream_handle))
+
     def set_count(self, row: int, n: int, lr: int = 0) -> None:
         _native.check(self.lib.nvrx_ring_set_count(self.ctx, lr * self.rows_per_rank + row, n))
 

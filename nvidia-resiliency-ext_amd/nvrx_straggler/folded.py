@@ -48,8 +48,12 @@ class FoldedJob:
             samples = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float32)).to(self.backend.device)
         self.backend.synchronize()
         torch.cuda.current_stream().synchronize()
-        for s, name in enumerate(self.section_names):
-            self.rings.push_device(self.rows[name], samples[s].contiguous(), lr=lr)
+        rows = [self.rows[name] for name in self.section_names]
+        if rows == list(range(rows[0], rows[0] + len(rows))) and samples.dim() == 2 and samples.stride(1) == 1:
+            self.rings.push_device_rows(rows[0], samples, lr=lr)     # the whole matrix in one call
+        else:
+            for s, row in enumerate(rows):
+                self.rings.push_device(row, samples[s].contiguous(), lr=lr)
         self.backend.synchronize()
 
     def rearm(self, n: int) -> None:

@@ -246,6 +246,48 @@ def test_ring_overwrite_oldest_matches_reference(be, cap, n):
         rings.close()
 
 
+@pytest.mark.parametrize("cap,n1,n2", [(64, 10, 20), (64, 50, 30), (64, 64, 64), (64, 5, 200), (8192, 10000, 100), (100, 0, 100)])
+@pytest.mark.parametrize("together", [True, False])
+def test_a_matrix_appended_to_consecutive_rows_at_once_matches_the_ring_of_the_reference(be, cap, n1, n2, together):
+    """``nvrx_ring_push_device_rows``: a [rows][n] device matrix (also a strided view of a wider one) appended to consecutive
+    rows in one call leaves every ring as the reference's deque(maxlen) / CircularBuffer would be (straggler.py:80-83,
+    CircularBuffer.h:53-61) -- rows standing at one ring position (one strided copy per segment, wrapping included) and rows
+    that do not (the row-by-row path)."""
+    R = 5
+    rings = be.make_rings(1, R + 2, cap)
+    try:
+        rows = [rings.row_for(0, f"s{r}") for r in range(R + 1)]
+        assert rows == list(range(rows[0], rows[0] + R + 1))
+        rng = np.random.default_rng(cap * 1000 + n1 + n2)
+        a = rng.random((R, max(n1, 1)), dtype=np.float32)[:, :n1]
+        wide = rng.random((R, n2 + 7), dtype=np.float32)
+        hist = [[] for _ in range(R)]
+        if n1:
+            rings.push_device_rows(rows[0], torch.from_numpy(np.ascontiguousarray(a)).cuda())
+            for r in range(R):
+                hist[r] += a[r].tolist()
+        if not together:                                  # row 2 moves ahead of the others
+            rings.push(rows[2], 123.0)
+            hist[2].append(123.0)
+        view = torch.from_numpy(wide).cuda()[:, 3 : 3 + n2]   # leading dimension n2 + 7
+        rings.push_device_rows(rows[0], view)
+        for r in range(R):
+            hist[r] += wide[r, 3 : 3 + n2].tolist()
+        for r in range(R):
+            exp = oracle.ring_run(np.asarray(hist[r], dtype=np.float32), cap)
+            assert rings.count(rows[r]) == exp.size
+            stored = rings.read_row(rows[r])[: exp.size]
+            assert sorted(stored.tolist()) == sorted(exp.tolist()), r
+        assert rings.count(rows[R]) == 0                 # the neighbour row was not touched
+        stats = rings.peek_stats()
+        for r in range(R):
+            exp = oracle.ring_run(np.asarray(hist[r], dtype=np.float32), cap)
+            e = oracle.section_stats(exp.astype(np.float64))
+            assert stats[rows[r]][2] == np.float32(e[2]) and stats[rows[r]][5] == exp.size
+    finally:
+        rings.close()
+
+
 @pytest.mark.parametrize("cap,rows,n", [(16, 40, 3000), (64, 300, 20000), (100, 4096, 409600)])
 def test_bulk_append_of_row_value_pairs_matches_the_ring_of_the_reference(be, cap, rows, n):
     """nvrx_ring_push_pairs (the per-kernel tracer's route into the rings: one scatter launch for all keys) == the
