@@ -1,0 +1,33 @@
+"""The C ABI from a host that is neither Python nor PyTorch: ``tests/c_abi/abi_host.c`` -- plain C99, gcc, only
+``include/nvrx_straggler.h`` -- drives rings -> row statistics -> exchange rows -> scores for a small three-rank job and
+checks every number against the C oracle and the reference's formulas itself (the boundary of section 2 of the brief:
+"plain pointers and sizes, no torch types in the signatures").  ``build()`` compiles it (tests/c_abi/Makefile)."""
+import os
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(REPO, "tests", "c_abi", "_build", "abi_host")
+
+
+def _need_binary():
+    if not os.path.exists(HOST):
+        subprocess.check_call(["make", "-C", os.path.join(REPO, "tests", "c_abi"), "all"])
+
+
+def test_the_plain_c_host_links_against_the_library_and_agrees_on_the_descriptor_layout():
+    """No device needed: the binary resolves every ABI symbol it uses at load time, ``nvrx_abi_version()`` is the header's
+    ``NVRX_ABI_VERSION`` and ``nvrx_report_desc_size()`` is ``sizeof(nvrx_report_desc)`` as a C compiler lays it out."""
+    _need_binary()
+    p = subprocess.run([HOST, "--link-only"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "abi version 2" in p.stdout
+
+
+@pytest.mark.gpu
+def test_a_plain_c_host_runs_one_report_through_the_abi_and_matches_the_oracle():
+    _need_binary()
+    p = subprocess.run([HOST], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
+    assert "ABI HOST OK" in p.stdout
