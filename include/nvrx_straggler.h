@@ -304,6 +304,10 @@ int nvrx_timing_read(nvrx_ctx *ctx, double *total_us, int *launches, int reset);
 /* Small asynchronous D2H into pinned memory + completion tracking for the report results. */
 /* Pinned, device-mapped host memory; *out_device (optional) receives the address kernels use. */
 int nvrx_host_alloc(void **out, void **out_device, size_t bytes);
+/* Zero-initialised device memory on the current device, for hosts without an allocator of their own (the Python package
+ * hands over tensor.data_ptr(); tests/c_abi/abi_host.c, plain C, uses these).  No counterpart in the reference. */
+int nvrx_device_alloc(void **out, size_t bytes);
+int nvrx_device_free(void *p);
 /* Spin until *h_word == expected (acquire); NVRX_ERR_TIMEOUT after timeout_s seconds. */
 int nvrx_poll_u32(const uint32_t *h_word, uint32_t expected, double timeout_s);
 int nvrx_host_free(void *p);

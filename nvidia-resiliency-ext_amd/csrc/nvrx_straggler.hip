@@ -3457,6 +3457,29 @@ int nvrx_poll_u32(const uint32_t *h_word, uint32_t expected, double timeout_s) {
     }
 }
 
+int nvrx_device_alloc(void **out, size_t bytes) {
+    if (!out || bytes == 0) return fail(NVRX_ERR_INVALID, "nvrx_device_alloc: bad arguments");
+    *out = nullptr;
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(NVRX_ERR_NOMEM, "hipMalloc of %zu bytes failed", bytes);
+    }
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return fail(NVRX_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return NVRX_OK;
+}
+
+int nvrx_device_free(void *p) {
+    if (!p) return NVRX_OK;
+    HIP_TRY(hipFree(p));
+    return NVRX_OK;
+}
+
 int nvrx_host_free(void *p) {
     if (p) HIP_TRY(hipHostFree(p));
     return NVRX_OK;

@@ -93,6 +93,8 @@ SYMBOLS = [
     ("nvrx_host_alloc", c_int, [POINTER(c_void_p), POINTER(c_void_p), c_size_t]),
     ("nvrx_poll_u32", c_int, [c_void_p, c_uint32, c_double]),
     ("nvrx_host_free", c_int, [c_void_p]),
+    ("nvrx_device_alloc", c_int, [c_void_p, c_size_t]),
+    ("nvrx_device_free", c_int, [c_void_p]),
     ("nvrx_d2h_sync", c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     ("nvrx_copy_to_host", c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("nvrx_wait", c_int, [c_void_p]),

@@ -13,7 +13,9 @@
  *   - kernel rows:  MIN/MAX/MED/NUM exact, AVG/STD 2e-4 vs oracle_kernel_stats (CuptiProfiler.cpp:44-74);
  *   - relative section scores == (float)(min over ranks of MED / MED) bit for bit (reporting.py:196-217,255-296), the
  *     relative GPU score within 2e-6 of the weighted mean of reporting.py:219-253, individual scores 1.0 on a first
- *     report (reporting.py:298-314), flags == score < threshold.
+ *     report (reporting.py:298-314), flags == score < threshold;
+ *   - the same report as ONE call (nvrx_report, descriptor reused three times, buffers from nvrx_device_alloc): scores,
+ *     flags and forwarded statistics rows byte-identical to the two-call path.
  */
 #include <math.h>
 #include <stdio.h>
@@ -33,8 +35,8 @@ int oracle_kernel_stats(const float *x, int n, float *out);
 
 #define RANKS 3
 #define ROWS_PER_RANK 4 /* row 0: the kernel key, rows 1..3: sections */
-#define K 1
-#define S 3
+#define NK 1
+#define NS 3
 #define CAP 100
 
 static int failures = 0;
@@ -105,7 +107,7 @@ int main(int argc, char **argv) {
         }
 
     /* ---- buffers through the ABI: pinned host memory the kernels address directly ---- */
-    const int L = NVRX_TABLE_LEN(K, S), W = NVRX_SCORE_LEN(S);
+    const int L = NVRX_TABLE_LEN(NK, NS), W = NVRX_SCORE_LEN(NS);
     float *h_stats, *d_stats, *h_send, *d_send, *h_scores, *d_scores;
     uint8_t *h_flags, *d_flags;
     uint32_t *h_meta, *d_meta;
@@ -116,15 +118,15 @@ int main(int argc, char **argv) {
     TRY(nvrx_host_alloc((void **)&h_meta, (void **)&d_meta, NVRX_META_WORDS * sizeof(uint32_t)));
 
     /* ---- one report: statistics + exchange rows, then the scores of the table (3 local ranks = the whole job) ---- */
-    TRY(nvrx_send_init(d_send, RANKS, K, S, NULL));
-    TRY(nvrx_report_local(ctx, d_stats, d_send, K, S, 1, 0, NULL));
+    TRY(nvrx_send_init(d_send, RANKS, NK, NS, NULL));
+    TRY(nvrx_report_local(ctx, d_stats, d_send, NK, NS, 1, 0, NULL));
     const double thresholds[4] = {0.75, 0.75, 0.75, 0.75};
-    TRY(nvrx_score(d_send, RANKS, K, S, 1, 1, thresholds, d_scores, d_flags, d_meta, NULL, 1u, NULL, NULL, 0, NULL));
+    TRY(nvrx_score(d_send, RANKS, NK, NS, 1, 1, thresholds, d_scores, d_flags, d_meta, NULL, 1u, NULL, NULL, 0, NULL));
     float *stats = (float *)malloc((size_t)rows * NVRX_STATS_STRIDE * sizeof(float));
     TRY(nvrx_d2h_sync(stats, d_stats, (size_t)rows * NVRX_STATS_STRIDE * sizeof(float), NULL)); /* waits for the stream */
 
     /* ---- rings and statistics against the oracle ---- */
-    double med[RANKS][K + S], weight[RANKS];
+    double med[RANKS][NK + NS], weight[RANKS];
     float *ring_dev = (float *)malloc((size_t)stride * sizeof(float));
     for (int row = 0; row < rows; row++) {
         float lin[CAP];
@@ -163,15 +165,15 @@ int main(int argc, char **argv) {
 
     /* ---- scores: the table is what nvrx_report_local packed; expectations restated from the reference's formulas ---- */
     for (int r = 0; r < RANKS; r++) {
-        const float *sc = h_scores + (size_t)r * W; /* {gpu_indiv, gpu_rel, indiv[S], rel[S]} */
+        const float *sc = h_scores + (size_t)r * W; /* {gpu_indiv, gpu_rel, indiv[NS], rel[NS]} */
         const uint8_t *fl = h_flags + (size_t)r * W;
-        for (int s = 0; s < S; s++) {
-            double ref = med[0][K + s];
-            for (int q = 1; q < RANKS; q++) ref = fmin(ref, med[q][K + s]);
-            const float want = (float)(ref / med[r][K + s]); /* reporting.py:208-214 on the MIN all-reduced medians (:281) */
-            CHECK(sc[2 + S + s] == want, "rank %d section %d: relative score %.9g != %.9g", r, s, sc[2 + S + s], want);
+        for (int s = 0; s < NS; s++) {
+            double ref = med[0][NK + s];
+            for (int q = 1; q < RANKS; q++) ref = fmin(ref, med[q][NK + s]);
+            const float want = (float)(ref / med[r][NK + s]); /* reporting.py:208-214 on the MIN all-reduced medians (:281) */
+            CHECK(sc[2 + NS + s] == want, "rank %d section %d: relative score %.9g != %.9g", r, s, sc[2 + NS + s], want);
             CHECK(sc[2 + s] == 1.0f, "rank %d section %d: individual score %.9g on a first report", r, s, sc[2 + s]);
-            CHECK(fl[2 + S + s] == (want < 0.75f), "rank %d section %d: flag %d for score %g", r, s, fl[2 + S + s], want);
+            CHECK(fl[2 + NS + s] == (want < 0.75f), "rank %d section %d: flag %d for score %g", r, s, fl[2 + NS + s], want);
         }
         double ref = med[0][0];
         for (int q = 1; q < RANKS; q++) ref = fmin(ref, med[q][0]);
@@ -181,8 +183,52 @@ int main(int argc, char **argv) {
         CHECK(fl[1] == (sc[1] < 0.75f), "rank %d: GPU flag %d for score %g", r, fl[1], sc[1]);
     }
     CHECK(h_flags[2 * W + 1] == 1 && h_flags[0 * W + 1] == 0 && h_flags[1 * W + 1] == 0, "only rank 2's GPU is slow (1 / 1.5 < 0.75)");
-    CHECK(h_flags[2 * W + 2 + S + 0] == 1 && h_flags[2 * W + 2 + S + 1] == 0, "only rank 2's first section is slow");
-    CHECK(h_meta[0] == 1 && h_meta[1] == RANKS && h_meta[2] == K && h_meta[3] == S, "meta %u %u %u %u", h_meta[0], h_meta[1], h_meta[2], h_meta[3]);
+    CHECK(h_flags[2 * W + 2 + NS + 0] == 1 && h_flags[2 * W + 2 + NS + 1] == 0, "only rank 2's first section is slow");
+    CHECK(h_meta[0] == 1 && h_meta[1] == RANKS && h_meta[2] == NK && h_meta[3] == NS, "meta %u %u %u %u", h_meta[0], h_meta[1], h_meta[2], h_meta[3]);
+
+    /* ---- the same report as ONE call (nvrx_report): statistics and exchange rows stay in device memory, scores, flags and
+     *      the forwarded statistics rows land in the pinned block under the completion word the call waits for ---- */
+    {
+        float *dev_stats = NULL, *dev_send = NULL, *h_stats2, *d_stats2, *h_scores2, *d_scores2;
+        uint8_t *h_flags2, *d_flags2;
+        uint32_t *dev_done = NULL, *h_meta2, *d_meta2;
+        TRY(nvrx_device_alloc((void **)&dev_stats, (size_t)rows * NVRX_STATS_STRIDE * sizeof(float)));
+        TRY(nvrx_device_alloc((void **)&dev_send, (size_t)RANKS * L * sizeof(float)));
+        TRY(nvrx_device_alloc((void **)&dev_done, 64));
+        TRY(nvrx_host_alloc((void **)&h_stats2, (void **)&d_stats2, (size_t)rows * NVRX_STATS_STRIDE * sizeof(float)));
+        TRY(nvrx_host_alloc((void **)&h_scores2, (void **)&d_scores2, (size_t)RANKS * W * sizeof(float) + 16));
+        TRY(nvrx_host_alloc((void **)&h_flags2, (void **)&d_flags2, (size_t)RANKS * W + 16));
+        TRY(nvrx_host_alloc((void **)&h_meta2, (void **)&d_meta2, NVRX_META_WORDS * sizeof(uint32_t)));
+        memset(h_meta2, 0, NVRX_META_WORDS * sizeof(uint32_t));
+        TRY(nvrx_send_init(dev_send, RANKS, NK, NS, NULL));
+        float scratch;
+        TRY(nvrx_d2h_sync(&scratch, dev_send, sizeof(scratch), NULL)); /* (a stream wait: the exchange rows are initialised before a resident scorer reads them) */
+        nvrx_report_desc d;
+        memset(&d, 0, sizeof(d));
+        d.R = RANKS, d.K = NK, d.S = NS, d.names_ok = 1, d.rows_active = 0, d.do_indiv = 1, d.do_rel = 1, d.stats_rows = rows;
+        for (int i = 0; i < 4; i++) d.thresholds[i] = 0.75;
+        d.d_stats = dev_stats, d.d_send = dev_send, d.d_table = NULL;
+        d.d_scores = d_scores2, d.d_flags = d_flags2, d.d_meta = d_meta2, d.d_stats_dst = d_stats2, d.d_done_counter = dev_done;
+        d.allgather_fn = NULL, d.comm = NULL, d.send_count = RANKS * L, d.seq = 0;
+        d.h_seq_word = &h_meta2[4], d.timeout_s = 30.0, d.resident = 1;
+        for (int rep = 0; rep < 3; rep++) { /* the descriptor is reused; the library advances seq */
+            TRY(nvrx_report(ctx, &d, NULL));
+            CHECK(d.seq == (uint32_t)(rep + 1) && h_meta2[4] == d.seq, "report %d: seq %u, completion word %u", rep, d.seq, h_meta2[4]);
+            CHECK(memcmp(h_scores2, h_scores, (size_t)RANKS * W * sizeof(float)) == 0, "report %d: scores differ from the two-call path", rep);
+            CHECK(memcmp(h_flags2, h_flags, (size_t)RANKS * W) == 0, "report %d: flags differ from the two-call path", rep);
+            if (nvrx_poll_u32(&h_meta2[5], d.seq, 5.0) == NVRX_OK) /* resident scorer: the statistics rows have a word of their own */
+                CHECK(memcmp(h_stats2, stats, (size_t)rows * NVRX_STATS_STRIDE * sizeof(float)) == 0, "report %d: forwarded statistics rows differ", rep);
+            else
+                CHECK(0, "report %d: the statistics rows' completion word never arrived (%u)", rep, h_meta2[5]);
+        }
+        TRY(nvrx_device_free(dev_stats));
+        TRY(nvrx_device_free(dev_send));
+        TRY(nvrx_device_free(dev_done));
+        TRY(nvrx_host_free(h_stats2));
+        TRY(nvrx_host_free(h_scores2));
+        TRY(nvrx_host_free(h_flags2));
+        TRY(nvrx_host_free(h_meta2));
+    }
 
     /* ---- error behaviour of the ABI: negative codes + a message, never an abort ---- */
     CHECK(nvrx_ring_push(ctx, rows, 1.0f) == NVRX_ERR_INVALID && strlen(nvrx_last_error()) > 0, "out-of-range row must be refused");
