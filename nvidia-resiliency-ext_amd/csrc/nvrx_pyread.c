@@ -144,6 +144,58 @@ fail:
     return NULL;
 }
 
+/* ---- recycling a mapping nobody holds any more --------------------------------------------------------------------------
+ * A report's mappings have the same keys as the previous report's.  When the previous mapping is still around -- the caller
+ * keeps the last one it built per plan in a list -- and NOTHING else refers to it (reference count 1: the report it was built
+ * for is gone, nobody kept the dict), building the next one needs no dict at all: the values of the inner dicts are swapped
+ * in place and the very same objects are handed out again (a cloned dict costs ~60 ns, a report has 192 of them).  Any
+ * doubt -- somebody else holds the outer dict or an inner one, a key was added / removed / replaced, a value is not what
+ * this module stores -- and that dict is built the usual way; a held object is never touched.  Same fences as the
+ * in-place fill (CPython 3.10 layout, self-test, keys checked by identity before every refill). */
+#if NVRX_INPLACE_POSSIBLE
+/* entry slots of `d` if it is an unshared dict whose keys are exactly keys[0..n) in order, else NULL */
+static nvrx_dict_entry310 *recyclable_entries(PyObject *d, PyObject *keys, Py_ssize_t n) {
+    if (!g_inplace || !d || !PyDict_CheckExact(d) || Py_REFCNT(d) != 1) return NULL;
+    nvrx_dict_entry310 *e = inplace_entries(d, n);
+    if (!e) return NULL;
+    for (Py_ssize_t j = 0; j < n; j++)
+        if (e[j].me_key != PyTuple_GET_ITEM(keys, j) || e[j].me_value == NULL) return NULL;
+    return e;
+}
+
+/* values[0..n) (new references) moved into the unshared inner dict d; 0 = d does not qualify, nothing was touched */
+static int refill_inner(PyObject *d, PyObject *keys, PyObject **values, Py_ssize_t n) {
+    nvrx_dict_entry310 *e = recyclable_entries(d, keys, n);
+    if (!e) return 0;
+    for (Py_ssize_t j = 0; j < n; j++)
+        if (!values[j] || !(PyFloat_CheckExact(e[j].me_value) || PyLong_CheckExact(e[j].me_value))) return 0;
+    for (Py_ssize_t j = 0; j < n; j++) {
+        PyObject *old = e[j].me_value;
+        e[j].me_value = values[j];
+        Py_DECREF(old);  /* a float or an int: no code runs */
+    }
+    return 1;
+}
+#endif
+
+/* the list slot's object, now owned by the caller (the slot holds None), or NULL when the slot is empty / there is no list */
+static PyObject *take_recycled(PyObject *list, Py_ssize_t i) {
+    if (!list || i >= PyList_GET_SIZE(list)) return NULL;
+    PyObject *o = PyList_GET_ITEM(list, i);
+    if (o == Py_None) return NULL;
+    Py_INCREF(Py_None);
+    PyList_SET_ITEM(list, i, Py_None);
+    return o;
+}
+
+static void keep_recycled(PyObject *list, Py_ssize_t i, PyObject *o) {
+    if (!list || i >= PyList_GET_SIZE(list) || !o) return;
+    PyObject *old = PyList_GET_ITEM(list, i);
+    Py_INCREF(o);
+    PyList_SET_ITEM(list, i, o);
+    Py_DECREF(old);
+}
+
 /* hashes of a tuple's items into out (heap-allocated beyond MAX_STACK_HASHES); NULL + exception on an unhashable key */
 static Py_hash_t *tuple_hashes(PyObject *t, Py_hash_t *stack) {
     const Py_ssize_t n = PyTuple_GET_SIZE(t);
@@ -166,7 +218,7 @@ static Py_hash_t *tuple_hashes(PyObject *t, Py_hash_t *stack) {
  * {name: None for name in names}, kept by the caller across reports -- the outer dict is then a filled clone as well */
 static PyObject *section_mapping(const float *p, int n_rows, int width, int first_col, PyObject *names, PyObject *ranks,
                                  const long *col, const Py_hash_t *name_hash, const Py_hash_t *rank_hash, PyObject *rank_tmpl,
-                                 PyObject *name_tmpl) {
+                                 PyObject *name_tmpl, PyObject *prev /* owned, may be NULL: an earlier result to recycle */) {
     const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
     PyObject *stack_vals[64], *stack_inner[MAX_STACK_HASHES];
     PyObject **vals = n_rows <= 64 ? stack_vals : PyMem_Malloc((size_t)n_rows * sizeof(PyObject *));
@@ -176,6 +228,26 @@ static PyObject *section_mapping(const float *p, int n_rows, int width, int firs
         PyErr_NoMemory();
         goto done;
     }
+#if NVRX_INPLACE_POSSIBLE
+    {
+        nvrx_dict_entry310 *eo = recyclable_entries(prev, names, n_names);
+        if (eo) {
+            for (Py_ssize_t i = 0; i < n_names; i++) {
+                const float *q = p + first_col + (col ? col[i] : i);
+                for (int r = 0; r < n_rows; r++) vals[r] = PyFloat_FromDouble((double)q[(Py_ssize_t)r * width]);
+                PyObject *old = eo[i].me_value;
+                if (refill_inner(old, ranks, vals, n_rows)) continue;
+                PyObject *fresh = dict_from(ranks, vals, n_rows, rank_tmpl, rank_hash, 0);  /* somebody holds the old one */
+                if (!fresh) goto done;  /* (prev is a consistent dict at every point; it is released below) */
+                eo[i].me_value = fresh;
+                Py_DECREF(old);
+            }
+            out = prev;
+            prev = NULL;
+            goto done;
+        }
+    }
+#endif
     for (Py_ssize_t i = 0; i < n_names; i++) {
         const float *q = p + first_col + (col ? col[i] : i);
         for (int r = 0; r < n_rows; r++) vals[r] = PyFloat_FromDouble((double)q[(Py_ssize_t)r * width]);
@@ -187,6 +259,7 @@ static PyObject *section_mapping(const float *p, int n_rows, int width, int firs
     }
     out = dict_from(names, inner, n_names, name_tmpl, name_hash, 1);  /* consumes the inner dicts */
 done:
+    Py_XDECREF(prev);
     if (vals && vals != stack_vals) PyMem_Free(vals);
     if (inner && inner != stack_inner) PyMem_Free(inner);
     return out;
@@ -200,11 +273,12 @@ static PyObject *pyread_sections(PyObject *self, PyObject *args) {
     Py_buffer view;
     Py_ssize_t offset;
     int n_rows, width, first_col, second_col = -1;
-    PyObject *name_tmpl = Py_None;
-    if (!PyArg_ParseTuple(args, "O!O!y*niiiO|iO", &PyTuple_Type, &names, &PyTuple_Type, &ranks, &view, &offset, &n_rows, &width, &first_col,
-                          &cols, &second_col, &name_tmpl))
+    PyObject *name_tmpl = Py_None, *recycle = Py_None;
+    if (!PyArg_ParseTuple(args, "O!O!y*niiiO|iOO", &PyTuple_Type, &names, &PyTuple_Type, &ranks, &view, &offset, &n_rows, &width, &first_col,
+                          &cols, &second_col, &name_tmpl, &recycle))
         return NULL;
     if (name_tmpl == Py_None || !PyDict_CheckExact(name_tmpl)) name_tmpl = NULL;
+    if (recycle == Py_None || !PyList_CheckExact(recycle)) recycle = NULL;
     PyObject *out = NULL, *a = NULL, *b = NULL, *rank_tmpl = NULL;
     Py_hash_t nh_stack[MAX_STACK_HASHES], rh_stack[MAX_STACK_HASHES], *nh = NULL, *rh = NULL;
     long col_stack[MAX_STACK_HASHES], *col = NULL;
@@ -240,11 +314,13 @@ static PyObject *pyread_sections(PyObject *self, PyObject *args) {
         rank_tmpl = template_dict(ranks);
         if (!rank_tmpl) PyErr_Clear();  /* (e.g. duplicate ranks: the dicts are built entry by entry) */
     }
-    a = section_mapping(p, n_rows, width, first_col, names, ranks, col, nh, rh, rank_tmpl, name_tmpl);
+    a = section_mapping(p, n_rows, width, first_col, names, ranks, col, nh, rh, rank_tmpl, name_tmpl, take_recycled(recycle, 0));
     if (!a) goto done;
+    keep_recycled(recycle, 0, a);
     if (second_col >= 0) {
-        b = section_mapping(p, n_rows, width, second_col, names, ranks, col, nh, rh, rank_tmpl, name_tmpl);
+        b = section_mapping(p, n_rows, width, second_col, names, ranks, col, nh, rh, rank_tmpl, name_tmpl, take_recycled(recycle, 1));
         if (!b) goto done;
+        keep_recycled(recycle, 1, b);
         out = PyTuple_Pack(2, a, b);
     } else {
         out = a;
@@ -294,10 +370,13 @@ done:
 static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
     PyObject *names, *keys, *rows;
     Py_buffer view;
-    PyObject *name_tmpl = Py_None;
-    if (!PyArg_ParseTuple(args, "O!O!y*O!|O", &PyTuple_Type, &names, &PyTuple_Type, &keys, &view, &PyTuple_Type, &rows, &name_tmpl)) return NULL;
+    PyObject *name_tmpl = Py_None, *recycle = Py_None;
+    if (!PyArg_ParseTuple(args, "O!O!y*O!|OO", &PyTuple_Type, &names, &PyTuple_Type, &keys, &view, &PyTuple_Type, &rows, &name_tmpl, &recycle))
+        return NULL;
     if (name_tmpl == Py_None || !PyDict_CheckExact(name_tmpl)) name_tmpl = NULL;
+    if (recycle == Py_None || !PyList_CheckExact(recycle)) recycle = NULL;
     PyObject *out = NULL, *key_tmpl = NULL, *stack_inner[MAX_STACK_HASHES], **inner = NULL;
+    PyObject *prev = take_recycled(recycle, 0);
     Py_hash_t kh[6];
     const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
     const Py_ssize_t total_rows = view.len / (Py_ssize_t)(8 * sizeof(float));
@@ -320,6 +399,9 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
     }
     const float *p = (const float *)view.buf;
     Py_ssize_t built = 0;
+#if NVRX_INPLACE_POSSIBLE
+    nvrx_dict_entry310 *eo = recyclable_entries(prev, names, n_names);
+#endif
     for (; built < n_names; built++) {
         const long row = PyLong_AsLong(PyTuple_GET_ITEM(rows, built));
         if (row == -1 && PyErr_Occurred()) goto fail;
@@ -333,14 +415,38 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
          * cannot come out of the statistics kernel: ValueError / OverflowError from PyLong_FromDouble, the same exceptions
          * the Python builder raises */
         for (int k = 0; k < 6; k++) vals[k] = k == 5 ? PyLong_FromDouble((double)v[k]) : PyFloat_FromDouble((double)v[k]);
+#if NVRX_INPLACE_POSSIBLE
+        if (eo) {  /* the previous mapping is being refilled: nothing is collected in inner[] */
+            PyObject *old = eo[built].me_value;
+            if (refill_inner(old, keys, vals, 6)) continue;
+            PyObject *fresh = dict_from(keys, vals, 6, key_tmpl, kh, 0);  /* (also the way a non-finite NUM raises) */
+            if (!fresh) goto done;
+            eo[built].me_value = fresh;
+            Py_DECREF(old);
+            continue;
+        }
+#endif
         inner[built] = dict_from(keys, vals, 6, key_tmpl, kh, 0);
         if (!inner[built]) goto fail;
     }
+#if NVRX_INPLACE_POSSIBLE
+    if (eo) {
+        out = prev;
+        prev = NULL;
+        keep_recycled(recycle, 0, out);
+        goto done;
+    }
+#endif
     out = dict_from(names, inner, n_names, name_tmpl, NULL, 1);  /* consumes the inner dicts */
+    keep_recycled(recycle, 0, out);
     goto done;
 fail:
-    for (Py_ssize_t j = 0; j < built; j++) Py_DECREF(inner[j]);
+#if NVRX_INPLACE_POSSIBLE
+    if (!eo)
+#endif
+        for (Py_ssize_t j = 0; j < built; j++) Py_DECREF(inner[j]);
 done:
+    Py_XDECREF(prev);
     if (inner && inner != stack_inner) PyMem_Free(inner);
     Py_XDECREF(key_tmpl);
     PyBuffer_Release(&view);

@@ -111,7 +111,8 @@ def _row_selector(rows: Mapping[str, int]):
     return np.asarray(idx, dtype=np.intp)
 
 
-def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray, selector=None, name_template=None) -> Dict[str, Dict[Statistic, Any]]:
+def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray, selector=None, name_template=None,
+                         recycle=None, tuples=None) -> Dict[str, Dict[Statistic, Any]]:
     """``name -> {Statistic: value}`` from device statistics rows (``_get_section_summaries``' result shape,
     straggler.py:185-195), NUM as an integer as in the reference (straggler.py:194).  Built by ``_nvrx_pyread`` when it
     is there; else one C-level conversion of the whole block and one ``dict(zip(keys, row))`` per name (``Statistic``
@@ -119,7 +120,8 @@ def _summaries_from_rows(rows: Mapping[str, int], stats: np.ndarray, selector=No
     if not rows:
         return {}
     if _pyread is not None and stats.dtype == np.float32 and stats.flags.c_contiguous and stats.shape[1] == 8:
-        return _pyread.summaries(tuple(rows), STAT_KEYS, stats, tuple(rows.values()), name_template)
+        names, idx = tuples if tuples is not None else (tuple(rows), tuple(rows.values()))
+        return _pyread.summaries(names, STAT_KEYS, stats, idx, name_template, recycle)
     block = stats[_row_selector(rows) if selector is None else selector]
     vals = block[:, : NUM_COLUMN + 1].tolist()
     out = dict(zip(rows, map(dict, map(zip, itertools.repeat(STAT_KEYS), vals))))
@@ -289,6 +291,25 @@ class _View:
             t = self.memo()[("tmpl", which)] = dict.fromkeys(src)
             return t
 
+    def row_tuples(self, which: str):
+        """``(names, rows)`` of ``section_rows`` / ``kernel_rows`` as the two tuples ``_nvrx_pyread.summaries`` takes."""
+        try:
+            return self._memo[("rows", which)]
+        except (AttributeError, KeyError):
+            rows = getattr(self, which)
+            t = self.memo()[("rows", which)] = (tuple(rows), tuple(rows.values()))
+            return t
+
+    def recycle_list(self, which: str, slots: int = 1):
+        """The last mapping(s) ``_nvrx_pyread`` built for this plan: when nothing else refers to one any more (the report it
+        was built for is gone and nobody kept the dict) the next report's mapping is that very object with its values
+        swapped -- see csrc/nvrx_pyread.c, "recycling".  A list per kind of mapping, owned by the plan's memo."""
+        try:
+            return self._memo[("recycle", which)]
+        except (AttributeError, KeyError):
+            lst = self.memo()[("recycle", which)] = [None] * slots
+            return lst
+
     def col_index(self):
         """Score-table column of every name of ``names``, in that order (None: the identity)."""
         try:
@@ -446,6 +467,13 @@ class _ScoreSource:
         """One of the six mappings as a plain dict.  ``stash``: the report's ``__dict__`` -- a call that can build a
         sibling in the same pass (both section-score families share names, ranks and hashes) leaves it there."""
         v = self.view
+        if field == "local_section_summaries" or field == "local_kernel_summaries":  # (nothing of the score rows is needed)
+            which = "section_rows" if field == "local_section_summaries" else "kernel_rows"
+            rows = getattr(v, which)
+            if not rows:
+                return {}
+            return _summaries_from_rows(rows, self.statistics(), v.selector(which), v.name_template(which), v.recycle_list(which),
+                                        v.row_tuples(which))
         S = v.S
         raw = self.raw_scores() if _pyread is not None else None
         fast = raw is not None
@@ -458,7 +486,11 @@ class _ScoreSource:
             if not (v.has_rel if col else v.has_indiv):
                 return {}
             if fast:
-                return _pyread.ranks(v.rank_tuple(), buf, off, nrows, W, col)
+                rt = v.rank_tuple()
+                other = "gpu_individual_perf_scores" if col else "gpu_relative_perf_scores"
+                if stash is not None and other not in stash and (v.has_indiv if col else v.has_rel):
+                    stash[other] = _pyread.ranks(rt, buf, off, nrows, W, 1 - col)  # the sibling costs one more C call now, no frame later
+                return _pyread.ranks(rt, buf, off, nrows, W, col)
             return dict(zip(v.ranks, sc[:, col].tolist()))
         if field == "section_relative_perf_scores" or field == "section_individual_perf_scores":
             rel = field == "section_relative_perf_scores"
@@ -467,19 +499,14 @@ class _ScoreSource:
             other = "section_individual_perf_scores" if rel else "section_relative_perf_scores"
             if fast and stash is not None and other not in stash and (v.has_indiv if rel else v.has_rel):
                 mine, sibling = _pyread.sections(v.names_tuple(), v.rank_tuple(), buf, off, nrows, W,
-                                                 2 + S if rel else 2, v.col_tuple(), 2 if rel else 2 + S, v.name_template())
+                                                 2 + S if rel else 2, v.col_tuple(), 2 if rel else 2 + S, v.name_template(),
+                                                 v.recycle_list("sections", 2))
                 stash[other] = sibling
                 return mine
             if fast:
                 return _pyread.sections(v.names_tuple(), v.rank_tuple(), buf, off, nrows, W, 2 + S if rel else 2, v.col_tuple(), -1,
-                                        v.name_template())
+                                        v.name_template(), v.recycle_list("sections", 2))
             return self._sections(2 + S if rel else 2)
-        if field == "local_section_summaries":
-            return (_summaries_from_rows(v.section_rows, self.statistics(), v.selector("section_rows"), v.name_template("section_rows"))
-                    if v.section_rows else {})
-        if field == "local_kernel_summaries":
-            return (_summaries_from_rows(v.kernel_rows, self.statistics(), v.selector("kernel_rows"), v.name_template("kernel_rows"))
-                    if v.kernel_rows else {})
         raise AttributeError(field)
 
     def _sections(self, first_col: int) -> Dict[str, Dict[int, float]]:
@@ -972,7 +999,9 @@ class ReportGenerator:
         plan.ws = be.workspace(world * local_ranks, K, S, local_ranks, total_rows)
         plan.snames, plan.knames = snames, knames
         plan.rows_used = rings.rows_used
-        plan.stats_needed = rings.rows_used if rings.local_ranks == 1 else total_rows
+        # the report's local summaries are those of this process' FIRST logical rank (rank 0 of a folded job): its rows are
+        # the first rows_used statistics rows, whatever the number of logical ranks -- nothing else is forwarded or copied
+        plan.stats_needed = rings.rows_used
         plan.section_rows, plan.kernel_rows = section_rows, kernel_rows
         plan.fused = hasattr(rings, "report_fused")  # the HIP engine; the CPU test backend takes the stepwise route
         if self.gather_on_rank0:
@@ -1180,7 +1209,7 @@ class ReportGenerator:
         knames, snames = list(kernel_rows.keys()), list(section_rows.keys())
         rows_used = rings.rows_used
         total_rows = rings.local_ranks * rings.rows_per_rank
-        stats_needed = rows_used if rings.local_ranks == 1 else total_rows
+        stats_needed = rows_used  # (see _build_ring_plan)
 
         def fill_send(ws, mapper, names_ok):
             state = (id(mapper), mapper.version, rows_used, id(ws))

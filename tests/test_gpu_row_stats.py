@@ -288,6 +288,33 @@ def test_a_matrix_appended_to_consecutive_rows_at_once_matches_the_ring_of_the_r
         rings.close()
 
 
+def test_a_matrix_append_that_wraps_in_the_last_rows_of_the_ring_storage_stays_inside_it(be):
+    """The strided copy of ``nvrx_ring_push_device_rows`` starts in the middle of a row when the rings are part full: for the
+    LAST rows of the ring storage the pitch-times-height span of that copy reaches past the allocation (only the span, not
+    the bytes copied).  The runtime must neither refuse nor overrun: every ring, the last one included, holds exactly the
+    newest samples, again and again."""
+    cap, R = 96, 6
+    rings = be.make_rings(1, R, cap)              # the matrix covers ALL rows: the last row ends the allocation
+    try:
+        rows = [rings.row_for(0, f"s{r}") for r in range(R)]
+        assert rows == list(range(R))
+        rng = np.random.default_rng(3)
+        hist = [[] for _ in range(R)]
+        for it in range(40):
+            n = int(rng.integers(1, 2 * cap))
+            m = rng.random((R, n), dtype=np.float32)
+            rings.push_device_rows(0, torch.from_numpy(m).cuda())
+            for r in range(R):
+                hist[r] += m[r].tolist()
+        torch.cuda.synchronize()
+        for r in range(R):
+            exp = oracle.ring_run(np.asarray(hist[r], dtype=np.float32), cap)
+            stored = rings.read_row(rows[r])[: exp.size]
+            assert sorted(stored.tolist()) == sorted(exp.tolist()), r
+    finally:
+        rings.close()
+
+
 @pytest.mark.parametrize("cap,rows,n", [(16, 40, 3000), (64, 300, 20000), (100, 4096, 409600)])
 def test_bulk_append_of_row_value_pairs_matches_the_ring_of_the_reference(be, cap, rows, n):
     """nvrx_ring_push_pairs (the per-kernel tracer's route into the rings: one scatter launch for all keys) == the

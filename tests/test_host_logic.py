@@ -1243,6 +1243,124 @@ def test_inplace_filled_dicts_are_ordinary_dicts():
         pr.inplace(1 if was else 0)
 
 
+def test_mappings_nobody_holds_are_recycled_and_held_ones_are_never_touched():
+    """``_nvrx_pyread`` keeps the last mapping it built per plan (a list the caller owns) and, when NOTHING else refers to it,
+    hands the very same dicts out again with the next report's values swapped in -- no dict is created.  The contract: what
+    comes back always equals what the plain builder gives; an object somebody still holds -- the outer dict, one inner
+    dict, a value -- is never modified; a mapping the caller changed (key added, value replaced) is not trusted."""
+    import gc
+    import tracemalloc
+
+    from nvrx_straggler import reporting
+    from nvrx_straggler.statistics import STAT_KEYS
+
+    pr = reporting._pyread
+    assert pr is not None
+    if not pr.inplace():
+        pytest.skip("recycling rides on the in-place fill (CPython 3.10 only)")
+    rng = np.random.default_rng(11)
+    R, S = 8, 64
+    W = 2 + 2 * S
+    names = tuple(f"section_{i:03d}" for i in range(S))
+    ranks = tuple(range(R))
+    rows = tuple(range(S))
+    tmpl = dict.fromkeys(names)
+
+    def blocks():
+        sc = rng.uniform(0.5, 1.0, (R, W)).astype(np.float32)
+        st = rng.uniform(1.0, 2.0, (S, 8)).astype(np.float32)
+        st[:, 5] = rng.integers(1, 10000, S)
+        return sc, st
+
+    def plain(sc, st):
+        return pr.sections(names, ranks, sc, 0, R, W, 2, None, 2 + S), pr.summaries(names, STAT_KEYS, st, rows)
+
+    keep_s, keep_m = [None, None], [None]
+
+    def build(sc, st):
+        return pr.sections(names, ranks, sc, 0, R, W, 2, None, 2 + S, tmpl, keep_s), pr.summaries(names, STAT_KEYS, st, rows, tmpl, keep_m)
+
+    # 1. dropped by the caller -> the same objects come back, refilled
+    sc, st = blocks()
+    (a, b), m = build(sc, st)
+    assert ((a, b), m) == plain(sc, st) and keep_s[0] is a and keep_s[1] is b and keep_m[0] is m
+    ids = (id(a), id(b), id(m), id(a[names[5]]), id(m[names[5]]))
+    del a, b, m
+    sc, st = blocks()
+    (a, b), m = build(sc, st)
+    assert ((a, b), m) == plain(sc, st)
+    assert (id(a), id(b), id(m), id(a[names[5]]), id(m[names[5]])) == ids
+    assert type(m[names[0]][STAT_KEYS[5]]) is int and list(a) == list(names) and list(a[names[0]]) == list(ranks)
+
+    # 2. the caller still holds them -> fresh objects, the held ones keep their values
+    held = ((a, b), m)
+    frozen = plain(sc, st)
+    sc2, st2 = blocks()
+    (a2, b2), m2 = build(sc2, st2)
+    assert a2 is not a and b2 is not b and m2 is not m
+    assert ((a2, b2), m2) == plain(sc2, st2) and held == frozen
+    del a, b, m, held
+
+    # 3. only an INNER dict (and one value) is held -> the outer is recycled, that inner one is replaced, not modified
+    inner_held, value_held = a2[names[7]], b2[names[2]][3]
+    inner_frozen, outer_id, other_inner_id = dict(inner_held), id(a2), id(a2[names[8]])
+    minner_held = m2[names[1]]
+    minner_frozen = dict(minner_held)
+    del a2, b2, m2
+    sc3, st3 = blocks()
+    (a3, b3), m3 = build(sc3, st3)
+    assert ((a3, b3), m3) == plain(sc3, st3)
+    assert id(a3) == outer_id and id(a3[names[8]]) == other_inner_id
+    assert a3[names[7]] is not inner_held and inner_held == inner_frozen
+    assert m3[names[1]] is not minner_held and minner_held == minner_frozen
+    assert isinstance(value_held, float)
+    del inner_held, minner_held
+
+    # 4. a mapping the caller changed is not trusted: grown, shrunk, a value that is not ours
+    a3["extra"] = {}
+    b3[names[0]][0] = ["not", "a", "float"]
+    m3[names[4]] = "replaced"
+    del m3[names[9]]
+    del a3, b3, m3
+    sc4, st4 = blocks()
+    (a4, b4), m4 = build(sc4, st4)
+    assert ((a4, b4), m4) == plain(sc4, st4)
+    assert id(a4) != outer_id and "extra" not in a4 and list(m4) == list(names)
+
+    # 5. an error in the middle of a refill leaves no half-built mapping behind
+    del a4, b4, m4
+    bad = st4.copy()
+    bad[10, 5] = np.nan
+    with pytest.raises(ValueError):
+        pr.summaries(names, STAT_KEYS, bad, rows, tmpl, keep_m)
+    assert keep_m == [None]
+    assert pr.summaries(names, STAT_KEYS, st4, rows, tmpl, keep_m) == plain(sc4, st4)[1]
+
+    # 6. nothing leaks: many refills, steady memory
+    (a, b), m = build(sc4, st4)
+    del a, b, m
+    gc.collect()
+    tracemalloc.start()
+    base = tracemalloc.get_traced_memory()[0]
+    for _ in range(300):
+        (a, b), m = build(sc4, st4)
+        del a, b, m
+    grown = tracemalloc.get_traced_memory()[0] - base
+    tracemalloc.stop()
+    assert grown < 64 * 1024, grown
+
+    # 7. with the in-place fill off nothing is recycled, everything is still right
+    try:
+        pr.inplace(0)
+        (a, b), m = build(sc4, st4)
+        first = id(a)
+        del a, b, m
+        (a, b), m = build(sc3, st3)
+        assert ((a, b), m) == plain(sc3, st3)
+    finally:
+        pr.inplace(1)
+
+
 @pytest.mark.parametrize("R,S", [(1, 1), (3, 7), (70, 5), (9, 300), (70, 300)])
 def test_c_builders_beyond_their_stack_buffers(R, S):
     """``_nvrx_pyread`` keeps its per-call scratch (values of one inner dict, hashes, column table) on the stack up to 64
