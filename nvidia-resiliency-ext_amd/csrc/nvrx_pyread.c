@@ -11,7 +11,7 @@
  *
  *   sections(names, ranks, buf, offset, n_rows, width, first_col, cols[, second_col]) -> {name: {rank: float}} (or a pair of them)
  *   ranks(ranks, buf, offset, n_rows, width, col) -> {rank: float}
- *   summaries(names, stat_keys, stats, rows) -> {name: {stat_key: float, ..., stat_keys[5]: int}}
+ *   summaries(names, stat_keys, stats, rows[, name_tmpl[, recycle[, offset]]]) -> {name: {stat_key: float, ..., stat_keys[5]: int}}
  *   inplace([on]) -> bool          is the in-place fill of cloned dicts active (CPython 3.10 only; see below)
  *   copy_sets(d) -> {key: set(value) for key, value in d.items()}      (fresh sets for every caller of identify_stragglers)
  *   flagged(buf, offset, rows, width, S, has_rel, has_indiv, ids, names, cols, memo) -> (gpu_rel, gpu_indiv, sec_rel, sec_indiv)
@@ -371,7 +371,9 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
     PyObject *names, *keys, *rows;
     Py_buffer view;
     PyObject *name_tmpl = Py_None, *recycle = Py_None;
-    if (!PyArg_ParseTuple(args, "O!O!y*O!|OO", &PyTuple_Type, &names, &PyTuple_Type, &keys, &view, &PyTuple_Type, &rows, &name_tmpl, &recycle))
+    Py_ssize_t offset = 0;  /* of the first statistics row inside buf (the result block itself, read in place) */
+    if (!PyArg_ParseTuple(args, "O!O!y*O!|OOn", &PyTuple_Type, &names, &PyTuple_Type, &keys, &view, &PyTuple_Type, &rows, &name_tmpl, &recycle,
+                          &offset))
         return NULL;
     if (name_tmpl == Py_None || !PyDict_CheckExact(name_tmpl)) name_tmpl = NULL;
     if (recycle == Py_None || !PyList_CheckExact(recycle)) recycle = NULL;
@@ -379,7 +381,11 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
     PyObject *prev = take_recycled(recycle, 0);
     Py_hash_t kh[6];
     const Py_ssize_t n_names = PyTuple_GET_SIZE(names);
-    const Py_ssize_t total_rows = view.len / (Py_ssize_t)(8 * sizeof(float));
+    if (offset < 0 || offset > view.len || (offset % (Py_ssize_t)sizeof(float)) != 0) {
+        PyErr_SetString(PyExc_ValueError, "nvrx_pyread.summaries: bad offset");
+        goto done;
+    }
+    const Py_ssize_t total_rows = (view.len - offset) / (Py_ssize_t)(8 * sizeof(float));
     if (PyTuple_GET_SIZE(keys) != 6 || PyTuple_GET_SIZE(rows) != n_names) {
         PyErr_SetString(PyExc_ValueError, "nvrx_pyread.summaries: six statistic keys and one row per name expected");
         goto done;
@@ -397,7 +403,7 @@ static PyObject *pyread_summaries(PyObject *self, PyObject *args) {
         PyErr_NoMemory();
         goto done;
     }
-    const float *p = (const float *)view.buf;
+    const float *p = (const float *)((const char *)view.buf + offset);
     Py_ssize_t built = 0;
 #if NVRX_INPLACE_POSSIBLE
     nvrx_dict_entry310 *eo = recyclable_entries(prev, names, n_names);

@@ -224,6 +224,28 @@ class _LiveBlock:
                     self._release()
         return self._stats
 
+    def in_place(self, fn, stats: bool):
+        """``fn(the block's pinned bytes)`` while the block is still this report's -- nothing is copied, not even for the
+        mapping builders: under the lock the generator cannot collect this report (``detach`` takes it too), and until it
+        has, nothing is enqueued that writes the block again.  ``stats``: the statistics rows are what is read (they have a
+        completion word of their own).  None when a private copy exists already or the block exports no flat buffer."""
+        with _LIVE_LOCK:
+            blk = self.blk
+            if blk is None or (self._stats if stats else self._head_bytes) is not None:
+                return None
+            live = getattr(blk, "_host", None)
+            if live is None:
+                return None
+            if stats:
+                if blk is self.ws:
+                    self.backend.wait_seq(self.ws, self.seq, stats=True)
+                else:
+                    self.backend.wait_seq(self.ws, self.seq, stats=True, block=blk)
+            try:
+                return fn(live)
+            except (BufferError, TypeError):
+                return None
+
     def detach(self) -> None:
         self.head_bytes()
         self.stats()
@@ -472,41 +494,63 @@ class _ScoreSource:
             rows = getattr(v, which)
             if not rows:
                 return {}
+            live = self.stats if self.stats is not None else self.pending
+            if _pyread is not None and type(live) is _LiveBlock and (self.scores is None or self.stats is live):
+                # the statistics rows straight out of the result block: no numpy copy of them for a report that only builds dicts
+                names, idx = v.row_tuples(which)
+                off_t = v.layout[2]
+                out = live.in_place(lambda buf: _pyread.summaries(names, STAT_KEYS, buf, idx, v.name_template(which),
+                                                                  v.recycle_list(which), off_t), True)
+                if out is not None:
+                    return out
             return _summaries_from_rows(rows, self.statistics(), v.selector(which), v.name_template(which), v.recycle_list(which),
                                         v.row_tuples(which))
-        S = v.S
-        raw = self.raw_scores() if _pyread is not None else None
-        fast = raw is not None
-        if fast:
-            buf, off, nrows, W = raw
-        else:
-            sc = self.ensure().scores
+        if _pyread is not None:
+            # (the score rows are NOT read in place from a live block: the builders walk them column by column, and strided
+            #  reads of the pinned, device-mapped block cost the CPU twice what one sequential copy of the head + reads of
+            #  the copy cost -- 12.0 against 6.7 us for both section families, tools/report_read_fields.py)
+            raw = self.raw_scores()
+            if raw is not None:
+                return self._score_field(field, stash, *raw)
+        sc = self.ensure().scores
         if field == "gpu_relative_perf_scores" or field == "gpu_individual_perf_scores":
             col = 1 if field == "gpu_relative_perf_scores" else 0
             if not (v.has_rel if col else v.has_indiv):
                 return {}
-            if fast:
-                rt = v.rank_tuple()
-                other = "gpu_individual_perf_scores" if col else "gpu_relative_perf_scores"
-                if stash is not None and other not in stash and (v.has_indiv if col else v.has_rel):
-                    stash[other] = _pyread.ranks(rt, buf, off, nrows, W, 1 - col)  # the sibling costs one more C call now, no frame later
-                return _pyread.ranks(rt, buf, off, nrows, W, col)
             return dict(zip(v.ranks, sc[:, col].tolist()))
         if field == "section_relative_perf_scores" or field == "section_individual_perf_scores":
             rel = field == "section_relative_perf_scores"
             if not ((v.has_rel if rel else v.has_indiv) and v.names):
                 return {}
+            return self._sections(2 + v.S if rel else 2)
+        raise AttributeError(field)
+
+    def _score_field(self, field: str, stash: Optional[dict], buf, off: int, nrows: int, W: int):
+        """A score mapping built by ``_nvrx_pyread`` from the [nrows, W] f32 rows at ``buf + off``; never None."""
+        v = self.view
+        S = v.S
+        if field == "gpu_relative_perf_scores" or field == "gpu_individual_perf_scores":
+            col = 1 if field == "gpu_relative_perf_scores" else 0
+            if not (v.has_rel if col else v.has_indiv):
+                return {}
+            rt = v.rank_tuple()
+            other = "gpu_individual_perf_scores" if col else "gpu_relative_perf_scores"
+            if stash is not None and other not in stash and (v.has_indiv if col else v.has_rel):
+                stash[other] = _pyread.ranks(rt, buf, off, nrows, W, 1 - col)  # the sibling costs one more C call now, no frame later
+            return _pyread.ranks(rt, buf, off, nrows, W, col)
+        if field == "section_relative_perf_scores" or field == "section_individual_perf_scores":
+            rel = field == "section_relative_perf_scores"
+            if not ((v.has_rel if rel else v.has_indiv) and v.names):
+                return {}
             other = "section_individual_perf_scores" if rel else "section_relative_perf_scores"
-            if fast and stash is not None and other not in stash and (v.has_indiv if rel else v.has_rel):
+            if stash is not None and other not in stash and (v.has_indiv if rel else v.has_rel):
                 mine, sibling = _pyread.sections(v.names_tuple(), v.rank_tuple(), buf, off, nrows, W,
                                                  2 + S if rel else 2, v.col_tuple(), 2 if rel else 2 + S, v.name_template(),
                                                  v.recycle_list("sections", 2))
                 stash[other] = sibling
                 return mine
-            if fast:
-                return _pyread.sections(v.names_tuple(), v.rank_tuple(), buf, off, nrows, W, 2 + S if rel else 2, v.col_tuple(), -1,
-                                        v.name_template(), v.recycle_list("sections", 2))
-            return self._sections(2 + S if rel else 2)
+            return _pyread.sections(v.names_tuple(), v.rank_tuple(), buf, off, nrows, W, 2 + S if rel else 2, v.col_tuple(), -1,
+                                    v.name_template(), v.recycle_list("sections", 2))
         raise AttributeError(field)
 
     def _sections(self, first_col: int) -> Dict[str, Dict[int, float]]:
