@@ -1072,6 +1072,16 @@ __global__ void k_stamp_end(const unsigned long long *slot, float us_per_tick, f
     if (dst_cpu) *dst_cpu = cpu_value;
 }
 
+// nvrx_ring_push_device_rows: `width` floats of every row of a [rows][ld] matrix into ring rows `dpitch` floats apart.
+// blockIdx.y = row, the x dimension strides over the row: consecutive lanes, consecutive floats (coalesced both ways).
+__global__ void k_append_rows(float *__restrict__ dst, size_t dpitch, const float *__restrict__ src, size_t ld, int width, int rows) {
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float *s = src + (size_t)row * ld;
+        float *d = dst + (size_t)row * dpitch;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < width; i += gridDim.x * blockDim.x) d[i] = s[i];
+    }
+}
+
 __global__ void k_fill_f32(float *p, size_t n, float v) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -2662,8 +2672,8 @@ int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, 
 }
 
 // A [n_rows][ld] device matrix appended to n_rows consecutive rows at once.  Rows whose write position is the same (the
-// usual case: rings filled together) take ONE strided copy per ring segment -- two when the append wraps -- instead of a
-// copy per row; otherwise the rows go one by one, as nvrx_ring_push_device does.
+// usual case: rings filled together) take ONE copy launch per ring segment (k_append_rows; two when the append wraps)
+// instead of a copy per row; otherwise the rows go one by one.
 int nvrx_ring_push_device_rows(nvrx_ctx *ctx, int first_row, int n_rows, const float *d_values, int n, int ld, void *stream) {
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     if (n_rows < 0 || first_row < 0 || first_row + n_rows > ctx->rows)
@@ -2693,8 +2703,13 @@ int nvrx_ring_push_device_rows(nvrx_ctx *ctx, int first_row, int n_rows, const f
         while (left > 0) {
             const int slot = (int)(pos % cap);
             const int chunk = std::min(left, (int)cap - slot);
-            HIP_TRY(hipMemcpy2DAsync(base + slot, (size_t)ctx->row_stride * sizeof(float), src, (size_t)ld * sizeof(float),
-                                     (size_t)chunk * sizeof(float), together ? (size_t)n_rows : 1, hipMemcpyDeviceToDevice, st));
+            // (a kernel of our own, not hipMemcpy2DAsync: nothing but the bytes named here is touched, and it is ordered on
+            //  `st` like every other ring writer)
+            const int bx = std::min((chunk + 255) / 256, 64);
+            const int ny = together ? n_rows : 1;
+            hipLaunchKernelGGL(k_append_rows, dim3((unsigned)bx, (unsigned)std::min(ny, 65535)), dim3(256), 0, st, base + slot,
+                               (size_t)ctx->row_stride, src, (size_t)ld, chunk, ny);
+            HIP_TRY(hipGetLastError());
             src += chunk;
             pos += (uint64_t)chunk;
             left -= chunk;
