@@ -1,0 +1,19 @@
+"""A short run of tools/soak.py: context create / destroy cycles, matrix loads, synchronous and asynchronous Detector
+reports with GPU-timed sections on two streams, reports read late or never, PyTorch allocations in between -- every report
+checked, and a GPU memory fault anywhere aborts the process (the long form, 2 x 50 s = 5 100 contexts / 36 000 reports, is in
+docs/MEASUREMENTS.md)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_soak_of_the_product_flows_for_a_few_seconds():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "NVRX_GPU_TIMING")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "soak.py"), "8"], capture_output=True, text=True, timeout=240, env=env)
+    assert p.returncode == 0, p.stdout[-1500:] + "\n" + p.stderr[-3000:]
+    assert "soak ok" in p.stdout
