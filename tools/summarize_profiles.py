@@ -27,7 +27,7 @@ def short(name):
     if m and m.group(2) != "5":  # <512,5> is the bench shape; other tiles come from the overhead leg
         return f"k_row_stats<{m.group(1)},{m.group(2)}>"
     for k in ("k_row_stats", "k_score1", "k_score", "k_peer_allgather", "k_scatter", "k_colmin", "k_send_init", "k_fill_f32",
-              "k_stamp_begin", "k_stamp_end"):
+              "k_stamp_begin", "k_stamp_end", "k_append_rows"):
         if k in name:
             return k
     return name[:40]
