@@ -3147,7 +3147,18 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
         {
             std::lock_guard<std::mutex> lk(ctx->mu);
             HIP_TRY(hipSetDevice(ctx->device));
-            if (!ctx->score_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->score_stream, hipStreamNonBlocking));
+            if (!ctx->score_stream) {
+                // the resident scorer's stream at high priority, like the detector's own (backend.py, _stream_priority):
+                // its one workgroup is dispatched ahead of a busy training stream's next ones; NVRX_STREAM_PRIORITY=normal|0|off
+                const char *pe = getenv("NVRX_STREAM_PRIORITY");
+                if (!(pe && (pe[0] == 'n' || pe[0] == 'N' || pe[0] == '0' || pe[0] == 'o' || pe[0] == 'O'))) {
+                    int least = 0, greatest = 0;  // (numerically lower = higher priority)
+                    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                    HIP_TRY(hipStreamCreateWithPriority(&ctx->score_stream, hipStreamNonBlocking, greatest));
+                } else {
+                    HIP_TRY(hipStreamCreateWithFlags(&ctx->score_stream, hipStreamNonBlocking));
+                }
+            }
             // the score kernel becomes dispatchable when the statistics kernel does, not before
             if (d->order_after_enabled && d->order_after_stream != stream)
                 HIP_TRY(hipStreamWaitEvent(ctx->score_stream, ctx->order_ev, 0));
