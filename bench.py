@@ -532,10 +532,42 @@ def _section_entry_leg(entries: int = 3000):
         out["stream_us_per_gpu_timed_entry"] = 3.5
         out["note"] = ("host time of one detection_section entry with an empty body, median of %d; reference_python_us = BASELINE.md "
                        "section 3 (survey probe of the reference's Python path); stream_us_per_gpu_timed_entry = what the two "
-                       "stamp kernels add to a busy user stream (tools/archive/micro/stamp_cost.cpp, profiles/r04e_stamp_cost.txt)" % entries)
-        return out
+                       "stamp kernels add to a busy user stream (tools/archive/micro/stamp_cost.cpp, profiles/r04e_stamp_cost.txt); "
+                       "profile_cuda_true_event_mode_us = the same entry with NVRX_GPU_TIMING=event (a hipEventRecord pair: no "
+                       "kernel arguments to place, +7.9 us of stream time instead of +3.5)" % entries)
     finally:
         Detector.shutdown()
+    # the same entry timed by a hipEvent pair (NVRX_GPU_TIMING=event is read when the Detector's profiler is built)
+    saved = os.environ.get("NVRX_GPU_TIMING")
+    os.environ["NVRX_GPU_TIMING"] = "event"
+    try:
+        Detector.initialize(scores_to_compute=["individual_perf_scores"], gather_on_rank0=False, node_name="node0")
+        try:
+            for _ in range(200):
+                with Detector.detection_section("entry_event", profile_cuda=True):
+                    pass
+            torch.cuda.synchronize()
+            Detector.generate_report()
+            t = []
+            for i in range(min(entries, 2000)):
+                t0 = time.perf_counter_ns()
+                with Detector.detection_section("entry_event", profile_cuda=True):
+                    pass
+                t.append(time.perf_counter_ns() - t0)
+                if len(t) % 256 == 0:
+                    torch.cuda.synchronize()
+                    Detector.generate_report()      # (harvests the event pairs: the pool is finite)
+            out["profile_cuda_true_event_mode_us"] = round(float(np.median(t)) / 1e3, 2)
+        finally:
+            Detector.shutdown()
+    except Exception as e:  # noqa: BLE001  (an extra figure: its failure must not take the leg down)
+        out["profile_cuda_true_event_mode_us"] = f"{type(e).__name__}: {str(e)[-200:]}"
+    finally:
+        if saved is None:
+            os.environ.pop("NVRX_GPU_TIMING", None)
+        else:
+            os.environ["NVRX_GPU_TIMING"] = saved
+    return out
 
 
 def _side_leg(fn, *a, **k):
