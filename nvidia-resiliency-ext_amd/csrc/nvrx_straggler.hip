@@ -28,6 +28,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "nvrx_straggler.h"
@@ -1065,6 +1066,25 @@ __global__ void k_scatter(const uint32_t *__restrict__ h_counts, const StagedSam
 // ------------------------------------------------------------------------------------------------
 __global__ void k_stamp_begin(unsigned long long *slot) { *slot = wall_clock64(); }
 
+// The same without a kernel argument, one instantiation per stamp slot.  This platform places kernel arguments in device
+// memory (HIP_FORCE_DEV_KERNARG defaults to 1): a launch WITH arguments writes them through the PCIe BAR and waits for the
+// write before it rings the doorbell -- 3.4-3.8 us of host time per launch against 1.3-2.3 us for a kernel that has none
+// (tools/archive/micro/launch_cost.cpp).  The slot is a compile-time constant, its storage a __device__ array (one per
+// device, shared by the contexts of a process; slots are handed out process-wide).
+constexpr int NVRX_NSTAMP = 256;
+__device__ unsigned long long g_stamp_slots[NVRX_NSTAMP];
+template <int SLOT>
+__global__ void k_stamp_begin_at() {
+    g_stamp_slots[SLOT] = wall_clock64();
+}
+using StampBeginFn = void (*)();
+template <int... I>
+static const StampBeginFn *stamp_begin_table(std::integer_sequence<int, I...>) {
+    static const StampBeginFn table[] = {k_stamp_begin_at<I>...};
+    return table;
+}
+static const StampBeginFn *const g_stamp_begin_fn = stamp_begin_table(std::make_integer_sequence<int, NVRX_NSTAMP>{});
+
 __global__ void k_stamp_end(const unsigned long long *slot, float us_per_tick, float *dst_gpu, float *dst_cpu,
                             float cpu_value) {
     const unsigned long long t = wall_clock64();
@@ -1986,8 +2006,10 @@ struct nvrx_ctx {
     std::vector<uint32_t> bulk_cnt, bulk_seen;
 
     // device-side region timing (k_stamp_begin / k_stamp_end)
-    static constexpr int NSTAMP = 256;
-    unsigned long long *d_stamps = nullptr;  // [NSTAMP] begin timestamps, handed out round-robin
+    static constexpr int NSTAMP = NVRX_NSTAMP;
+    unsigned long long *d_stamps = nullptr;  // [NSTAMP] begin timestamps, handed out round-robin: the device's g_stamp_slots
+                                             // (argument-free begin kernels, the default) or an allocation of this context
+    bool stamps_argfree = true;              // NVRX_STAMP_ARGFREE=0: the one-argument begin kernel
     int stamp_next = 0;
     float us_per_tick = 0.01f;
     struct OpenStamp {
@@ -2436,8 +2458,16 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
         ctx->h_gather_err[0] = 0;
         CTX_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->d_gather_err), ctx->h_gather_err, 0));
     }
-    CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
-    CTX_TRY(hipMemset(ctx->d_stamps, 0, nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
+    {
+        const char *e = getenv("NVRX_STAMP_ARGFREE");
+        ctx->stamps_argfree = !(e && e[0] == '0');
+    }
+    if (ctx->stamps_argfree) {
+        CTX_TRY(hipGetSymbolAddress(reinterpret_cast<void **>(&ctx->d_stamps), HIP_SYMBOL(g_stamp_slots)));
+    } else {
+        CTX_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps), nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
+        CTX_TRY(hipMemset(ctx->d_stamps, 0, nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
+    }
     {
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) {
@@ -2496,7 +2526,7 @@ int nvrx_ctx_destroy(nvrx_ctx *ctx) {
     if (ctx->score_stream) (void)hipStreamDestroy(ctx->score_stream);
     if (ctx->d_rowg) (void)hipFree(ctx->d_rowg);
     if (ctx->h_gather_err) (void)hipHostFree(ctx->h_gather_err);
-    if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
+    if (ctx->d_stamps && !ctx->stamps_argfree) (void)hipFree(ctx->d_stamps);
     delete ctx;
     return NVRX_OK;
 }
@@ -2907,9 +2937,17 @@ int nvrx_stamp_begin(nvrx_ctx *ctx, int row, void *stream) {
         ctx->regions_skipped++;
         return NVRX_REGION_SKIPPED;
     }
-    const int slot = ctx->stamp_next;
-    ctx->stamp_next = (ctx->stamp_next + 1) % nvrx_ctx::NSTAMP;
-    hipLaunchKernelGGL(k_stamp_begin, dim3(1), dim3(1), 0, as_stream(stream), ctx->d_stamps + slot);
+    int slot;
+    if (ctx->stamps_argfree) {
+        // the slots are the device's, shared by every context of the process on it: handed out process-wide
+        static std::atomic<unsigned> g_next{0};
+        slot = (int)(g_next.fetch_add(1u, std::memory_order_relaxed) % (unsigned)nvrx_ctx::NSTAMP);
+        hipLaunchKernelGGL(g_stamp_begin_fn[slot], dim3(1), dim3(1), 0, as_stream(stream));
+    } else {
+        slot = ctx->stamp_next;
+        ctx->stamp_next = (ctx->stamp_next + 1) % nvrx_ctx::NSTAMP;
+        hipLaunchKernelGGL(k_stamp_begin, dim3(1), dim3(1), 0, as_stream(stream), ctx->d_stamps + slot);
+    }
     HIP_TRY(hipGetLastError());
     ctx->open_stamps.push_back({row, slot});
     return NVRX_OK;
