@@ -69,9 +69,24 @@ def main():
              f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}` (N=1: 8 logical ranks x 64 sections x "
              "10000 samples on one MI355X; kernel source sha " + kernel_source_sha() + ")", "",
              "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
+    # (k_stamp_begin is one argument-free instantiation per stamp slot: 256 kernel names, one line here)
+    merged, order = {}, []
     for r in rows:
-        lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | "
-                     f"{float(r['MaxNs'])/1e3:.2f} | {float(r['Percentage']):.1f} |")
+        k = short(r["Name"])
+        key = k if k == "k_stamp_begin" else r["Name"]
+        calls, total = int(r["Calls"]), float(r["TotalDurationNs"])
+        if key not in merged:
+            merged[key] = [k, 0, 0.0, float("inf"), 0.0, 0.0]
+            order.append(key)
+        m = merged[key]
+        m[1] += calls
+        m[2] += total
+        m[3] = min(m[3], float(r["MinNs"]))
+        m[4] = max(m[4], float(r["MaxNs"]))
+        m[5] += float(r["Percentage"])
+    for key in sorted(order, key=lambda q: -merged[q][2]):
+        k, calls, total, mn, mx, pct = merged[key]
+        lines.append(f"| {k} | {calls} | {total/max(calls,1)/1e3:.2f} | {mn/1e3:.2f} | {mx/1e3:.2f} | {pct:.1f} |")
     # the same trace split by launch size: k_row_stats runs at the bench shape (512 rows), at the N=8 per-GPU shape (64
     # rows) and, in the Detector legs, on a handful of rows; the stats table above averages over all of them
     by_size = collections.defaultdict(list)
