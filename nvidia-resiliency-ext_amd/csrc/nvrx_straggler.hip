@@ -1071,7 +1071,7 @@ __global__ void k_stamp_begin(unsigned long long *slot) { *slot = wall_clock64()
 // write before it rings the doorbell -- 3.4-3.8 us of host time per launch against 1.3-2.3 us for a kernel that has none
 // (tools/archive/micro/launch_cost.cpp).  The slot is a compile-time constant, its storage a __device__ array (one per
 // device, shared by the contexts of a process; slots are handed out process-wide).
-constexpr int NVRX_NSTAMP = 256;
+constexpr int NVRX_NSTAMP = 64;  // (the Python layer times the OUTERMOST region only -- cupti.py -- so two are open at most; 64 kernel names is what a user's own profile of the job shows at worst)
 __device__ unsigned long long g_stamp_slots[NVRX_NSTAMP];
 template <int SLOT>
 __global__ void k_stamp_begin_at() {

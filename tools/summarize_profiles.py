@@ -69,7 +69,7 @@ def main():
              f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}` (N=1: 8 logical ranks x 64 sections x "
              "10000 samples on one MI355X; kernel source sha " + kernel_source_sha() + ")", "",
              "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
-    # (k_stamp_begin is one argument-free instantiation per stamp slot: 256 kernel names, one line here)
+    # (k_stamp_begin is one argument-free instantiation per stamp slot: 64 kernel names, one line here)
     merged, order = {}, []
     for r in rows:
         k = short(r["Name"])
