@@ -294,8 +294,19 @@ def _stream_priority() -> int:
     units; on a high-priority queue its few workgroups are dispatched ahead of the GEMM's next ones instead of behind them
     (nothing running is preempted).  Same-box A/B, three alternating rounds of config #4: a report every step costs the step
     1.15 / 1.15 / 0.80 % at normal priority, 0.96 / 0.83 / 0.77 % at high (asynchronous); 3.43 / 3.10 / 2.93 against
-    3.01 / 3.00 / 2.91 % (synchronous); no effect on an idle GPU (profiles/r04p_stream_priority.txt)."""
-    return 0 if os.environ.get("NVRX_STREAM_PRIORITY", "high").strip().lower() in ("normal", "0", "off") else -1
+    3.01 / 3.00 / 2.91 % (synchronous); no effect on an idle GPU (profiles/r04p_stream_priority.txt).
+
+    That is the default of a SINGLE-process job only.  In a multi-rank job the detector's stream also carries the report's
+    RCCL all-gather, beside the job's own collectives on other streams and communicators; which of two communicators' kernels
+    is dispatched first is better left to the order they were enqueued in until a run across real GPUs says otherwise, so the
+    default there stays normal (``NVRX_STREAM_PRIORITY=high`` asks for it by name)."""
+    want = os.environ.get("NVRX_STREAM_PRIORITY", "").strip().lower()
+    if not want:
+        from . import ktrace as _ktrace  # (the launcher's job size: WORLD_SIZE, else srun's / mpirun's / PMI's)
+
+        want = "normal" if _ktrace._job_size()[0] > 1 else "high"
+        os.environ["NVRX_STREAM_PRIORITY"] = want  # the library reads the same switch for the resident scorer's stream
+    return 0 if want in ("normal", "0", "off") else -1
 
 
 class HipBackend:
