@@ -3186,10 +3186,23 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
             std::lock_guard<std::mutex> lk(ctx->mu);
             HIP_TRY(hipSetDevice(ctx->device));
             if (!ctx->score_stream) {
-                // the resident scorer's stream at high priority, like the detector's own (backend.py, _stream_priority):
-                // its one workgroup is dispatched ahead of a busy training stream's next ones; NVRX_STREAM_PRIORITY=normal|0|off
+                // the resident scorer's stream follows the rule of the detector's own (backend.py, _stream_priority): high
+                // priority in a single-process job -- its one workgroup is dispatched ahead of a busy training stream's next
+                // ones --, normal in a multi-rank job; NVRX_STREAM_PRIORITY=high|normal names it outright
+                bool high = true;
                 const char *pe = getenv("NVRX_STREAM_PRIORITY");
-                if (!(pe && (pe[0] == 'n' || pe[0] == 'N' || pe[0] == '0' || pe[0] == 'o' || pe[0] == 'O'))) {
+                if (pe && *pe) {
+                    high = !(pe[0] == 'n' || pe[0] == 'N' || pe[0] == '0' || pe[0] == 'o' || pe[0] == 'O');
+                } else {
+                    for (const char *var : {"WORLD_SIZE", "SLURM_NTASKS", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE"}) {
+                        const char *v = getenv(var);
+                        if (!v || !*v) continue;
+                        const long n = strtol(v, nullptr, 10);
+                        if (n > 1) high = false;
+                        if (n > 1 || strcmp(var, "WORLD_SIZE") == 0) break;  // WORLD_SIZE, where present, has the word (ktrace._job_size)
+                    }
+                }
+                if (high) {
                     int least = 0, greatest = 0;  // (numerically lower = higher priority)
                     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
                     HIP_TRY(hipStreamCreateWithPriority(&ctx->score_stream, hipStreamNonBlocking, greatest));

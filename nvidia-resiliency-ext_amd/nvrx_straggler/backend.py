@@ -304,8 +304,7 @@ def _stream_priority() -> int:
     if not want:
         from . import ktrace as _ktrace  # (the launcher's job size: WORLD_SIZE, else srun's / mpirun's / PMI's)
 
-        want = "normal" if _ktrace._job_size()[0] > 1 else "high"
-        os.environ["NVRX_STREAM_PRIORITY"] = want  # the library reads the same switch for the resident scorer's stream
+        want = "normal" if _ktrace._job_size()[0] > 1 else "high"  # (the library applies the same rule to the resident scorer's stream)
     return 0 if want in ("normal", "0", "off") else -1
 
 

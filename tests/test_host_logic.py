@@ -1418,7 +1418,7 @@ def test_c_builders_beyond_their_stack_buffers(R, S):
 def test_stream_priority_default_is_high_for_a_single_process_and_normal_for_a_multi_rank_job(monkeypatch):
     """``backend._stream_priority``: the detector's own streams run at high HIP priority in a single-process job (measured
     gain, nothing to interact with); in a multi-rank job they carry the report's RCCL all-gather beside the job's own
-    collectives, and the default stays normal; ``NVRX_STREAM_PRIORITY`` names it outright and is exported for the library."""
+    collectives, and the default stays normal; ``NVRX_STREAM_PRIORITY`` names it outright (the library applies the same rule to the resident scorer's stream)."""
     from nvrx_straggler import backend, ktrace
 
     def prio(env):
@@ -1428,10 +1428,11 @@ def test_stream_priority_default_is_high_for_a_single_process_and_normal_for_a_m
             monkeypatch.setenv(k, v)
         return backend._stream_priority(), os.environ.get("NVRX_STREAM_PRIORITY")
 
-    assert prio({}) == (-1, "high")
-    assert prio({"WORLD_SIZE": "1"}) == (-1, "high")
-    assert prio({"WORLD_SIZE": "8"}) == (0, "normal")
-    assert prio({"SLURM_NTASKS": "4"}) == (0, "normal")
+    assert prio({}) == (-1, None)                       # (nothing is exported: child processes decide for themselves)
+    assert prio({"WORLD_SIZE": "1"}) == (-1, None)
+    assert prio({"WORLD_SIZE": "8"}) == (0, None)
+    assert prio({"SLURM_NTASKS": "4"}) == (0, None)
+    assert prio({"WORLD_SIZE": "1", "SLURM_NTASKS": "4"}) == (-1, None)
     assert prio({"WORLD_SIZE": "8", "NVRX_STREAM_PRIORITY": "high"}) == (-1, "high")
     assert prio({"NVRX_STREAM_PRIORITY": "normal"}) == (0, "normal")
     assert prio({"NVRX_STREAM_PRIORITY": "off"})[0] == 0
