@@ -62,7 +62,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 # tools/port_vs_reference_timing.py, build container (the only place that has /root/reference), round 4: one rank x 64 sections
 # x 10 000 samples -- reference 37.12 ms (summaries 35.99 + generate_report 1.13), port 37.49 ms (37.22 + 0.27)
 PORT_VS_REFERENCE = {"ratio": 1.01, "reference_ms": 37.12, "port_ms": 37.49, "host": "build container, 8 cpus, 1 torch thread",
-                     "source": "tools/port_vs_reference_timing.py (round 4; 0.99 in round 3)"}
+                     "source": "tools/port_vs_reference_timing.py (round 4; 0.99 in round 3)",
+                     "note": "NOT measured by this run: port (oracle/port_mp.py) vs the real reference, timed where both exist"}
 
 
 def _cpu_baseline(reps: int):
@@ -136,8 +137,7 @@ def _cpu_baseline(reps: int):
         "host_cpus": os.cpu_count(),
         # the reference tree does not exist on the GPU box, so what is timed is the port; how far the port's timing is
         # from the real reference's was measured where both exist (build container, same process, same inputs)
-        "port_vs_reference_ratio": PORT_VS_REFERENCE["ratio"],
-        "port_vs_reference": PORT_VS_REFERENCE,
+        "quoted_from_profiles": {"port_vs_reference": PORT_VS_REFERENCE},
     }
 
 
@@ -313,9 +313,13 @@ def _cadence_leg(reports: int, job=None):
 
 def _per_kernel_leg(reports: int = 12):
     """Per-kernel mode at the scale of the reference's own sizing (tests/straggler/unit/test_data_shared.py:62-66): K
-    kernel keys x 100 durations per report.  The records are synthetic (tracing 400 000 real launches per report is
-    not a benchmark step) and enter where the tracer's drained records enter: ``KernelTraceProfiler.ingest`` (key ->
-    row table, ONE ``nvrx_ring_push_pairs`` scatter), then one report over the K kernel rows."""
+    kernel keys x 100 durations per report.  The dispatch records are synthetic (tracing 400 000 real launches per report
+    is not a benchmark step) and take the tracer's NATIVE path: a feeder thread plays the rocprofiler-sdk callback thread
+    and hands batches of ~1100 records (what a 256 KB SDK buffer holds) to ``nvrx_ktrace_feed`` -> key cache -> sink ->
+    ``nvrx_ring_push_staged`` while the 'training' thread sleeps; the training thread's part of a report is ``harvest()``
+    (``nvrx_ktrace_sync``: a counter comparison, no record is touched) and then one report over the K kernel rows."""
+    import threading
+
     from nvrx_straggler import ktrace
     from nvrx_straggler.reporting import ReportGenerator
 
@@ -326,34 +330,213 @@ def _per_kernel_leg(reports: int = 12):
         gen = ReportGenerator(["relative_perf_scores", "individual_perf_scores"], gather_on_rank0=True, node_name="node0")
         try:
             rng = np.random.default_rng(K)
-            recs = np.empty(K * 100, dtype=ktrace.RECORD_DTYPE)
-            recs["key"] = rng.permutation(np.repeat(np.arange(K, dtype=np.uint32), 100))
-            recs["us"] = rng.lognormal(3.0, 0.3, K * 100).astype(np.float32)
+            base = (1 << 52) + (K << 20)
+            for k in range(K):
+                ktrace.feed_kernel_name(base + k, f"bench_kernel_{k:04d}")
+            d = np.zeros(K * 100, dtype=ktrace.DISPATCH_DTYPE)
+            d["kernel_id"] = base + rng.permutation(np.repeat(np.arange(K, dtype=np.uint64), 100))
+            d["workgroup"], d["grid"], d["start_ns"] = (256, 1, 1), (256 * 64, 1, 1), 1000
+            d["end_ns"] = 1000 + (rng.lognormal(3.0, 0.3, K * 100) * 1000.0).astype(np.uint64)
             rings = prof._rings
             no_sections = {}  # the same object every report: the generator's cached plan stays valid
-            t_in, t_rep = [], []
-            for i in range(reports + 2):
+            t_feed, t_in, t_rep = [], [], []
+
+            def feeder():
                 t0 = time.perf_counter_ns()
-                prof.ingest(recs)
+                for lo in range(0, d.size, 1100):
+                    ktrace.feed(d[lo:lo + 1100])
+                t_feed.append(time.perf_counter_ns() - t0)
+
+            for i in range(reports + 2):
+                th = threading.Thread(target=feeder)
+                th.start()
+                th.join()                       # (the window's kernels have all finished: nothing left to wait for)
+                t0 = time.perf_counter_ns()
+                missing = prof.harvest(wait=True)
                 t1 = time.perf_counter_ns()
                 rep = gen.generate_report_from_rings(rings, no_sections, rings.kernel_row_names)
                 score = rep.gpu_relative_perf_scores[0]
                 t2 = time.perf_counter_ns()
                 rings.reset()
+                assert missing == 0
                 if i >= 2:
                     t_in.append(t1 - t0)
                     t_rep.append(t2 - t1)
-            assert abs(score - 1.0) < 1e-6
-            out[f"K{K}"] = {"records_per_report": int(recs.size), "ingest_us_median": round(float(np.median(t_in)) / 1e3, 1),
-                            "report_us_median": round(float(np.median(t_rep)) / 1e3, 1)}
+            assert abs(score - 1.0) < 1e-6 and len(rings.kernel_row_names) == K
+            out[f"K{K}"] = {"records_per_report": int(d.size), "ingest_us_median": round(float(np.median(t_in)) / 1e3, 2),
+                            "report_us_median": round(float(np.median(t_rep)) / 1e3, 1),
+                            "tracer_thread_us_per_window": round(float(np.median(t_feed[2:])) / 1e3, 1),
+                            "tracer_thread_ns_per_record": round(float(np.median(t_feed[2:])) / d.size, 1)}
         finally:
             gen.close()
             prof.close()
             ktrace.KernelTraceProfiler._live = None
-    out["workload"] = ("K kernel keys x 100 durations per report (synthetic drained records): KernelTraceProfiler.ingest = key->row "
-                       "lookup + ONE scatter launch for all keys, then one report over the K kernel rows (statistics, GPU score) "
-                       "with its GPU score read")
+    out["workload"] = ("K kernel keys x 100 durations per report, fed as dispatch records through the tracer's native path by a "
+                       "feeder thread (the SDK callback thread's part: key cache -> sink -> staged ring appends, a scatter launch "
+                       "per 128 samples here); ingest_us = what the TRAINING thread does at report time (harvest = "
+                       "nvrx_ktrace_sync), report_us = one report over the K kernel rows with its GPU score read; round 4: "
+                       "K256 85.7 + 30.1 us, K4096 1310 + 196 us with the ingest on the training thread in Python")
     return out
+
+
+def _kernels_mode_child():
+    """``python bench.py --child kernels_mode``: the legs that need PER-KERNEL tracing, in a fresh interpreter -- the tracer
+    registers with rocprofiler-sdk before the HIP runtime starts, and the bench's main process has selected its device long
+    before.  Prints one JSON object.  This is the mode every multi-rank job runs in (``ktrace.timing_mode``).
+
+    * ``per_step_overhead_kernels`` -- BASELINE.json's second figure in that mode: a step with a realistic dispatch count
+      (8 pre-norm transformer layers, d_model 2048, 8 x 1024 tokens, bf16, forward + backward + SGD: > 500 kernel dispatches,
+      GPU-bound so the host runs ahead) inside ONE ``detection_section(profile_cuda=True)``.  Legs, A/B blocks alternating in
+      one process, medians over blocks: no detector / section every step, no report (production cadence between reports) at
+      ``profiling_interval`` 1 and 10 / a synchronous report EVERY step / an asynchronous report every step.  The reference's
+      claim for kernel profiling: < 1 % (docs/source/straggler_det/usage_guide.rst:169).
+    * ``report_at_cadence_kernels`` -- one report per 100 of those steps, each timed alone after the step's own device
+      synchronisation: synchronous (call -> flagged set) and asynchronous (the enqueue; read one interval later)."""
+    os.environ["NVRX_GPU_TIMING"] = "kernels"
+    import nvrx_straggler  # noqa: F401  (registers the tracer: nothing has touched HIP yet)
+    from nvrx_straggler import Detector, ktrace
+
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    d_model, layers, batch, seq = 2048, 8, 8, 1024
+    blocks = torch.nn.ModuleList([torch.nn.TransformerEncoderLayer(d_model, 16, 4 * d_model, dropout=0.0, batch_first=True,
+                                                                   norm_first=True) for _ in range(layers)])
+    blocks = blocks.to("cuda", torch.bfloat16)
+    opt = torch.optim.SGD(blocks.parameters(), lr=1e-6, foreach=True)
+    x = torch.randn(batch, seq, d_model, device="cuda", dtype=torch.bfloat16)
+
+    def train_step():
+        h = x
+        for blk in blocks:
+            h = blk(h)
+        h.float().square().mean().backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    for _ in range(3):
+        train_step()
+    torch.cuda.synchronize()
+    out = {"python": "%d.%d.%d" % sys.version_info[:3]}
+
+    def timed(fn, steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def overhead_legs(interval, steps, rounds):
+        Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="node0", profiling_interval=interval)
+        try:
+            def with_section():
+                with Detector.detection_section("train_step", profile_cuda=True):
+                    train_step()
+
+            def with_report():
+                with_section()
+                Detector.generate_report().identify_stragglers()
+
+            for _ in range(3):
+                with_report()
+            c0 = ktrace.counters()
+            with_section()
+            Detector.cupti_manager.harvest(wait=True)
+            dispatches = ktrace.counters()["enqueued"] - c0["enqueued"]
+            Detector.generate_report()
+            legs = [("without", train_step), ("section", with_section)] + ([("report_every_step", with_report)] if interval == 1 else [])
+            acc = {k: [] for k, _ in legs}
+            for r in range(rounds):
+                for name, fn in legs[r % len(legs):] + legs[:r % len(legs)]:
+                    acc[name].append(timed(fn, steps))
+                    if name == "section":
+                        Detector.generate_report()   # empties the rings (not timed)
+            med = {k: float(np.median(v)) for k, v in acc.items()}
+            res = {"profiling_interval": interval, "dispatches_traced_per_profiled_step": int(dispatches),
+                   "step_ms_without": round(med["without"] * 1e3, 4),
+                   "section_every_step_no_report_pct": round((med["section"] - med["without"]) / med["without"] * 100.0, 3),
+                   "section_added_us_per_step": round((med["section"] - med["without"]) * 1e6, 1)}
+            if "report_every_step" in med:
+                res["report_every_step_pct"] = round((med["report_every_step"] - med["without"]) / med["without"] * 100.0, 3)
+                res["report_every_step_added_us"] = round((med["report_every_step"] - med["without"]) * 1e6, 1)
+            return res
+        finally:
+            Detector.shutdown()
+
+    steps, rounds = 20, 6
+    try:
+        o1 = overhead_legs(1, steps, rounds)
+        o10 = overhead_legs(10, steps, rounds)
+        # one report per 100 steps on top of the section: what a job at the reference's default cadence pays per step
+        out["per_step_overhead_kernels"] = {
+            "profiling_interval_1": o1, "profiling_interval_10": o10,
+            "pct": o1["section_every_step_no_report_pct"],
+            "pct_at_profiling_interval_10": o10["section_every_step_no_report_pct"],
+            "steps_per_block": steps, "blocks": rounds, "counters": ktrace.counters(),
+            "workload": f"{layers} x TransformerEncoderLayer(d_model {d_model}, 16 heads, ffn {4 * d_model}, pre-norm, bf16), batch {batch} x "
+                        f"{seq} tokens, forward + backward + SGD inside ONE detection_section(profile_cuda=True), NVRX_GPU_TIMING=kernels "
+                        "(every dispatch of the section traced by name); pct = section every step, no report (what a step pays between "
+                        "two reports); report_every_step_pct = a synchronous generate_report() + identify_stragglers() after every step"}
+    except Exception as e:  # noqa: BLE001
+        out["per_step_overhead_kernels"] = {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
+
+    def cadence(asynchronous, reports):
+        Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="node0", asynchronous=asynchronous)
+        try:
+            t, t_late, t_harvest = [], [], []
+            held = None
+            for i in range(reports + 2):
+                for _ in range(60):
+                    with Detector.detection_section("train_step", profile_cuda=True):
+                        train_step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter_ns()
+                rep = Detector.generate_report()
+                if not asynchronous:
+                    rep.identify_stragglers()
+                t1 = time.perf_counter_ns()
+                if asynchronous and held is not None:
+                    held.identify_stragglers()
+                t2 = time.perf_counter_ns()
+                held = rep
+                if i >= 2:
+                    t.append(t1 - t0)
+                    t_late.append(t2 - t1)
+            a = np.asarray(t, dtype=np.float64) / 1e3
+            res = {"us_median": round(float(np.median(a)), 2), "us_p95": round(float(np.percentile(a, 95)), 2),
+                   "us_max": round(float(a.max()), 2), "reports": len(t)}
+            if asynchronous:
+                res["read_one_interval_later_us_median"] = round(float(np.median(t_late)) / 1e3, 2)
+            return res
+        finally:
+            Detector.shutdown()
+
+    try:
+        out["report_at_cadence_kernels"] = {
+            "synchronous": cadence(False, 5), "asynchronous": cadence(True, 5),
+            "workload": "the transformer step above in a GPU-timed section, 60 steps between reports, tens of thousands of traced dispatches per "
+                        "window appended to their rings by the tracer's thread as they complete; each generate_report() timed alone "
+                        "after the step's device synchronisation (synchronous: call -> identify_stragglers() returned)"}
+    except Exception as e:  # noqa: BLE001
+        out["report_at_cadence_kernels"] = {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
+    out["gpu_timing_mode"] = ktrace.timing_mode()
+    out["registered_through"] = ktrace._setup_route
+    print("KERNELS_MODE " + json.dumps(out), flush=True)
+
+
+def _kernels_mode_leg(timeout_s: float = 420.0):
+    """Run ``_kernels_mode_child`` in a fresh interpreter on the same GPU (this process is idle meanwhile)."""
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NVRX_GPU_TIMING"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "kernels_mode"], capture_output=True, text=True,
+                       timeout=timeout_s, env=env)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("KERNELS_MODE ")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"child exited {p.returncode}: {(p.stderr or p.stdout)[-400:]}"}
+    return json.loads(lines[-1][len("KERNELS_MODE "):])
 
 
 def _kernel_source_sha() -> str:
@@ -528,13 +711,13 @@ def _section_entry_leg(entries: int = 3000):
             out[label] = round(float(np.median(t)) / 1e3, 2)
             out[label.replace("_us", "_p95_us")] = round(float(np.percentile(t, 95)) / 1e3, 2)
             Detector.generate_report()
-        out["reference_python_us"] = 2.7
-        out["stream_us_per_gpu_timed_entry"] = 3.5
-        out["note"] = ("host time of one detection_section entry with an empty body, median of %d; reference_python_us = BASELINE.md "
-                       "section 3 (survey probe of the reference's Python path); stream_us_per_gpu_timed_entry = what the two "
-                       "stamp kernels add to a busy user stream (tools/archive/micro/stamp_cost.cpp, profiles/r04e_stamp_cost.txt); "
-                       "profile_cuda_true_event_mode_us = the same entry with NVRX_GPU_TIMING=event (a hipEventRecord pair: no "
-                       "kernel arguments to place, +7.9 us of stream time instead of +3.5)" % entries)
+        # NOT measured by this run: figures of earlier profile runs, kept apart so that nobody takes them for this box's
+        out["quoted_from_profiles"] = {
+            "reference_python_us": {"value": 2.7, "source": "BASELINE.md section 3 (survey probe of the reference's Python path, build container)"},
+            "stream_us_per_gpu_timed_entry": {"value": 3.5, "source": "profiles/r04e_stamp_cost.txt (tools/archive/micro/stamp_cost.cpp, round 4, "
+                                              "NVRX_STAMP_ARGFREE=1): what the two stamp kernels add to a busy user stream; a hipEventRecord pair: 7.9"}}
+        out["note"] = ("host time of one detection_section entry with an empty body, median of %d; "
+                       "profile_cuda_true_event_mode_us = the same entry with NVRX_GPU_TIMING=event (a hipEventRecord pair)" % entries)
     finally:
         Detector.shutdown()
     # the same entry timed by a hipEvent pair (NVRX_GPU_TIMING=event is read when the Detector's profiler is built)
@@ -631,7 +814,11 @@ def main():
     ap.add_argument("--no-cadence", action="store_true", help="skip the production-cadence leg (one report per 100 training steps)")
     ap.add_argument("--cadence-reports", type=int, default=30)
     ap.add_argument("--dump-steps", action="store_true", help="add the per-step latencies of the timed region to the JSON line")
+    ap.add_argument("--no-kernels-mode", action="store_true", help="skip the per-kernel-tracing legs (they run in a child interpreter)")
+    ap.add_argument("--child", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.child == "kernels_mode":
+        return _kernels_mode_child()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         if TOTAL_RANKS % args.gpus:
@@ -806,8 +993,41 @@ def main():
                 job.reporter._exchange(job.backend, ws)
                 job.backend.synchronize()
                 t_ex.append(time.perf_counter() - t0)
+            # the floor of that collective on this machine: ONE rank's row -- 129 floats = 516 B, the production payload of a
+            # one-rank-per-GPU job -- all-gathered on the SAME communicator and stream, nothing else enqueued
+            L1 = 2 * SECTIONS + 1
+            f_send = torch.zeros(L1, dtype=torch.float32, device="cuda")
+            f_recv = torch.zeros(world * L1, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            direct = job.reporter._direct
+            be_ = job.backend
+
+            def floor_once():
+                if direct is not None and hasattr(direct, "all_gather"):
+                    direct.all_gather(f_send.data_ptr(), f_recv.data_ptr(), L1, be_.stream_handle)
+                else:
+                    with be_.stream_context():
+                        dist.all_gather_into_tensor(f_recv, f_send)
+                be_.synchronize()
+
+            for _ in range(10):
+                floor_once()
+            t_fl = []
+            for _ in range(100):
+                t0 = time.perf_counter()
+                floor_once()
+                t_fl.append(time.perf_counter() - t0)
+            floor_us = float(np.median(t_fl)) * 1e6
             exchange = {"us_median": float(np.median(t_ex)) * 1e6,
-                        "route": getattr(job.reporter._direct, "route", "torch.distributed"),
+                        "floor_us": round(floor_us, 2),
+                        "floor_note": f"bare all-gather of {L1} f32 ({L1 * 4} B) per rank on the same communicator / stream + stream wait",
+                        # ring all-gather: every rank forwards (world - 1) rows over one xGMI link (~153 GB/s per link, MI355X_MICROARCH.md)
+                        "xgmi": {"bytes_per_link": int((world - 1) * ws.local_ranks * ws.L * 4), "peak_gbs_per_link": 153.0,
+                                 "achieved_gbs": round((world - 1) * ws.local_ranks * ws.L * 4 / (float(np.median(t_ex)) * 1e9) if t_ex else 0.0, 6),
+                                 "frac": round((world - 1) * ws.local_ranks * ws.L * 4 / (float(np.median(t_ex)) * 1e9) / 153.0, 8),
+                                 "note": "latency-bound by construction: half a kilobyte per rank; the fraction of the link's bandwidth is "
+                                         "reported because north_star asks for it, the figure to watch is us_median against floor_us"},
+                        "route": getattr(job.reporter._direct, "route", None) or job.reporter.exchange_info.get("route", "torch.distributed"),
                         "selection": dict(job.reporter.exchange_info),
                         "bytes_per_rank": int(ws.local_ranks * ws.L * 4),
                         "ranks": world, "distinct_devices": distinct_devices}
@@ -860,6 +1080,12 @@ def main():
         job.backend.synchronize()
         per_kernel = _side_leg(_per_kernel_leg)
 
+    kernels_mode = None
+    if world == 1 and not args.no_kernels_mode and not args.no_overhead:
+        job.backend.synchronize()
+        torch.cuda.synchronize()
+        kernels_mode = _side_leg(_kernels_mode_leg)
+
     overhead = overhead_async = None
     if not args.no_overhead:
         job.backend.synchronize()
@@ -904,6 +1130,7 @@ def main():
                 "exchange": "none (single process)" if world == 1 else f"1 all-gather of {job.local_ranks}x{2 * SECTIONS + 1} f32 per rank ({getattr(job.reporter._direct, 'route', 'torch.distributed ' + args.backend)})",
                 "target_us": 50,
             },
+            "python": "%d.%d.%d" % sys.version_info[:3],  # (nvrx_pyread.c fills CPython 3.10's dict layout in place; any other version takes the public-API path)
             "gpu_timing_mode": _ktrace.timing_mode(),  # how profile_cuda sections would be timed in these processes (kernels = the default of multi-rank jobs)
             # why: this script selects its device BEFORE it imports the package (the headline path has no sections), so even
             # at N > 1 the per-step-overhead leg runs on region stamps; a job that imports nvrx_straggler first gets `kernels`
@@ -967,6 +1194,12 @@ def main():
             out["per_step_overhead"] = overhead
         if overhead_async is not None:
             out["per_step_overhead_async"] = overhead_async
+        if kernels_mode is not None:
+            # the mode every multi-rank job runs in: measured in a child interpreter that registered the tracer before HIP started
+            for k in ("per_step_overhead_kernels", "report_at_cadence_kernels", "error"):
+                if k in kernels_mode:
+                    out[k if k != "error" else "kernels_mode_error"] = kernels_mode[k]
+            out["kernels_mode_registered_through"] = kernels_mode.get("registered_through")
         if host_inputs is not None:
             out["host_inputs"] = host_inputs
         if exchange is not None:

@@ -130,9 +130,15 @@ int nvrx_ctx_destroy(nvrx_ctx *ctx);
 /* Stream used for flushes triggered implicitly by a full staging buffer (default: null stream). */
 int nvrx_ctx_set_stream(nvrx_ctx *ctx, void *stream);
 /* Geometry queries: 0 local_ranks, 1 rows_per_rank, 2 ring_cap, 3 row_stride, 4 device; diagnostics: 5 reports re-homed,
- * 6 verdict of the last re-homing decision, 7 GPU-timed regions skipped because their stream was being captured. */
+ * 6 verdict of the last re-homing decision, 7 GPU-timed regions skipped because their stream was being captured; 8 rows
+ * of a logical rank handed out by nvrx_row_alloc so far. */
 int nvrx_ctx_info(const nvrx_ctx *ctx, int what);
 
+/* Hand out the next unused row of a logical rank (the same index in every logical rank of the context), configured as
+ * `kind`, not exchanged: the entry of a section name / kernel key seen for the first time -- unordered_map::emplace of
+ * CuptiProfiler.cpp:199-203, CustomSection creation of straggler.py:301-305.  Returns the row (>= 0) or NVRX_ERR_RANGE
+ * when all rows_per_rank rows are taken.  Thread-safe: the per-kernel tracer calls it on its own thread. */
+int nvrx_row_alloc(nvrx_ctx *ctx, int kind);
 /* Row metadata: kind (NVRX_KIND_*) and position `gid` in the exchange table (-1 = not exchanged).
  * `row` indexes [0, local_ranks*rows_per_rank). Takes effect at the next flush. */
 int nvrx_row_configure(nvrx_ctx *ctx, int row, int kind, int gid);
@@ -147,6 +153,11 @@ int nvrx_ring_push_many(nvrx_ctx *ctx, int row, const float *values, int n);
  * per-kernel tracer's drained records reach the rings: the reference appends every CUPTI record to its key's
  * CircularBuffer on the host (CuptiProfiler.cpp:186-207, CircularBuffer.h:53-61). */
 int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values, int n);
+/* The same n pairs appended one by one and STAGED like nvrx_ring_push: nothing is launched unless a staging buffer fills
+ * up; thread-safe.  This is the `push` of the per-kernel tracer's sink (include/nvrx_ktrace.h): the tracer's thread
+ * appends every kernel record to its key's ring as the records arrive, the way the reference does on CUPTI's thread
+ * (CuptiProfiler.cpp:168-207) -- the newest ring_cap durations per key survive (CircularBuffer.h:53-61). */
+int nvrx_ring_push_staged(nvrx_ctx *ctx, const int32_t *rows, const float *values, int n);
 /* Append n samples that already live in device memory (device-to-device, wraps as needed). */
 int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, void *stream);
 /* The same for n_rows consecutive rows at once: row first_row + r gets the n samples at d_values + r * ld (ld >= n).  Rows

@@ -1,14 +1,23 @@
 // nvrx_ktrace.cpp -- implementation of include/nvrx_ktrace.h on rocprofiler-sdk (host code only).
 //
 // Role in the straggler path: the reference's CuptiProfiler (cupti_src/CuptiProfiler.cpp) keeps, per kernel
-// key "<name>_blk_x_y_z_grid_x_y_z", a ring of durations fed from CUPTI activity records on CUPTI's thread.
-// Here the rocprofiler-sdk buffered KERNEL_DISPATCH service plays CUPTI's part; the rings and their
-// statistics live on the device (libnvrx_straggler_hip.so), so this file only turns dispatch records into
-// (key id, microseconds) pairs and hands them to whoever drains them.
+// key "<name>_blk_x_y_z_grid_x_y_z", an overwrite-oldest ring of durations fed from CUPTI activity records ON
+// CUPTI's thread (CuptiProfiler.cpp:168-207, CircularBuffer.h:53-61).  Here the rocprofiler-sdk buffered
+// KERNEL_DISPATCH service plays CUPTI's part and the SDK's callback thread plays CUPTI's thread: consume() turns a
+// batch of dispatch records into (ring row, microseconds) pairs -- one hash lookup per record on the dispatch's
+// (kernel id, launch geometry), the key string is only ever formatted the first time a geometry shows up -- and
+// appends the batch to the rings through the installed sink with ONE call.  The rings and their statistics live
+// on the device (libnvrx_straggler_hip.so).  What the training thread does at report time is nvrx_ktrace_sync().
 //
-// Threads: the SDK's callback thread runs on_records() / on_code_object(); the application thread calls the
-// exported functions.  One mutex guards the shared state (the reference: _kernelDurationsMutex,
-// CuptiProfiler.cpp:174).  nvrx_ktrace_flush() calls rocprofiler_flush_buffer WITHOUT holding it, as the
+// Threads:
+//   * launching threads: on_dispatch_enqueue() -- one relaxed atomic increment per traced dispatch;
+//   * the SDK's callback thread: on_records() -> consume(); code-object callbacks arrive on whichever thread
+//     loads the code object;
+//   * the pump thread (ours): after nvrx_ktrace_stop() it flushes the SDK's buffer until every dispatch of the
+//     window has arrived, so that the records reach the rings while the job trains on;
+//   * the application thread: the exported functions.
+// One mutex guards the shared state (the reference: _kernelDurationsMutex, CuptiProfiler.cpp:174); it is held for
+// a whole batch, including the sink's push.  rocprofiler_flush_buffer is always called WITHOUT it, as the
 // reference flushes before taking its mutex (CuptiProfiler.cpp:138-139,149-150).
 #include <rocprofiler-sdk/buffer.h>
 #include <rocprofiler-sdk/buffer_tracing.h>
@@ -19,13 +28,16 @@
 #include <rocprofiler-sdk/registration.h>
 #include <rocprofiler-sdk/rocprofiler.h>
 
-
+#include <dirent.h>
 #include <dlfcn.h>
 #include <link.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +48,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "nvrx_ktrace.h"
@@ -61,17 +74,55 @@ int fail(int code, const char *fmt, ...) {
             return fail(NVRX_KTRACE_ERR_SDK, "%s failed: %s", #expr, rocprofiler_get_status_string(s_)); \
     } while (0)
 
+bool env_is(const char *name, const char *value) {
+    const char *v = getenv(name);
+    return v && strcmp(v, value) == 0;
+}
+
+// a dispatch's identity as far as its key goes: the kernel and its launch geometry
+struct Shape {
+    uint64_t kernel_id;
+    uint32_t d[6];  // workgroup x y z, grid (in workgroups) x y z
+    bool operator==(const Shape &o) const { return kernel_id == o.kernel_id && memcmp(d, o.d, sizeof(d)) == 0; }
+};
+struct ShapeHash {
+    size_t operator()(const Shape &s) const {
+        uint64_t h = s.kernel_id * 0x9E3779B97F4A7C15ull;
+        for (uint32_t v : s.d) h = (h ^ v) * 0x100000001B3ull;
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+
+constexpr int32_t KEY_IGNORED = -1;
+constexpr int ROW_NOT_ASKED = -2;
+
 struct State {
     std::mutex mu;
     // kernel_id -> mangled name (code-object callbacks arrive before the first dispatch of the kernel)
     std::unordered_map<uint64_t, std::string> kernel_names;
-    // key string -> dense id; names are never moved once created (nvrx_ktrace_key_name hands out pointers)
+    // code objects that come out of libnvrx_straggler_hip.so, and the kernels in them: the engine's own launches (a
+    // staging flush inside a user's section) are the measuring apparatus, not the job
+    std::unordered_set<uint64_t> own_code_objects, own_kernels;
+    // (kernel, geometry) -> key id (KEY_IGNORED: left out); key string -> key id; names are never moved once created
+    // (nvrx_ktrace_key_name hands out pointers)
+    std::unordered_map<Shape, int32_t, ShapeHash> shape_keys;
     std::unordered_map<std::string, uint32_t> key_ids;
     std::deque<std::string> key_names;
+    std::vector<int32_t> key_row;  // under the current sink (ROW_NOT_ASKED / -1 / row)
+    // sink
+    nvrx_ktrace_sink sink{};
+    bool has_sink = false;
+    // nvrx_ktrace_hold: batches park here instead of going to the sink (report + ring reset of an asynchronous report)
+    bool hold = false;
+    std::vector<int32_t> parked_rows;
+    std::vector<float> parked_vals;
+    uint64_t parked_records = 0;
+    bool tap = false;  // a copy of every duration handed to the sink also goes to the pending queue (nvrx_ktrace_tap)
+    std::vector<int32_t> batch_rows;
+    std::vector<float> batch_vals;
+    // no sink: the bounded queue nvrx_ktrace_drain pops
     std::deque<nvrx_ktrace_record> pending;
     size_t max_pending = 1u << 20;
-    uint64_t dropped = 0;
-    uint64_t received = 0;  // records seen by the callback thread, dropped or not
 
     rocprofiler_context_id_t names_ctx{0};  // code-object callbacks: active for the whole process
     rocprofiler_context_id_t ctx{0};        // kernel-dispatch tracing: active between start and stop
@@ -79,6 +130,19 @@ struct State {
     std::atomic<int> setup_done{0};  // force_configure has been issued
     std::atomic<int> ready{0};       // tool_init ran and the context is valid
     std::atomic<int> running{0};
+    std::atomic<int> counting{0};  // the ENQUEUE callback is configured
+
+    // counters (include/nvrx_ktrace.h, nvrx_ktrace_counter)
+    std::atomic<uint64_t> enqueued{0}, arrived{0}, delivered{0}, lost_no_row{0}, sink_errors{0}, own_skipped{0},
+        keys_without_row{0}, forgiven{0}, pump_flushes{0}, dropped{0}, rows_assigned{0};
+
+    // pump thread
+    std::mutex pump_mu;
+    std::condition_variable pump_cv;
+    bool pump_kick = false;
+    std::atomic<int> pump_idle{1};
+    std::once_flag pump_once;
+    bool pump_enabled = true;
 };
 
 State &st() {
@@ -86,99 +150,237 @@ State &st() {
     return *s;
 }
 
+inline uint64_t outstanding(State &s) {
+    const uint64_t have = s.arrived.load(std::memory_order_acquire) + s.forgiven.load(std::memory_order_acquire);
+    const uint64_t want = s.enqueued.load(std::memory_order_acquire);
+    return want > have ? want - have : 0;
+}
+
 // ---- tool discovery guard ---------------------------------------------------------------------------------------
 // When rocprofiler-sdk initialises (rocprofiler_force_configure, or the HIP runtime handing over its API table) it looks
 // for tools by ELF-parsing EVERY shared library of the process' link map, and its parser reads each file front to back
-// (std::ifstream::read of the whole file; backtrace in tools/archive/debug/readtrace.c / profiles/r04c_ktrace_start_up.txt):
-// 10.7 GB of read() calls in a PyTorch process (libmagma 1.3 GB, MIOpen 0.95, rocsolver 0.76, libtorch_hip 0.42 ...).
-// From a warm page cache that is 3 s; where storage is cold it is minutes -- the "start-up stall" of rounds 1-3.  The
-// tool we want the SDK to find is handed over explicitly (rocprofiler_force_configure), so for the duration of that one
-// call the large libraries are taken out of the search: their link-map names are pointed at "" (what the main program
-// has, which the search skips) and put back right after.  Nothing is unloaded or remapped; only the name the SDK's
-// search would open is hidden.  NVRX_KTRACE_SCAN_GUARD=0 turns it off, NVRX_KTRACE_SCAN_GUARD_MIN_MB (default 4) is the size from
-// which a library is hidden.  A tool library (one exporting rocprofiler_configure) larger than that would not be
-// discovered by the search while hidden; tools named in ROCP_TOOL_LIBRARIES are loaded by name and unaffected.
-struct HiddenName {
-    link_map *lm;
-    char *name;
+// (std::ifstream::read of the whole file; profiles/r04c_ktrace_start_up.txt): 10.7 GB of read() calls in a PyTorch
+// process (libmagma 1.3 GB, MIOpen 0.95, rocsolver 0.76, libtorch_hip 0.42 ...).  From a warm page cache that is 3 s;
+// where storage is cold it is minutes.  The tool we want the SDK to find is handed over explicitly
+// (rocprofiler_force_configure), so for the duration of that one call (~20 ms) the large libraries are taken out of the
+// search: their link-map names are pointed at "" (what the main program has, which the search skips) and put back by a
+// scope guard.  Nothing is unloaded or remapped; only the name the SDK's search would open is hidden.
+//
+// The link map belongs to the dynamic loader, so this is fenced: it is done only while every OTHER thread of the process
+// is asleep (/proc/self/task/<tid>/stat: nobody can be inside dlopen / dl_iterate_phdr / an unwinder) -- the usual
+// situation at import time, where the only other threads are BLAS pool workers parked on a futex.  Otherwise
+// nvrx_ktrace_setup refuses (NVRX_KTRACE_ERR_UNSAFE) and the caller takes the SDK's own route (ROCP_TOOL_LIBRARIES,
+// full search).  NVRX_KTRACE_SCAN_GUARD=0 turns the guard off, =force skips the check;
+// NVRX_KTRACE_SCAN_GUARD_MIN_MB (default 4) is the size from which a library is hidden.  A tool library (one exporting
+// rocprofiler_configure) larger than that would not be discovered by the search while hidden; tools named in
+// ROCP_TOOL_LIBRARIES are loaded by name and unaffected.
+struct HiddenNames {
+    struct Item {
+        link_map *lm;
+        char *name;
+    };
+    std::vector<Item> items;
+    HiddenNames() = default;
+    HiddenNames(const HiddenNames &) = delete;
+    HiddenNames &operator=(const HiddenNames &) = delete;
+    ~HiddenNames() { restore(); }
+    void restore() {
+        for (const Item &h : items) h.lm->l_name = h.name;
+        items.clear();
+    }
+    void hide(size_t min_bytes) {
+        void *self = dlopen(nullptr, RTLD_LAZY | RTLD_NOLOAD);
+        link_map *lm = nullptr;
+        if (!self || dlinfo(self, RTLD_DI_LINKMAP, &lm) != 0 || !lm) return;
+        while (lm->l_prev) lm = lm->l_prev;
+        static char empty[1] = {0};
+        for (; lm; lm = lm->l_next) {
+            if (!lm->l_name || !lm->l_name[0]) continue;
+            if (strstr(lm->l_name, "rocprofiler") || strstr(lm->l_name, "nvrx_ktrace")) continue;
+            struct stat sb;
+            if (stat(lm->l_name, &sb) != 0 || (size_t)sb.st_size < min_bytes) continue;
+            items.push_back(Item{lm, lm->l_name});
+            lm->l_name = empty;
+        }
+    }
 };
 
-std::vector<HiddenName> hide_large_libraries(size_t min_bytes) {
-    std::vector<HiddenName> out;
-    void *self = dlopen(nullptr, RTLD_LAZY | RTLD_NOLOAD);
-    link_map *lm = nullptr;
-    if (!self || dlinfo(self, RTLD_DI_LINKMAP, &lm) != 0 || !lm) return out;
-    while (lm->l_prev) lm = lm->l_prev;
-    static char empty[1] = {0};
-    for (; lm; lm = lm->l_next) {
-        if (!lm->l_name || !lm->l_name[0]) continue;
-        if (strstr(lm->l_name, "rocprofiler") || strstr(lm->l_name, "nvrx_ktrace")) continue;
-        struct stat sb;
-        if (stat(lm->l_name, &sb) != 0 || (size_t)sb.st_size < min_bytes) continue;
-        out.push_back(HiddenName{lm, lm->l_name});
-        lm->l_name = empty;
+// Threads of this process other than the caller that are not asleep right now (-1: /proc could not be read).
+int other_threads_awake() {
+    DIR *dir = opendir("/proc/self/task");
+    if (!dir) return -1;
+    const long self = (long)syscall(SYS_gettid);
+    int awake = 0;
+    while (dirent *e = readdir(dir)) {
+        if (e->d_name[0] < '0' || e->d_name[0] > '9') continue;
+        if (atol(e->d_name) == self) continue;
+        char path[320], buf[512];
+        snprintf(path, sizeof(path), "/proc/self/task/%s/stat", e->d_name);
+        FILE *f = fopen(path, "r");
+        if (!f) continue;  // the thread has gone since
+        const size_t n = fread(buf, 1, sizeof(buf) - 1, f);
+        fclose(f);
+        buf[n] = 0;
+        const char *p = strrchr(buf, ')');  // "pid (comm) S ..." -- comm may hold anything, the state follows the LAST ')'
+        const char state = (p && p[1] == ' ') ? p[2] : '?';
+        if (!(state == 'S' || state == 'D' || state == 'I' || state == 'Z' || state == 'X' || state == 'T' || state == 't')) awake++;
     }
-    return out;
-}
-
-void restore_library_names(const std::vector<HiddenName> &hidden) {
-    for (const HiddenName &h : hidden) h.lm->l_name = h.name;
+    closedir(dir);
+    return awake;
 }
 
 std::atomic<int> g_hidden_last{0};
 
+// ---- names ------------------------------------------------------------------------------------------------------
 void on_code_object(rocprofiler_callback_tracing_record_t record, rocprofiler_user_data_t *, void *) {
-    if (record.kind != ROCPROFILER_CALLBACK_TRACING_CODE_OBJECT ||
-        record.operation != ROCPROFILER_CODE_OBJECT_DEVICE_KERNEL_SYMBOL_REGISTER ||
-        record.phase != ROCPROFILER_CALLBACK_PHASE_LOAD)
+    if (record.kind != ROCPROFILER_CALLBACK_TRACING_CODE_OBJECT || record.phase != ROCPROFILER_CALLBACK_PHASE_LOAD) return;
+    State &s = st();
+    if (record.operation == ROCPROFILER_CODE_OBJECT_LOAD) {
+        auto *data = static_cast<rocprofiler_callback_tracing_code_object_load_data_t *>(record.payload);
+        if (data && data->uri && strstr(data->uri, "libnvrx_straggler_hip")) {
+            std::lock_guard<std::mutex> lk(s.mu);
+            s.own_code_objects.insert(data->code_object_id);
+        }
         return;
+    }
+    if (record.operation != ROCPROFILER_CODE_OBJECT_DEVICE_KERNEL_SYMBOL_REGISTER) return;
     auto *data = static_cast<rocprofiler_callback_tracing_code_object_kernel_symbol_register_data_t *>(record.payload);
     if (!data || !data->kernel_name) return;
     std::string name(data->kernel_name);
     // the code object names a kernel's descriptor symbol: "<mangled name>.kd"
     if (name.size() > 3 && name.compare(name.size() - 3, 3, ".kd") == 0) name.resize(name.size() - 3);
-    State &s = st();
     std::lock_guard<std::mutex> lk(s.mu);
+    if (s.own_code_objects.count(data->code_object_id)) s.own_kernels.insert(data->kernel_id);
     s.kernel_names[data->kernel_id] = std::move(name);
+}
+
+// ---- records ----------------------------------------------------------------------------------------------------
+// Key id of a dispatch (KEY_IGNORED: one of the engine's own kernels).  Called with s.mu held.
+int32_t key_of(State &s, const nvrx_ktrace_dispatch &d) {
+    Shape sh;
+    sh.kernel_id = d.kernel_id;
+    // CUDA's gridDim counts blocks; HSA's grid counts work-items
+    for (int i = 0; i < 3; i++) {
+        const uint32_t b = d.workgroup[i] ? d.workgroup[i] : 1;
+        sh.d[i] = b;
+        sh.d[3 + i] = (d.grid[i] + b - 1) / b;
+    }
+    auto it = s.shape_keys.find(sh);
+    if (it != s.shape_keys.end()) return it->second;
+    int32_t id;
+    if (s.own_kernels.count(d.kernel_id)) {
+        id = KEY_IGNORED;
+    } else {
+        auto nit = s.kernel_names.find(d.kernel_id);
+        const char *name = nit != s.kernel_names.end() ? nit->second.c_str() : "unknown_kernel";
+        char key[4096];  // KERNEL_NAME_BUF_LEN of the reference (CuptiProfiler.cpp:172)
+        snprintf(key, sizeof(key), "%s_blk_%u_%u_%u_grid_%u_%u_%u", name, sh.d[0], sh.d[1], sh.d[2], sh.d[3], sh.d[4], sh.d[5]);
+        auto kit = s.key_ids.find(key);
+        if (kit != s.key_ids.end()) {
+            id = (int32_t)kit->second;
+        } else {
+            id = (int32_t)s.key_names.size();
+            s.key_names.emplace_back(key);
+            s.key_ids.emplace(s.key_names.back(), (uint32_t)id);
+            s.key_row.push_back(ROW_NOT_ASKED);
+        }
+    }
+    s.shape_keys.emplace(sh, id);
+    return id;
+}
+
+// Called with s.mu held.
+void push_batch(State &s, const std::vector<int32_t> &rows, const std::vector<float> &vals) {
+    if (!s.has_sink || rows.empty()) return;
+    const int rc = s.sink.push(s.sink.ctx, rows.data(), vals.data(), (int)rows.size());
+    if (rc < 0)
+        s.sink_errors.fetch_add(1, std::memory_order_relaxed);
+    else
+        s.delivered.fetch_add(rows.size(), std::memory_order_relaxed);
+}
+
+// One batch of dispatch records, in arrival order, into the sink (or the pending queue).  `arrived` moves only after
+// the sink has the batch: nvrx_ktrace_sync() returning 0 means the durations are in the rings' staging.
+void consume(const nvrx_ktrace_dispatch *recs, size_t n) {
+    if (!n) return;
+    State &s = st();
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.batch_rows.clear();
+        s.batch_vals.clear();
+        for (size_t i = 0; i < n; i++) {
+            const nvrx_ktrace_dispatch &d = recs[i];
+            if (d.start_ns == 0 || d.end_ns == 0) continue;  // CuptiProfiler.cpp:182-184
+            const int32_t key = key_of(s, d);
+            if (key == KEY_IGNORED) {
+                s.own_skipped.fetch_add(1, std::memory_order_relaxed);
+                continue;
+            }
+            // nanoseconds -> microseconds exactly as the reference: integer difference, one f32 division
+            const float us = (float)(d.end_ns - d.start_ns) / 1000.0f;
+            if (s.has_sink) {
+                int32_t row = s.key_row[(size_t)key];
+                if (row == ROW_NOT_ASKED) {
+                    row = s.sink.row_alloc(s.sink.ctx, s.sink.kind);
+                    if (row < 0) {
+                        row = -1;
+                        s.keys_without_row.fetch_add(1, std::memory_order_relaxed);
+                    } else {
+                        s.rows_assigned.fetch_add(1, std::memory_order_relaxed);
+                    }
+                    s.key_row[(size_t)key] = row;
+                }
+                if (row < 0) {
+                    s.lost_no_row.fetch_add(1, std::memory_order_relaxed);
+                    continue;
+                }
+                s.batch_rows.push_back(row);
+                s.batch_vals.push_back(us);
+            }
+            if (!s.has_sink || s.tap) {
+                if (s.pending.size() >= s.max_pending) {  // keep the newest (CircularBuffer.h:53-61)
+                    s.pending.pop_front();
+                    s.dropped.fetch_add(1, std::memory_order_relaxed);
+                }
+                s.pending.push_back(nvrx_ktrace_record{(uint32_t)key, us});
+            }
+        }
+        if (s.has_sink && s.hold) {  // (counted as arrived when the hold is lifted and the sink has them)
+            s.parked_rows.insert(s.parked_rows.end(), s.batch_rows.begin(), s.batch_rows.end());
+            s.parked_vals.insert(s.parked_vals.end(), s.batch_vals.begin(), s.batch_vals.end());
+            s.parked_records += n;
+            return;
+        }
+        push_batch(s, s.batch_rows, s.batch_vals);
+    }
+    s.arrived.fetch_add(n, std::memory_order_release);
 }
 
 void on_records(rocprofiler_context_id_t, rocprofiler_buffer_id_t, rocprofiler_record_header_t **headers,
                 size_t num_headers, void *, uint64_t) {
-    State &s = st();
-    char key[4096];  // KERNEL_NAME_BUF_LEN of the reference (CuptiProfiler.cpp:172)
-    std::lock_guard<std::mutex> lk(s.mu);
+    static thread_local std::vector<nvrx_ktrace_dispatch> batch;
+    batch.clear();
     for (size_t i = 0; i < num_headers; i++) {
         rocprofiler_record_header_t *h = headers[i];
         if (h->category != ROCPROFILER_BUFFER_CATEGORY_TRACING || h->kind != ROCPROFILER_BUFFER_TRACING_KERNEL_DISPATCH)
             continue;
         auto *rec = static_cast<rocprofiler_buffer_tracing_kernel_dispatch_record_t *>(h->payload);
-        if (rec->start_timestamp == 0 || rec->end_timestamp == 0) continue;  // CuptiProfiler.cpp:182-184
-        const auto &d = rec->dispatch_info;
-        auto it = s.kernel_names.find(d.kernel_id);
-        const char *name = it != s.kernel_names.end() ? it->second.c_str() : "unknown_kernel";
-        // CUDA's gridDim counts blocks; HSA's grid counts work-items
-        const unsigned bx = d.workgroup_size.x ? d.workgroup_size.x : 1, by = d.workgroup_size.y ? d.workgroup_size.y : 1,
-                       bz = d.workgroup_size.z ? d.workgroup_size.z : 1;
-        snprintf(key, sizeof(key), "%s_blk_%u_%u_%u_grid_%u_%u_%u", name, bx, by, bz, (d.grid_size.x + bx - 1) / bx,
-                 (d.grid_size.y + by - 1) / by, (d.grid_size.z + bz - 1) / bz);
-        uint32_t id;
-        auto kit = s.key_ids.find(key);
-        if (kit != s.key_ids.end()) {
-            id = kit->second;
-        } else {
-            id = (uint32_t)s.key_names.size();
-            s.key_names.emplace_back(key);
-            s.key_ids.emplace(s.key_names.back(), id);
-        }
-        s.received++;
-        if (s.pending.size() >= s.max_pending) {
-            s.dropped++;
-            continue;
-        }
-        // nanoseconds -> microseconds exactly as the reference: integer difference, one f32 division
-        const float us = (float)(rec->end_timestamp - rec->start_timestamp) / 1000.0f;
-        s.pending.push_back(nvrx_ktrace_record{id, us});
+        const auto &di = rec->dispatch_info;
+        nvrx_ktrace_dispatch d;
+        d.kernel_id = di.kernel_id;
+        d.workgroup[0] = di.workgroup_size.x, d.workgroup[1] = di.workgroup_size.y, d.workgroup[2] = di.workgroup_size.z;
+        d.grid[0] = di.grid_size.x, d.grid[1] = di.grid_size.y, d.grid[2] = di.grid_size.z;
+        d.start_ns = rec->start_timestamp, d.end_ns = rec->end_timestamp;
+        batch.push_back(d);
     }
+    consume(batch.data(), batch.size());
+}
+
+// On the launching thread, before the packet is written: the dispatch WILL produce a record (the contexts active now are
+// captured with it, fwd.h ROCPROFILER_KERNEL_DISPATCH_ENQUEUE), so it is counted as expected.
+void on_dispatch_enqueue(rocprofiler_callback_tracing_record_t record, rocprofiler_user_data_t *, void *) {
+    if (record.phase == ROCPROFILER_CALLBACK_PHASE_ENTER && record.operation == ROCPROFILER_KERNEL_DISPATCH_ENQUEUE)
+        st().enqueued.fetch_add(1, std::memory_order_relaxed);
 }
 
 #define KT_DBG(msg)                                                        \
@@ -197,8 +399,8 @@ int tool_init(rocprofiler_client_finalize_t, void *) {
     // whole process (a callback per code object, nothing per launch).  The dispatch-tracing context is the one
     // start / stop switch, so launches outside profiled sections cost nothing.
     if (rocprofiler_create_context(&s.names_ctx) != ROCPROFILER_STATUS_SUCCESS) return -1;
-    rocprofiler_tracing_operation_t ops[] = {ROCPROFILER_CODE_OBJECT_DEVICE_KERNEL_SYMBOL_REGISTER};
-    if (rocprofiler_configure_callback_tracing_service(s.names_ctx, ROCPROFILER_CALLBACK_TRACING_CODE_OBJECT, ops, 1,
+    rocprofiler_tracing_operation_t ops[] = {ROCPROFILER_CODE_OBJECT_LOAD, ROCPROFILER_CODE_OBJECT_DEVICE_KERNEL_SYMBOL_REGISTER};
+    if (rocprofiler_configure_callback_tracing_service(s.names_ctx, ROCPROFILER_CALLBACK_TRACING_CODE_OBJECT, ops, 2,
                                                        on_code_object, nullptr) != ROCPROFILER_STATUS_SUCCESS)
         return -1;
     KT_DBG("tool_init: names context configured");
@@ -210,6 +412,14 @@ int tool_init(rocprofiler_client_finalize_t, void *) {
     if (rocprofiler_configure_buffer_tracing_service(s.ctx, ROCPROFILER_BUFFER_TRACING_KERNEL_DISPATCH, nullptr, 0,
                                                      s.buffer) != ROCPROFILER_STATUS_SUCCESS)
         return -1;
+    if (!env_is("NVRX_KTRACE_COUNT", "0")) {
+        rocprofiler_tracing_operation_t dops[] = {ROCPROFILER_KERNEL_DISPATCH_ENQUEUE};
+        if (rocprofiler_configure_callback_tracing_service(s.ctx, ROCPROFILER_CALLBACK_TRACING_KERNEL_DISPATCH, dops, 1,
+                                                           on_dispatch_enqueue, nullptr) == ROCPROFILER_STATUS_SUCCESS)
+            s.counting.store(1, std::memory_order_release);
+        else
+            KT_DBG("tool_init: the ENQUEUE callback could not be configured; nvrx_ktrace_sync settles by flushing");
+    }
     KT_DBG("tool_init: dispatch service configured");
     rocprofiler_callback_thread_t thr{};
     if (rocprofiler_create_callback_thread(&thr) != ROCPROFILER_STATUS_SUCCESS) return -1;
@@ -219,12 +429,57 @@ int tool_init(rocprofiler_client_finalize_t, void *) {
     if (rocprofiler_context_is_valid(s.ctx, &valid) != ROCPROFILER_STATUS_SUCCESS || !valid) return -1;
     KT_DBG("tool_init: callback thread assigned, starting names context");
     if (rocprofiler_start_context(s.names_ctx) != ROCPROFILER_STATUS_SUCCESS) return -1;
+    s.pump_enabled = !env_is("NVRX_KTRACE_PUMP", "0");
     s.ready.store(1, std::memory_order_release);
     KT_DBG("tool_init: done");
     return 0;
 }
 
 void tool_fini(void *) { st().ready.store(0, std::memory_order_release); }
+
+// One flush of the SDK's buffer; BUSY (somebody else is flushing) is not an error.
+int flush_once(State &s) {
+    rocprofiler_status_t rs = rocprofiler_flush_buffer(s.buffer);
+    if (rs != ROCPROFILER_STATUS_SUCCESS && rs != ROCPROFILER_STATUS_ERROR_BUFFER_BUSY)
+        return fail(NVRX_KTRACE_ERR_SDK, "rocprofiler_flush_buffer failed: %s", rocprofiler_get_status_string(rs));
+    return NVRX_KTRACE_OK;
+}
+
+// After a window closes: flush the SDK's buffer until every dispatch enqueued so far has arrived -- as the kernels
+// finish -- so the durations are in the rings long before anybody asks for a report.  Backs off from 100 us to 2 ms
+// and gives up after 5 s (a window whose kernels run longer is completed by the next kick or by nvrx_ktrace_sync).
+void pump_main() {
+    State &s = st();
+    std::unique_lock<std::mutex> lk(s.pump_mu);
+    for (;;) {
+        s.pump_idle.store(1, std::memory_order_release);
+        s.pump_cv.wait(lk, [&] { return s.pump_kick; });
+        s.pump_kick = false;
+        s.pump_idle.store(0, std::memory_order_release);
+        lk.unlock();
+        int pause_us = 100;
+        const auto give_up = std::chrono::steady_clock::now() + std::chrono::seconds(5);
+        while (s.ready.load(std::memory_order_acquire) && outstanding(s) && std::chrono::steady_clock::now() < give_up) {
+            flush_once(s);
+            s.pump_flushes.fetch_add(1, std::memory_order_relaxed);
+            if (!outstanding(s)) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(pause_us));
+            pause_us = std::min(pause_us * 2, 2000);
+        }
+        lk.lock();
+    }
+}
+
+void kick_pump(State &s) {
+    if (!s.pump_enabled || !s.counting.load(std::memory_order_acquire)) return;
+    std::call_once(s.pump_once, [] { std::thread(pump_main).detach(); });
+    if (!s.pump_idle.load(std::memory_order_acquire)) return;  // already flushing: it re-reads the counters every round
+    {
+        std::lock_guard<std::mutex> lk(s.pump_mu);
+        s.pump_kick = true;
+    }
+    s.pump_cv.notify_one();
+}
 
 }  // namespace
 
@@ -242,12 +497,20 @@ extern "C" {
 
 const char *nvrx_ktrace_last_error(void) { return g_err.c_str(); }
 
+int nvrx_ktrace_set_max_pending(int max_pending) {
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    s.max_pending = max_pending > 0 ? (size_t)max_pending : (size_t)1 << 20;
+    while (s.pending.size() > s.max_pending) {
+        s.pending.pop_front();
+        s.dropped.fetch_add(1, std::memory_order_relaxed);
+    }
+    return NVRX_KTRACE_OK;
+}
+
 int nvrx_ktrace_setup(int max_pending) {
     State &s = st();
-    {
-        std::lock_guard<std::mutex> lk(s.mu);
-        s.max_pending = max_pending > 0 ? (size_t)max_pending : (size_t)1 << 20;
-    }
+    nvrx_ktrace_set_max_pending(max_pending);
     if (s.setup_done.load(std::memory_order_acquire)) return NVRX_KTRACE_OK;  // already registered (or via ROCP_TOOL_LIBRARIES)
     int status = 0;
     KT_DBG("setup: enter");
@@ -257,17 +520,27 @@ int nvrx_ktrace_setup(int max_pending) {
                     "rocprofiler-sdk is already configured (the HIP runtime initialised before nvrx_ktrace_setup): import "
                     "nvrx_straggler with NVRX_GPU_TIMING=kernels before the first HIP call, or name libnvrx_ktrace.so in "
                     "ROCP_TOOL_LIBRARIES");
-    KT_DBG("setup: calling rocprofiler_force_configure");
-    std::vector<HiddenName> hidden;
-    const char *guard = getenv("NVRX_KTRACE_SCAN_GUARD");
-    if (!guard || strcmp(guard, "0") != 0) {
-        const char *mb = getenv("NVRX_KTRACE_SCAN_GUARD_MIN_MB");
-        const long min_mb = mb && atol(mb) > 0 ? atol(mb) : 4;
-        hidden = hide_large_libraries((size_t)min_mb << 20);
+    rocprofiler_status_t rs;
+    {
+        HiddenNames hidden;  // (put back by its destructor, whatever happens below)
+        const char *guard = getenv("NVRX_KTRACE_SCAN_GUARD");
+        if (!guard || strcmp(guard, "0") != 0) {
+            if (!guard || strcmp(guard, "force") != 0) {
+                const int awake = other_threads_awake();
+                if (awake != 0)
+                    return fail(NVRX_KTRACE_ERR_UNSAFE,
+                                "%d other thread(s) of this process are running: the tool-search guard only touches the link map "
+                                "while they are all asleep (NVRX_KTRACE_SCAN_GUARD=force overrides, =0 registers without the guard)",
+                                awake);
+            }
+            const char *mb = getenv("NVRX_KTRACE_SCAN_GUARD_MIN_MB");
+            const long min_mb = mb && atol(mb) > 0 ? atol(mb) : 4;
+            hidden.hide((size_t)min_mb << 20);
+        }
+        g_hidden_last.store((int)hidden.items.size());
+        KT_DBG("setup: calling rocprofiler_force_configure");
+        rs = rocprofiler_force_configure(&rocprofiler_configure);
     }
-    g_hidden_last.store((int)hidden.size());
-    rocprofiler_status_t rs = rocprofiler_force_configure(&rocprofiler_configure);
-    restore_library_names(hidden);
     KT_DBG("setup: rocprofiler_force_configure returned");
     if (rs != ROCPROFILER_STATUS_SUCCESS)
         return fail(rs == ROCPROFILER_STATUS_ERROR_CONFIGURATION_LOCKED ? NVRX_KTRACE_ERR_STATE : NVRX_KTRACE_ERR_SDK,
@@ -278,6 +551,50 @@ int nvrx_ktrace_setup(int max_pending) {
 int nvrx_ktrace_hidden_libraries(void) { return g_hidden_last.load(); }
 
 int nvrx_ktrace_ready(void) { return st().ready.load(std::memory_order_acquire); }
+
+int nvrx_ktrace_set_sink(const nvrx_ktrace_sink *sink) {
+    if (sink && (!sink->push || !sink->row_alloc)) return fail(NVRX_KTRACE_ERR_INVALID, "a sink needs push and row_alloc");
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);  // (a batch in progress on the SDK's thread finishes first)
+    s.has_sink = sink != nullptr;
+    s.sink = sink ? *sink : nvrx_ktrace_sink{};
+    std::fill(s.key_row.begin(), s.key_row.end(), ROW_NOT_ASKED);
+    if (s.parked_records) {  // rows of the old sink: nowhere to go
+        s.arrived.fetch_add(s.parked_records, std::memory_order_release);
+        s.parked_records = 0;
+        s.parked_rows.clear();
+        s.parked_vals.clear();
+    }
+    s.hold = false;
+    s.rows_assigned.store(0, std::memory_order_relaxed);
+    s.keys_without_row.store(0, std::memory_order_relaxed);
+    return NVRX_KTRACE_OK;
+}
+
+int nvrx_ktrace_hold(int on) {
+    State &s = st();
+    uint64_t released = 0;
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.hold = on != 0;
+        if (!s.hold && s.parked_records) {
+            push_batch(s, s.parked_rows, s.parked_vals);
+            s.parked_rows.clear();
+            s.parked_vals.clear();
+            released = s.parked_records;
+            s.parked_records = 0;
+        }
+    }
+    if (released) s.arrived.fetch_add(released, std::memory_order_release);
+    return NVRX_KTRACE_OK;
+}
+
+int nvrx_ktrace_tap(int on) {
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    s.tap = on != 0;
+    return NVRX_KTRACE_OK;
+}
 
 int nvrx_ktrace_start(void) {
     State &s = st();
@@ -296,6 +613,7 @@ int nvrx_ktrace_stop(void) {
     int active = 0;
     SDK_TRY(rocprofiler_context_is_active(s.ctx, &active));
     if (active) SDK_TRY(rocprofiler_stop_context(s.ctx));
+    if (outstanding(s)) kick_pump(s);
     return NVRX_KTRACE_OK;
 }
 
@@ -309,16 +627,49 @@ int nvrx_ktrace_flush(void) {
         rocprofiler_status_t rs = rocprofiler_flush_buffer(s.buffer);
         if (rs != ROCPROFILER_STATUS_SUCCESS && rs != ROCPROFILER_STATUS_ERROR_BUFFER_BUSY)
             return fail(NVRX_KTRACE_ERR_SDK, "rocprofiler_flush_buffer failed: %s", rocprofiler_get_status_string(rs));
-        uint64_t now;
-        {
-            std::lock_guard<std::mutex> lk(s.mu);
-            now = s.received;
-        }
+        const uint64_t now = s.arrived.load(std::memory_order_acquire);
         if (rs == ROCPROFILER_STATUS_SUCCESS && now == last) break;
         last = now;
         std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
     return NVRX_KTRACE_OK;
+}
+
+int nvrx_ktrace_sync(double timeout_s) {
+    State &s = st();
+    const bool ready = s.ready.load(std::memory_order_acquire) != 0;  // (not ready: only nvrx_ktrace_feed brings records)
+    if (!outstanding(s) && (s.counting.load(std::memory_order_acquire) || !ready)) return 0;  // (the usual case: the pump was there first)
+    if (ready && !s.counting.load(std::memory_order_acquire)) return nvrx_ktrace_flush();
+    // dispatches enqueued after this point are not waited for: `want` is fixed now
+    const uint64_t want = s.enqueued.load(std::memory_order_acquire);
+    auto missing = [&]() -> uint64_t {
+        const uint64_t have = s.arrived.load(std::memory_order_acquire) + s.forgiven.load(std::memory_order_acquire);
+        return want > have ? want - have : 0;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    int round = 0;
+    for (;;) {
+        if (ready) {
+            int rc = flush_once(s);
+            if (rc < 0) return rc;
+        }
+        uint64_t m = missing();
+        if (!m) return 0;
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited >= timeout_s) return (int)std::min<uint64_t>(m, 0x7FFFFFFF);
+        // the kernels are still running (or their completion handlers are): short pauses first, then 100 us
+        if (++round < 50)
+            std::this_thread::sleep_for(std::chrono::microseconds(10));
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
+
+int nvrx_ktrace_forgive(void) {
+    State &s = st();
+    const uint64_t out = outstanding(s);
+    if (out) s.forgiven.fetch_add(out, std::memory_order_acq_rel);
+    return (int)std::min<uint64_t>(out, 0x7FFFFFFF);
 }
 
 int nvrx_ktrace_drain(nvrx_ktrace_record *out, int cap) {
@@ -339,10 +690,24 @@ int nvrx_ktrace_pending(void) {
     return (int)s.pending.size();
 }
 
-uint64_t nvrx_ktrace_dropped(void) {
+uint64_t nvrx_ktrace_dropped(void) { return st().dropped.load(std::memory_order_relaxed); }
+
+uint64_t nvrx_ktrace_counter(int what) {
     State &s = st();
-    std::lock_guard<std::mutex> lk(s.mu);
-    return s.dropped;
+    switch (what) {
+        case 0: return s.enqueued.load();
+        case 1: return s.arrived.load();
+        case 2: return s.delivered.load();
+        case 3: return s.lost_no_row.load();
+        case 4: return s.sink_errors.load();
+        case 5: return s.own_skipped.load();
+        case 6: return s.keys_without_row.load();
+        case 7: return s.forgiven.load();
+        case 8: return s.pump_flushes.load();
+        case 9: return (uint64_t)s.counting.load();
+        case 10: return s.rows_assigned.load();
+        default: return 0;
+    }
 }
 
 int nvrx_ktrace_num_keys(void) {
@@ -357,14 +722,37 @@ const char *nvrx_ktrace_key_name(uint32_t key) {
     return key < s.key_names.size() ? s.key_names[key].c_str() : nullptr;
 }
 
+int nvrx_ktrace_key_row(uint32_t key) {
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    return key < s.key_row.size() ? s.key_row[key] : ROW_NOT_ASKED;
+}
+
 int nvrx_ktrace_reset(void) {
     State &s = st();
     if (s.ready.load(std::memory_order_acquire)) {
-        int rc = nvrx_ktrace_flush();
+        int rc = s.counting.load(std::memory_order_acquire) ? nvrx_ktrace_sync(0.05) : nvrx_ktrace_flush();
         if (rc < 0) return rc;
     }
     std::lock_guard<std::mutex> lk(s.mu);
     s.pending.clear();
+    return NVRX_KTRACE_OK;
+}
+
+int nvrx_ktrace_feed_kernel_name(uint64_t kernel_id, const char *name, int own) {
+    if (!name) return fail(NVRX_KTRACE_ERR_INVALID, "name is null");
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    s.kernel_names[kernel_id] = name;
+    if (own) s.own_kernels.insert(kernel_id);
+    return NVRX_KTRACE_OK;
+}
+
+int nvrx_ktrace_feed(const nvrx_ktrace_dispatch *recs, int n, int counted) {
+    if (n < 0 || (n > 0 && !recs && !counted)) return fail(NVRX_KTRACE_ERR_INVALID, "bad records");
+    State &s = st();
+    if (counted) s.enqueued.fetch_add((uint64_t)n, std::memory_order_relaxed);
+    if (recs) consume(recs, (size_t)n);
     return NVRX_KTRACE_OK;
 }
 

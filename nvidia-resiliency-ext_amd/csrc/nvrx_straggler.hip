@@ -1962,6 +1962,7 @@ struct nvrx_ctx {
     float *d_hist_min = nullptr;
 
     std::vector<uint64_t> total;  // samples ever pushed per row since the last reset
+    int rows_used = 0;            // rows of a logical rank handed out so far (nvrx_row_alloc)
     uint8_t *h_kinds = nullptr;   // pinned
     int32_t *h_gid = nullptr;     // pinned
     bool meta_dirty = true;
@@ -2549,6 +2550,10 @@ int nvrx_ctx_info(const nvrx_ctx *ctx, int what) {
         case 5: return (int)ctx->reports_rehomed;   // reports that were enqueued on the stream they had to follow (diagnostics)
         case 6: return ctx->last_rehome_verdict;    // why the last report was / was not re-homed: see nvrx_report
         case 7: return (int)ctx->regions_skipped;   // GPU-timed regions that got no sample because their stream was being captured
+        case 8: {                                   // rows of a logical rank handed out so far (nvrx_row_alloc)
+            std::lock_guard<std::mutex> lk(const_cast<nvrx_ctx *>(ctx)->mu);
+            return ctx->rows_used;
+        }
         default: return fail(NVRX_ERR_INVALID, "unknown info selector %d", what);
     }
 }
@@ -2564,6 +2569,24 @@ int nvrx_row_configure(nvrx_ctx *ctx, int row, int kind, int gid) {
         ctx->meta_dirty = true;
     }
     return NVRX_OK;
+}
+
+int nvrx_row_alloc(nvrx_ctx *ctx, int kind) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (kind != NVRX_KIND_SECTION && kind != NVRX_KIND_KERNEL) return fail(NVRX_ERR_INVALID, "bad kind %d", kind);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->rows_used >= ctx->rows_per_rank)
+        return fail(NVRX_ERR_RANGE, "straggler rings are full: %d timing rows per rank", ctx->rows_per_rank);
+    const int row = ctx->rows_used++;
+    for (int lr = 0; lr < ctx->local_ranks; lr++) {
+        const size_t g = (size_t)lr * ctx->rows_per_rank + row;
+        if (ctx->h_kinds[g] != (uint8_t)kind || ctx->h_gid[g] != -1) {
+            ctx->h_kinds[g] = (uint8_t)kind;
+            ctx->h_gid[g] = -1;
+            ctx->meta_dirty = true;
+        }
+    }
+    return row;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2585,6 +2608,26 @@ int nvrx_ring_push_many(nvrx_ctx *ctx, int row, const float *values, int n) {
     if (rc) return rc;
     for (int i = 0; i < n; i++) {
         rc = push_locked(ctx, row, values[i]);
+        if (rc) return rc;
+    }
+    return NVRX_OK;
+}
+
+// The per-kernel tracer's path into the rings (nvrx_ktrace_sink.push): n (row, value) pairs appended one by one under
+// ONE lock, staged in pinned memory like nvrx_ring_push -- nothing is launched unless a staging buffer fills up (one
+// scatter per min(4096, ring_cap) samples, on the context's stream), and what is still staged when a report comes is
+// flushed by the report.  Called on the tracer's thread, so the device is selected first.
+int nvrx_ring_push_staged(nvrx_ctx *ctx, const int32_t *rows, const float *values, int n) {
+    if (!ctx || (n > 0 && (!rows || !values)) || n < 0) return fail(NVRX_ERR_INVALID, "bad arguments");
+    if (n == 0) return NVRX_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int rc = ctx_set_device(ctx);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+        const int32_t r = rows[i];
+        if (r < 0) continue;
+        if (r >= ctx->rows) return fail(NVRX_ERR_RANGE, "row %d out of range (%d rows)", (int)r, ctx->rows);
+        rc = push_locked(ctx, r, values[i]);
         if (rc) return rc;
     }
     return NVRX_OK;

@@ -24,6 +24,7 @@ KIND_SECTION, KIND_KERNEL = 0, 1
 MAX_RING_CAP = 65536
 META_WORDS = 8
 ERR_TIMEOUT = -62
+ERR_RANGE = -34
 
 
 
@@ -54,10 +55,12 @@ SYMBOLS = [
     ("nvrx_ctx_destroy", c_int, [c_void_p]),
     ("nvrx_ctx_set_stream", c_int, [c_void_p, c_void_p]),
     ("nvrx_ctx_info", c_int, [c_void_p, c_int]),
+    ("nvrx_row_alloc", c_int, [c_void_p, c_int]),
     ("nvrx_row_configure", c_int, [c_void_p, c_int, c_int, c_int]),
     ("nvrx_ring_push", c_int, [c_void_p, c_int, c_float]),
     ("nvrx_ring_push_many", c_int, [c_void_p, c_int, c_void_p, c_int]),
     ("nvrx_ring_push_pairs", c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    ("nvrx_ring_push_staged", c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     ("nvrx_ring_push_device", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     ("nvrx_ring_push_device_rows", c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     ("nvrx_ring_set_count", c_int, [c_void_p, c_int, c_int]),

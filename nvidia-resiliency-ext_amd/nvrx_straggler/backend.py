@@ -438,7 +438,6 @@ class HipRings:
         _native.check(self.lib.nvrx_ctx_create(backend.device.index, local_ranks, rows_per_rank, ring_cap, ctypes.byref(ctx)))
         self.ctx = ctx
         _native.check(self.lib.nvrx_ctx_set_stream(ctx, backend.stream_handle))
-        self.rows_used = 0
         self._counts_buf = np.zeros(64, dtype=np.int32)
         #: every name that ever got a ring row (rows are never recycled; a reset only empties them)
         self.section_row_names = {}
@@ -457,24 +456,38 @@ class HipRings:
             pass
 
     # ---- rows ----------------------------------------------------------------------------------
-    def alloc_row(self) -> int:
-        if self.rows_used >= self.rows_per_rank:
-            raise RuntimeError(
-                f"straggler rings are full: {self.rows_per_rank} timing rows per rank "
-                "(raise max_rows in Detector.initialize)"
-            )
-        self.rows_used += 1
-        return self.rows_used - 1
+    @property
+    def rows_used(self) -> int:
+        """Rows handed out so far.  The count lives in the library (``nvrx_row_alloc``): the per-kernel tracer's thread
+        takes rows for new kernel keys on its own (``ktrace_sink``)."""
+        return self.lib.nvrx_ctx_info(self.ctx, 8)
+
+    def alloc_row(self, kind: int = _native.KIND_SECTION) -> int:
+        row = self.lib.nvrx_row_alloc(self.ctx, kind)
+        if row < 0:
+            if row == _native.ERR_RANGE:
+                raise RuntimeError(
+                    f"straggler rings are full: {self.rows_per_rank} timing rows per rank "
+                    "(raise max_rows in Detector.initialize)"
+                )
+            _native.check(row)
+        return row
 
     def row_for(self, kind: int, name: str) -> int:
         """Ring row of a section (kind 0) / GPU-timed region (kind 1), allocated on first use."""
         table = self.kernel_row_names if kind == _native.KIND_KERNEL else self.section_row_names
         row = table.get(name)
         if row is None:
-            row = self.alloc_row()
+            row = self.alloc_row(kind)
             table[name] = row
-            self.configure(row, kind, -1)
         return row
+
+    def ktrace_sink(self):
+        """``(ctx, push, row_alloc)`` as plain addresses: what ``nvrx_ktrace_set_sink`` needs to append kernel durations to
+        these rings from the tracer's thread (include/nvrx_ktrace.h)."""
+        cast = ctypes.cast
+        return (self.ctx.value, cast(self.lib.nvrx_ring_push_staged, ctypes.c_void_p).value,
+                cast(self.lib.nvrx_row_alloc, ctypes.c_void_p).value)
 
     def configure(self, row: int, kind: int, gid: int, lr: Optional[int] = None) -> None:
         lrs = range(self.local_ranks) if lr is None else (lr,)

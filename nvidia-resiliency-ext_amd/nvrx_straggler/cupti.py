@@ -45,9 +45,10 @@ class CuptiManager:
         from . import ktrace as _ktrace
 
         self.per_kernel = _ktrace.timing_mode() == "kernels"
-        profiler_cls = profiler_module.KernelTraceProfiler if self.per_kernel else profiler_module.CuptiProfiler
-        self.cupti_ext = profiler_cls(bufferSize=bufferSize, numBuffers=numBuffers, statsMaxLenPerKernel=statsMaxLenPerKernel,
-                                      **({} if rings is None else {"rings": rings}))
+        profiler_cls = profiler_module.KernelTraceProfiler if self.per_kernel else profiler_module.RegionProfiler
+        self._ext_args = dict(bufferSize=bufferSize, numBuffers=numBuffers, statsMaxLenPerKernel=statsMaxLenPerKernel,
+                              **({} if rings is None else {"rings": rings}))
+        self.cupti_ext = profiler_cls(**self._ext_args)
         self.lock = threading.Lock()
         self.is_initialized = False
         self.started_cnt = 0  # nesting depth of start_profiling(): only the outermost pair opens / closes a region
@@ -88,6 +89,30 @@ class CuptiManager:
             self.cupti_ext.stop()
             return False
         return bool(self.cupti_ext.stop(cpu_row, cpu_value))
+
+    @_serialised()
+    def switch_to_regions(self) -> bool:
+        """Per-kernel tracing -> one GPU-time row per profiled region (the job's ranks did not all get per-kernel tracing:
+        ``Detector`` agrees on the common mode at the first collective report).  The kernel rows recorded so far stay
+        where they are and simply stop growing.  False when a region is open right now (try again at the next report)."""
+        if not self.per_kernel:
+            return True
+        if self.started_cnt:
+            return False
+        import nvrx_cupti_module as profiler_module
+
+        old = self.cupti_ext
+        old.shutdown()
+        shared = "rings" in self._ext_args
+        if shared:
+            old._owns_rings = False
+        old.close()  # (takes the tracer's sink off the rings)
+        if not shared:
+            self._ext_args.pop("rings", None)
+        self.cupti_ext = profiler_module.RegionProfiler(**self._ext_args)
+        self.cupti_ext.initialize()
+        self.per_kernel = False
+        return True
 
     @_serialised()
     def harvest(self, wait: bool = True) -> int:

@@ -1,31 +1,36 @@
 """Per-kernel GPU timing with real kernel names: the CUPTI-activity equivalent on MI355X.
 
-``NVRX_GPU_TIMING=kernels`` selects this profiler instead of the per-region device timestamps of
-``hip_profiler``.  It keeps the interface of the reference's native module (``CuptiProfiler`` with
-``initialize / shutdown / start / stop / get_stats / reset``, cupti_src/cupti_module_py.cpp:33-55) and its
-data model: while a profiled section is open every kernel the process launches is recorded under the key
-``<mangled name>_blk_x_y_z_grid_x_y_z`` with its duration in microseconds (CuptiProfiler.cpp:186-191), so
-the rank's GPU score is the kernel-weighted mean of reporting.py:219-253 over real kernels, and RCCL's
-``ncclDev*`` kernels are left out exactly as in the reference (reporting.py:330-336).
+``NVRX_GPU_TIMING=kernels`` (the default of a multi-rank job) selects this profiler instead of the per-region device
+timestamps of ``hip_profiler``.  It keeps the interface of the reference's native module (``CuptiProfiler`` with
+``initialize / shutdown / start / stop / get_stats / reset``, cupti_src/cupti_module_py.cpp:33-55) and its data
+model: while a profiled section is open every kernel the process launches is recorded under the key
+``<mangled name>_blk_x_y_z_grid_x_y_z`` with its duration in microseconds (CuptiProfiler.cpp:186-191), so the
+rank's GPU score is the kernel-weighted mean of reporting.py:219-253 over real kernels, and RCCL's ``ncclDev*``
+kernels are left out exactly as in the reference (reporting.py:330-336).
 
-Underneath, ``libnvrx_ktrace.so`` (include/nvrx_ktrace.h) is a rocprofiler-sdk tool: dispatch records are
-collected on the SDK's thread, ``harvest()`` drains them and appends each kernel's durations to its DEVICE
-ring row, and the statistics (mean-of-middles median, population stddev; CuptiProfiler.cpp:44-74) are
-computed by the same HIP kernel as every other row.
+The data path is native end to end (``libnvrx_ktrace.so``, include/nvrx_ktrace.h): the rocprofiler-sdk callback
+thread turns each batch of dispatch records into (ring row, microseconds) pairs and appends them to the DEVICE rings
+through a sink of two function pointers into ``libnvrx_straggler_hip.so`` -- per key an overwrite-oldest ring, the
+newest ``ring_cap`` durations survive, as in the reference (CuptiProfiler.cpp:168-207, CircularBuffer.h:53-61).
+Python sees no record.  At report time the training thread calls ``harvest()``: ONE C call (``nvrx_ktrace_sync``:
+every kernel enqueued in a section so far has finished and is in the rings -- the role of
+``torch.cuda.synchronize()`` in straggler.py:234 without waiting for the rest of the device), plus, when kernel keys
+nobody has seen before turned up, their names (cold).  The statistics (mean-of-middles median, population stddev;
+CuptiProfiler.cpp:44-74) are computed by the same HIP kernel as every other row.
 
 The SDK only accepts tools before the HIP runtime initialises.  Importing ``nvrx_straggler`` registers the tool
-right away (``setup``: ``rocprofiler_force_configure`` with the SDK's tool search kept off the large libraries) when
-the mode is ``kernels`` -- named by ``NVRX_GPU_TIMING=kernels``, or chosen for the processes of a multi-rank job
-(``timing_mode``); if HIP was initialised earlier the profiler raises with the advice to import the package first.
+right away (``setup``) when the mode is ``kernels``; if HIP was initialised earlier the profiler raises with the
+advice to import the package first.  ``NVRX_KTRACE_AT_IMPORT=0`` defers the decision to ``Detector.initialize``.
 """
 from __future__ import annotations
 
 import ctypes
+import logging
 import os
 import threading
 import warnings
 import weakref
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_uint32, c_uint64
+from ctypes import CFUNCTYPE, POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_uint32, c_uint64, c_void_p
 from typing import Dict, Optional
 
 import numpy as np
@@ -34,10 +39,12 @@ from . import _native
 from . import backend as _backend_mod
 from .hip_profiler import KernelStats
 
+_log = logging.getLogger(__name__)
 _LIB_NAME = "libnvrx_ktrace.so"
 # NVRX_LIB_DIR: load the native libraries from another directory (the sanitizer build of `make -C csrc asan` lives in
 # lib_asan/; tools/run_sanitized.sh points here)
 _LIB_PATH = os.path.join(os.environ.get("NVRX_LIB_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib"), _LIB_NAME)
+ERR_UNSAFE = -16
 
 
 class Record(Structure):
@@ -45,28 +52,57 @@ class Record(Structure):
 
 
 RECORD_DTYPE = np.dtype([("key", np.uint32), ("us", np.float32)])
-_ROW_UNKNOWN = -2  # key id without an entry in the key -> row table yet (-1: the rings had no row left for it)
+
+
+class Sink(Structure):
+    """``nvrx_ktrace_sink``: where the tracer's thread appends the durations."""
+
+    _fields_ = [("ctx", c_void_p), ("push", c_void_p), ("row_alloc", c_void_p), ("kind", c_int32)]
+
+
+class Dispatch(Structure):
+    """``nvrx_ktrace_dispatch``: one kernel execution as the feed entry takes it."""
+
+    _fields_ = [("kernel_id", c_uint64), ("workgroup", c_uint32 * 3), ("grid", c_uint32 * 3), ("start_ns", c_uint64), ("end_ns", c_uint64)]
+
+
+DISPATCH_DTYPE = np.dtype([("kernel_id", np.uint64), ("workgroup", np.uint32, (3,)), ("grid", np.uint32, (3,)),
+                           ("start_ns", np.uint64), ("end_ns", np.uint64)])
+assert DISPATCH_DTYPE.itemsize == ctypes.sizeof(Dispatch) == 48
 
 # every symbol include/nvrx_ktrace.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("nvrx_ktrace_setup", c_int, [c_int]),
+    ("nvrx_ktrace_set_max_pending", c_int, [c_int]),
     ("nvrx_ktrace_hidden_libraries", c_int, []),
     ("nvrx_ktrace_ready", c_int, []),
+    ("nvrx_ktrace_set_sink", c_int, [POINTER(Sink)]),
+    ("nvrx_ktrace_hold", c_int, [c_int]),
+    ("nvrx_ktrace_tap", c_int, [c_int]),
     ("nvrx_ktrace_start", c_int, []),
     ("nvrx_ktrace_stop", c_int, []),
+    ("nvrx_ktrace_sync", c_int, [c_double]),
+    ("nvrx_ktrace_forgive", c_int, []),
     ("nvrx_ktrace_flush", c_int, []),
     ("nvrx_ktrace_drain", c_int, [POINTER(Record), c_int]),
     ("nvrx_ktrace_pending", c_int, []),
     ("nvrx_ktrace_dropped", c_uint64, []),
+    ("nvrx_ktrace_counter", c_uint64, [c_int]),
     ("nvrx_ktrace_num_keys", c_int, []),
     ("nvrx_ktrace_key_name", c_char_p, [c_uint32]),
+    ("nvrx_ktrace_key_row", c_int, [c_uint32]),
     ("nvrx_ktrace_reset", c_int, []),
     ("nvrx_ktrace_last_error", c_char_p, []),
+    ("nvrx_ktrace_feed_kernel_name", c_int, [c_uint64, c_char_p, c_int]),
+    ("nvrx_ktrace_feed", c_int, [c_void_p, c_int, c_int]),
 ]
+COUNTERS = ("enqueued", "arrived", "delivered", "lost_no_row", "sink_errors", "own_skipped", "keys_without_row", "forgiven",
+            "pump_flushes", "counting", "rows_assigned")
 
 _lib = None
 _lock = threading.Lock()
 _setup_error: Optional[str] = None
+_setup_route: str = ""  # how the tool was handed to the SDK ("force_configure" | "ROCP_TOOL_LIBRARIES")
 
 
 def lib_path() -> str:
@@ -98,35 +134,53 @@ def _check(rc: int) -> int:
     return rc
 
 
+def counters() -> Dict[str, int]:
+    """The tracer's process-wide counters (include/nvrx_ktrace.h, ``nvrx_ktrace_counter``)."""
+    lib = load()
+    return {name: int(lib.nvrx_ktrace_counter(i)) for i, name in enumerate(COUNTERS)}
+
+
+def _name_in_tool_libraries() -> None:
+    libs = [p for p in os.environ.get("ROCP_TOOL_LIBRARIES", "").split(":") if p]
+    if _LIB_PATH not in libs:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_NAME} not found at {_LIB_PATH}; build it with `make -C nvidia-resiliency-ext_amd/csrc`")
+        os.environ["ROCP_TOOL_LIBRARIES"] = ":".join(libs + [_LIB_PATH])
+
+
 def setup(max_pending: int = 0) -> None:
     """Register the tool with rocprofiler-sdk.  Call before the first HIP call of the process.
 
     Default: ``rocprofiler_force_configure`` right now, with the SDK's tool search kept away from the large libraries of
     the process (``nvrx_ktrace.cpp``, "tool discovery guard").  What rounds 1-3 knew as the SDK's start-up stall is that
     search: the SDK ELF-parses EVERY loaded shared library for a ``rocprofiler_configure`` symbol and its parser reads
-    each file front to back -- 10.7 GB of ``read()`` calls in a PyTorch process, 3 s from a warm page cache, 70 s in the
-    build container, 130-165 s on a GPU box with cold storage (``tools/archive/debug/readtrace.c`` has the backtrace:
-    ``rocprofiler_set_api_table -> ... -> std::istream::read``).  Handing our tool over explicitly while the big libraries
-    are hidden from that one search costs 0.1 GB of reads and 0.05 s (``profiles/r04c_ktrace_start_up.txt``).
+    each file front to back -- 10.7 GB of ``read()`` calls in a PyTorch process, 3 s from a warm page cache, 130-165 s on a
+    GPU box with cold storage.  Handing our tool over explicitly while the big libraries are hidden from that one search
+    costs 0.1 GB of reads and 0.05 s (``profiles/r04c_ktrace_start_up.txt``).  The guard touches loader state, so the
+    library only applies it while every other thread of the process is asleep (the situation at import time: BLAS pool
+    workers parked on a futex); when it refuses (``NVRX_KTRACE_ERR_UNSAFE``) the SDK's own route is taken instead.
 
-    ``NVRX_KTRACE_FORCE=0`` takes the SDK's own route instead -- the library named in ``ROCP_TOOL_LIBRARIES``, loaded
+    ``NVRX_KTRACE_FORCE=0`` takes the SDK's own route outright -- the library named in ``ROCP_TOOL_LIBRARIES``, loaded
     when the HIP runtime registers with the SDK (what ``rocprofv3`` does for its tool) -- and pays the full search."""
-    global _setup_error
-    if os.environ.get("NVRX_KTRACE_FORCE", "1") != "0":
-        try:
-            _check(load().nvrx_ktrace_setup(int(max_pending)))
-            _setup_error = None
-        except RuntimeError as e:
-            _setup_error = str(e)
-            raise
-        return
-    libs = [p for p in os.environ.get("ROCP_TOOL_LIBRARIES", "").split(":") if p]
-    if _LIB_PATH not in libs:
-        if not os.path.exists(_LIB_PATH):
-            _setup_error = f"{_LIB_NAME} not found at {_LIB_PATH}; build it with `make -C nvidia-resiliency-ext_amd/csrc`"
-            raise RuntimeError(_setup_error)
-        os.environ["ROCP_TOOL_LIBRARIES"] = ":".join(libs + [_LIB_PATH])
-    _setup_error = None
+    global _setup_error, _setup_route
+    try:
+        if os.environ.get("NVRX_KTRACE_FORCE", "1") != "0":
+            rc = load().nvrx_ktrace_setup(int(max_pending))
+            if rc != ERR_UNSAFE:
+                _check(rc)
+                _setup_error, _setup_route = None, "force_configure"
+                return
+            msg = load().nvrx_ktrace_last_error()
+            if _hip_is_up():  # (naming the library for the HIP runtime's start-up is pointless once it has started)
+                raise RuntimeError("per-kernel tracing has to be registered before the HIP runtime starts: import nvrx_straggler "
+                                   "(in a multi-rank job, or with NVRX_GPU_TIMING=kernels) before the first HIP call")
+            _log.info("nvrx straggler: %s -- registering through ROCP_TOOL_LIBRARIES instead (the SDK searches every loaded "
+                      "library for tools when HIP starts: seconds to minutes)", msg.decode() if msg else "tool-search guard refused")
+        _name_in_tool_libraries()
+        _setup_error, _setup_route = None, "ROCP_TOOL_LIBRARIES"
+    except RuntimeError as e:
+        _setup_error = str(e)
+        raise
 
 
 _mode: Optional[str] = None
@@ -163,11 +217,19 @@ def _job_size() -> tuple:
     return 1, ""
 
 
+def _foreign_tool() -> str:
+    """Another rocprofiler-sdk tool that is in charge of this process (``rocprofv3 -- python ...`` names its tool library in
+    ROCP_TOOL_LIBRARIES and preloads the SDK), or ''.  Two tools can coexist in the SDK, but a profiling run is the user's
+    measurement: the tracer stays out of it unless asked for by name."""
+    libs = [p for p in os.environ.get("ROCP_TOOL_LIBRARIES", "").split(":") if p and os.path.basename(p) != _LIB_NAME]
+    return libs[0] if libs else ""
+
+
 def timing_mode() -> str:
     """How ``profile_cuda=True`` sections measure GPU time in this process: ``stamp`` | ``event`` | ``kernels``.
 
     ``NVRX_GPU_TIMING`` names it outright.  Unset (or ``auto``) it is decided ONCE, the first time anybody asks -- at
-    ``import nvrx_straggler``:
+    ``import nvrx_straggler`` (``NVRX_KTRACE_AT_IMPORT=0``: at ``Detector.initialize``):
 
     * a process of a multi-rank job (``WORLD_SIZE`` > 1 in the environment, what ``torchrun`` and every launcher that
       follows its convention exports; without it srun's, mpirun's or a PMI launcher's job size) gets ``kernels`` -- the reference's data model (CuptiProfiler.cpp:168-207): the GPU
@@ -175,10 +237,12 @@ def timing_mode() -> str:
       time, are left out (reporting.py:330-336).  One row per REGION cannot do that: a step that ends in a collective
       lasts as long as the slowest rank's on every rank and a slow GPU scores 1.0 (tests/test_host_logic.py,
       ``test_region_timing_flattens_gpu_scores...``; tests/test_gpu_multiproc.py runs it on real kernels);
-    * a single-process job, or a process whose HIP runtime is already up (rocprofiler-sdk accepts tools only before
-      that), gets ``stamp``.
+    * a single-process job, a process whose HIP runtime is already up (rocprofiler-sdk accepts tools only before
+      that), or one that runs under another rocprofiler-sdk tool (``rocprofv3``), gets ``stamp``.
 
-    Registration is cheap now (``setup``); if it fails the mode falls back to ``stamp`` and ``mode_note()`` says why."""
+    If the registration fails the mode falls back to ``stamp`` and ``mode_note()`` says why.  The ranks of a job agree on
+    ONE mode at their first collective report (``Detector``: a rank that could not trace kernels pulls everybody to
+    ``stamp``, with a warning -- mixed modes share no kernel names and every relative GPU score would be NaN)."""
     global _mode, _mode_note
     if _mode is not None:
         return _mode
@@ -187,11 +251,12 @@ def timing_mode() -> str:
             return _mode
         want = os.environ.get("NVRX_GPU_TIMING", "").strip().lower() or "auto"
         if want in ("stamp", "event"):
-            _mode = want
+            _mode, _mode_note = want, f"NVRX_GPU_TIMING={want}"
         elif want == "kernels":
-            _mode = "kernels"  # asked for by name: errors of the registration surface when the profiler is built
+            _mode, _mode_note = "kernels", "NVRX_GPU_TIMING=kernels"  # asked for by name: errors of the registration surface when the profiler is built
         else:
             world, said_by = _job_size()
+            foreign = _foreign_tool()
             if world <= 1:
                 _mode, _mode_note = "stamp", "single-process job"
             elif not os.path.exists("/dev/kfd"):
@@ -199,6 +264,8 @@ def timing_mode() -> str:
             elif _hip_is_up():
                 _mode, _mode_note = "stamp", ("multi-rank job, but the HIP runtime was initialised before nvrx_straggler was "
                                               "imported: rocprofiler-sdk accepts tools only before that")
+            elif foreign:
+                _mode, _mode_note = "stamp", f"multi-rank job under another rocprofiler-sdk tool (ROCP_TOOL_LIBRARIES={foreign})"
             else:
                 _mode, _mode_note = "kernels", f"multi-rank job ({said_by}={world})"
     if _mode == "kernels":
@@ -216,6 +283,18 @@ def mode_note() -> str:
     return _mode_note
 
 
+def mode_code() -> int:
+    """What the ranks MIN-reduce to agree on a mode: 1 = per-kernel keys, 0 = one row per region (stamp / event)."""
+    return 1 if timing_mode() == "kernels" else 0
+
+
+def fall_back_to_regions(why: str) -> None:
+    """The job's common mode is per-region timing (some rank cannot trace kernels): this process follows."""
+    global _mode, _mode_note
+    with _lock:
+        _mode, _mode_note = "stamp", why
+
+
 def _reset_mode_for_tests() -> None:
     global _mode, _mode_note
     _mode, _mode_note = None, ""
@@ -223,12 +302,16 @@ def _reset_mode_for_tests() -> None:
 
 def setup_from_env() -> None:
     """Import-time hook: settle the timing mode, which registers the tracer when the mode is ``kernels`` (it has to
-    happen before anything touches HIP; errors of an explicitly requested mode surface at first use)."""
-    timing_mode()
+    happen before anything touches HIP; errors of an explicitly requested mode surface at first use).
+    ``NVRX_KTRACE_AT_IMPORT=0`` leaves it to ``Detector.initialize`` -- nothing of the SDK is touched by the import then
+    (and the mode becomes ``stamp`` if HIP is up by that time)."""
+    if os.environ.get("NVRX_KTRACE_AT_IMPORT", "1") != "0":
+        timing_mode()
 
 
 def drain_all() -> np.ndarray:
-    """Flush, then pop every pending record: structured array with fields ``key`` (u32) and ``us`` (f32)."""
+    """Without a sink (no live profiler): flush, then pop every pending record -- structured array with fields ``key``
+    (u32) and ``us`` (f32).  Diagnostics / C-ABI hosts that keep their own rings; the package itself never drains."""
     lib = load()
     _check(lib.nvrx_ktrace_flush())
     chunks = []
@@ -249,6 +332,24 @@ def key_name(key: int) -> str:
     return name.decode() if name else f"unknown_key_{key}"
 
 
+def feed(dispatches: np.ndarray, counted: bool = True) -> None:
+    """Hand ``DISPATCH_DTYPE`` records to the tracer's data path on the calling thread (``nvrx_ktrace_feed``): what the SDK's
+    callback thread does with a batch of dispatch records.  Tests and the benchmark's feeder thread."""
+    a = np.ascontiguousarray(dispatches, dtype=DISPATCH_DTYPE)
+    _check(load().nvrx_ktrace_feed(a.ctypes.data, int(a.size), int(counted)))
+
+
+def feed_kernel_name(kernel_id: int, name: str, own: bool = False) -> None:
+    _check(load().nvrx_ktrace_feed_kernel_name(int(kernel_id), name.encode(), int(own)))
+
+
+def _sync_patience_s() -> float:
+    try:
+        return float(os.environ.get("NVRX_KTRACE_SYNC_PATIENCE_S", "2.0"))
+    except ValueError:
+        return 2.0
+
+
 class KernelTraceProfiler:
     """rocprofiler-sdk stand-in for the CUPTI profiler object; one live instance per process."""
 
@@ -262,7 +363,7 @@ class KernelTraceProfiler:
         self._lib = load()
         if _setup_error is not None and not self._lib.nvrx_ktrace_ready():
             raise RuntimeError(_setup_error)
-        if not self._lib.nvrx_ktrace_ready():
+        if not self._lib.nvrx_ktrace_ready() and timing_mode() == "kernels":
             setup()  # no-op when the import hook already ran; too late if HIP is already up (checked in initialize)
         self._owns_rings = rings is None
         if rings is None:
@@ -271,9 +372,14 @@ class KernelTraceProfiler:
         self._initialized = False
         self._started = False
         self._closed = False
-        self._key_rows: Dict[int, int] = {}  # tracer key id -> ring row (-1: no row left)
-        self._row_table = np.full(1024, _ROW_UNKNOWN, dtype=np.int32)  # the same as an array indexed by key id
+        self._rows_known = 0  # keys of the tracer whose ring row (and name) this object has learnt
+        self._key_learnt = bytearray()  # ... which ones, by key id
         self.keys_without_row = 0
+        self._warned_leak = False
+        # from now on the tracer's thread appends every kernel duration to these rings
+        ctx, push, row_alloc = rings.ktrace_sink()
+        self._sink = Sink(ctx, push, row_alloc, _native.KIND_KERNEL)
+        _check(self._lib.nvrx_ktrace_set_sink(ctypes.byref(self._sink)))
         KernelTraceProfiler._live = weakref.ref(self)
 
     # ---- lifecycle -----------------------------------------------------------------------------
@@ -301,6 +407,8 @@ class KernelTraceProfiler:
     def close(self) -> None:
         if not self._closed:
             self._closed = True
+            # the tracer's thread lets go of the rings before they are destroyed (returns once a batch in progress is through)
+            self._lib.nvrx_ktrace_set_sink(None)
             if self._owns_rings:
                 self._rings.close()
 
@@ -328,45 +436,64 @@ class KernelTraceProfiler:
 
     # ---- results -----------------------------------------------------------------------------------
     def harvest(self, wait: bool = True) -> int:
-        """Move the recorded kernel durations into their device ring rows.  ``wait``: let the device finish
-        first, as the reference does before it reads its statistics (straggler.py:234)."""
-        if wait:
-            import torch
+        """Report time.  ``wait``: every kernel enqueued inside a section so far has finished and its duration is in the
+        rings when this returns (straggler.py:234 synchronises the whole device for that); ``wait=False`` (asynchronous
+        reports) only looks: what has not arrived yet counts in the next window.  One C call; names of kernel keys seen
+        for the first time are fetched on top (cold).  Returns the number of dispatches still missing."""
+        lib = self._lib
+        missing = lib.nvrx_ktrace_sync(_sync_patience_s() if wait else 0.0)
+        if missing < 0:
+            _check(missing)
+        if missing > 0 and wait:
+            missing = self._wait_the_long_way(missing)
+        if lib.nvrx_ktrace_counter(10) != self._rows_known or lib.nvrx_ktrace_counter(6) != self.keys_without_row:
+            self._learn_keys()
+        return missing
 
-            torch.cuda.synchronize()
-        return self.ingest(drain_all())
+    def _wait_the_long_way(self, missing: int) -> int:
+        """The kernels of the window are still running after ``NVRX_KTRACE_SYNC_PATIENCE_S`` (a long step, a collective
+        waiting for a straggler) -- or a dispatch was counted and its record never came.  Wait for the device as the
+        reference does, look again, and if records are STILL missing stop expecting them."""
+        import torch
 
-    def ingest(self, recs: np.ndarray) -> int:
-        """Append drained ``(key, us)`` records (``RECORD_DTYPE``, arrival order) to the device rings: every key id is
-        looked up in a key -> ring-row table (rows are handed out the first time a key shows up: cold) and ALL records
-        go to the device with one ``nvrx_ring_push_pairs`` call = one scatter launch, whether they belong to two
-        kernel keys or to four thousand (data_shared test sizes of the reference: tests/straggler/unit/test_data_shared.py:62-66)."""
-        if recs.size == 0:
-            return 0
-        keys = recs["key"]
-        table = self._row_table
-        top = int(keys.max())
-        if top >= table.size:
-            grown = np.full(max(top + 1, 2 * table.size), _ROW_UNKNOWN, dtype=np.int32)
-            grown[: table.size] = table
-            table = self._row_table = grown
-        rows = table[keys]
-        if (rows == _ROW_UNKNOWN).any():
-            rings = self._rings
-            for k in np.unique(keys[rows == _ROW_UNKNOWN]).tolist():
-                try:
-                    row = rings.row_for(_native.KIND_KERNEL, key_name(k))
-                except RuntimeError:
-                    row = -1
-                    self.keys_without_row += 1
-                    if self.keys_without_row == 1:
-                        warnings.warn("straggler rings are full: further kernel names are not recorded "
-                                      "(raise max_rows in Detector.initialize)")
-                table[k] = row
-                self._key_rows[k] = row
-            rows = table[keys]
-        self._rings.push_pairs(rows, recs["us"])
-        return int(recs.size)
+        torch.cuda.synchronize()
+        lib = self._lib
+        missing = lib.nvrx_ktrace_sync(0.2)
+        if missing > 0:
+            _check(lib.nvrx_ktrace_flush())
+            missing = lib.nvrx_ktrace_sync(0.0)
+        if missing > 0:
+            lib.nvrx_ktrace_forgive()
+            if not self._warned_leak:
+                self._warned_leak = True
+                _log.warning("nvrx straggler: %d traced kernel dispatch(es) never produced a record; not waiting for them", missing)
+        return 0 if missing < 0 else missing
+
+    def _learn_keys(self) -> None:
+        """Kernel keys the tracer's thread has met since the last look: their names and ring rows (cold path)."""
+        lib, rings = self._lib, self._rings
+        n = lib.nvrx_ktrace_num_keys()
+        learnt = self._key_learnt
+        if len(learnt) < n:
+            learnt.extend(bytes(n - len(learnt)))
+        for k in range(n):
+            if not learnt[k]:
+                row = lib.nvrx_ktrace_key_row(k)  # (-2: no record of this key has come under this sink yet; -1: no row was left)
+                if row >= 0:
+                    rings.kernel_row_names[key_name(k)] = row
+                    learnt[k] = 1
+                    self._rows_known += 1
+        lost = int(lib.nvrx_ktrace_counter(6))
+        if lost > self.keys_without_row:
+            if self.keys_without_row == 0:
+                warnings.warn("straggler rings are full: further kernel names are not recorded "
+                              "(raise max_rows in Detector.initialize)")
+            self.keys_without_row = lost
+
+    def hold(self, on: bool) -> None:
+        """Bracket of an asynchronous report's "statistics launch + ring reset": durations that arrive meanwhile wait on the
+        tracer's thread and land in the next window (``nvrx_ktrace_hold``)."""
+        self._lib.nvrx_ktrace_hold(int(on))
 
     def active_rows(self) -> Dict[str, int]:
         r = self._rings
@@ -394,4 +521,5 @@ class KernelTraceProfiler:
 
     @property
     def dropped(self) -> int:
-        return int(self._lib.nvrx_ktrace_dropped())
+        """Durations that did not make it into a ring: their key found no row left (rings full)."""
+        return int(self._lib.nvrx_ktrace_counter(3)) + int(self._lib.nvrx_ktrace_dropped())

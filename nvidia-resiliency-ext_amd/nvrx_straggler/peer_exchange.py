@@ -162,9 +162,15 @@ def create(group=None, device_index: Optional[int] = None, timeout_s: float = 18
 
 
 def exchange_mode() -> str:
-    """``NVRX_EXCHANGE``: ``rccl`` (default) | ``peer`` | ``auto``."""
+    """``NVRX_EXCHANGE``: ``rccl`` (default) | ``peer`` | ``auto`` | ``c10d``.
+
+    ``c10d`` is the conservative choice: no communicator of our own, the report's all-gather is a plain
+    ``torch.distributed.all_gather_into_tensor`` on the JOB's process group, i.e. on the communicator and in the launch order
+    of the job's own collectives (c10d serialises a group's collectives on its one RCCL stream).  It costs a c10d dispatch
+    and two event hops per report; what it buys is that nothing of ours can be launched out of order against the job's
+    collectives ("two communicators")."""
     mode = os.environ.get("NVRX_EXCHANGE", "") or "rccl"
-    return mode if mode in ("rccl", "peer", "auto") else "rccl"
+    return mode if mode in ("rccl", "peer", "auto", "c10d") else "rccl"
 
 
 def trial_timeout_s() -> float:

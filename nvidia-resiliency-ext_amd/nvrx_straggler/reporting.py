@@ -894,6 +894,15 @@ class ReportGenerator:
             return
         from . import peer_exchange, rccl_direct
 
+        mode = peer_exchange.exchange_mode()
+        # NVRX_EXCHANGE=c10d on ANY rank keeps every rank on torch.distributed (the decision has to be the same everywhere:
+        # building a communicator is collective)
+        if not dist_utils.is_all_true(mode != "c10d", self.group):
+            self._direct = None
+            self.exchange_info = {"route": "torch.distributed all-gather on the job's own process group (NVRX_EXCHANGE=c10d)"}
+            if self.rank == 0:
+                _LOG.info("straggler report exchange route: %s", self.exchange_info["route"])
+            return
         index = getattr(be.device, "index", None)
         # the exchange kernel gives up a little BEFORE the host's wait for the completion word does: a peer that is
         # later than the report timeout then surfaces as the exchange's own error (NaN rows, error word, the next
@@ -901,7 +910,6 @@ class ReportGenerator:
         peer_wait_s = 0.9 * _backend_mod.report_timeout_s() or 1e9
         rccl = rccl_direct.create(self.group, index)
         peer = None
-        mode = peer_exchange.exchange_mode()
         if mode != "rccl" and (rccl is not None or mode == "peer"):
             # windows need a group that can reach every rank's GPU: built next to the RCCL route (a gloo group whose
             # ranks share one GPU qualifies too when asked for explicitly: that is how the tests run it)

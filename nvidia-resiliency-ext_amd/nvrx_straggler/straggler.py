@@ -22,6 +22,7 @@ from __future__ import annotations
 import dataclasses
 import functools
 import inspect
+import logging
 import os
 import socket
 import sys
@@ -39,6 +40,7 @@ from .reporting import ReportGenerator
 from .statistics import Statistic  # noqa: F401  (re-exported for callers that poke summaries)
 
 GPU_KEY_PREFIX = "hipevent::"  # kernel-summary key of a section's GPU-time row
+_log = logging.getLogger(__name__)
 
 
 @dataclasses.dataclass(frozen=True)
@@ -171,6 +173,8 @@ class Detector(metaclass=_DeviceSideOnDemand):
     _occupied_key: Optional[bytes] = None
     _active_sections: Dict[str, int] = {}
     _active_kernels: Dict[str, int] = {}
+    # the GPU-timing mode has been compared across the ranks of this process group (a token of the group, or None)
+    _mode_agreed: Any = None
 
     def __new__(cls):
         raise RuntimeError(f"class {cls.__name__} should not be instantiated")
@@ -216,6 +220,9 @@ class Detector(metaclass=_DeviceSideOnDemand):
             max_rows = 4096  # one row per distinct kernel key; 4096 x 8192 f32 = 128 MB of 288 GB
         cls._rings = cls._cupti_manager = None
         cls._device_side_args = (int(max_rows), capacity)
+        cls._mode_agreed = None
+        _log.info("nvrx straggler: GPU time of profile_cuda sections is measured per %s (mode '%s': %s)",
+                  "kernel, by kernel name" if per_kernel else "profiled region", _ktrace.timing_mode(), _ktrace.mode_note())
 
         # host side: who scores, and when
         if asynchronous is None:
@@ -239,6 +246,38 @@ class Detector(metaclass=_DeviceSideOnDemand):
             rings.close()
             raise
         cls._rings, cls._cupti_manager = rings, manager
+
+    @classmethod
+    def _agree_timing_mode(cls, group) -> None:
+        """Once per process group, at the first collective report: the ranks compare how they measure GPU time (one MIN
+        all-reduce of a mode code).  Per-kernel keys and per-region keys share no names, so a job in which ONE rank fell
+        back to region timing (HIP was up before the import, the tracer could not register, ...) would get NaN for every
+        relative GPU score without a word: instead every rank drops to the common mode and says so."""
+        import torch
+        import torch.distributed as dist
+
+        from . import dist_utils
+
+        mine = _ktrace.mode_code()
+        t = torch.tensor([mine, -mine], dtype=torch.int32, device=dist_utils.get_device_for_backend(group))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)  # (min, -max) in one collective
+        common, highest = int(t[0].item()), -int(t[1].item())
+        if common == highest:
+            _log.info("nvrx straggler: every rank measures GPU time in mode '%s'", _ktrace.timing_mode())
+            return
+        if common == mine:
+            _log.info("nvrx straggler: other ranks of this job trace kernels by name, this one times GPU work per profiled region "
+                      "(%s): they fall back to region timing as well", _ktrace.mode_note())
+            return
+        why = ("another rank of this job cannot trace kernels (its HIP runtime was up before nvrx_straggler was imported, or "
+               "the tracer could not register): all ranks time GPU work per profiled region")
+        if cls.cupti_manager.switch_to_regions():
+            _ktrace.fall_back_to_regions(why)
+            _log.warning("nvrx straggler: %s. GPU scores of THIS report window mix kernel keys and region keys and may be NaN; "
+                         "later windows are consistent. Collectives inside profile_cuda sections now count into the region's "
+                         "time: keep them outside, or fix the slow-starting rank (NVRX_GPU_TIMING=kernels makes it an error).", why)
+        else:
+            cls._mode_agreed = None  # a region is open on this rank: compare again at the next report
 
     @classmethod
     def shutdown(cls):
@@ -312,9 +351,34 @@ class Detector(metaclass=_DeviceSideOnDemand):
         """Score everything recorded since the last report, then empty the rings.  Collective."""
         assert cls.initialized
         rings = cls.rings
-        # the recorded GPU regions must have finished; nothing else on the device is waited for
-        # (per-kernel tracing: the device is synchronised and the traced durations move into their rows)
-        cls.cupti_manager.harvest(wait=True)
+        reporter = cls.reporter
+        manager = cls.cupti_manager
+        if reporter.world_size > 1 or cls._mode_agreed is None:
+            from . import dist_utils
+
+            world, _ = dist_utils.world_and_rank(reporter.group, reporter._wr_cache)
+            token = (world, id(reporter.group)) if world > 1 else "single"
+            if token != cls._mode_agreed:
+                cls._mode_agreed = token
+                if world > 1:
+                    cls._agree_timing_mode(reporter.group)
+        # the recorded GPU regions must have finished; nothing else on the device is waited for.  Per-kernel tracing:
+        # every kernel enqueued inside a section so far has finished and its duration is in its ring (one C call; the
+        # tracer's thread has been appending them all along) -- an ASYNCHRONOUS report does not wait even for that:
+        # durations that arrive later count in the next window
+        if manager.per_kernel and reporter.asynchronous:
+            # ... and what arrives from here to the ring reset below stays with the tracer's thread until then
+            manager.cupti_ext.hold(True)
+            try:
+                manager.harvest(wait=False)
+                return cls._report_and_reset(rings, reporter)
+            finally:
+                manager.cupti_ext.hold(False)
+        manager.harvest(wait=True)
+        return cls._report_and_reset(rings, reporter)
+
+    @classmethod
+    def _report_and_reset(cls, rings, reporter):
         # which rows hold samples this window (one C call); the name tables are rebuilt only when
         # that set changes, so a steady-state report does no per-section Python work
         occupied = (rings.counts() > 0).tobytes()
@@ -323,7 +387,6 @@ class Detector(metaclass=_DeviceSideOnDemand):
             cls._active_sections = {n: sec.row for n, sec in cls.custom_sections.items() if counts[sec.row] > 0}
             cls._active_kernels = {k: row for k, row in rings.kernel_row_names.items() if counts[row] > 0}
             cls._occupied_key = occupied
-        reporter = cls.reporter
         order_after = _backend_mod.get_backend().current_stream_handle() if reporter.world_size > 1 else None
         report = reporter.generate_report_from_rings(rings, cls._active_sections, cls._active_kernels,
                                                      order_after=order_after)

@@ -172,18 +172,43 @@ class OracleRings:
     def close(self):
         self.closed = True
 
-    def alloc_row(self):
+    def alloc_row(self, kind=0):
         if self.rows_used >= self.rows_per_rank:
             raise RuntimeError("straggler rings are full")
         self.rows_used += 1
+        self.configure(self.rows_used - 1, kind, -1)
         return self.rows_used - 1
 
     def row_for(self, kind, name):
         table = self.kernel_row_names if kind == 1 else self.section_row_names
         if name not in table:
-            table[name] = self.alloc_row()
-            self.configure(table[name], kind, -1)
+            table[name] = self.alloc_row(kind)
         return table[name]
+
+    def ktrace_sink(self):
+        """The checker's counterpart of HipRings.ktrace_sink: (ctx, push, row_alloc) as addresses -- two ctypes callbacks
+        into these NumPy rings, so the per-kernel tracer's C data path (libnvrx_ktrace.so) can be driven on a box without
+        a GPU.  push / row_alloc have the signatures of nvrx_ring_push_staged / nvrx_row_alloc."""
+        import ctypes
+
+        if getattr(self, "_sink_cbs", None) is None:
+            def push(_ctx, rows, values, n):
+                for i in range(n):
+                    if rows[i] >= 0:
+                        self.push(rows[i], float(values[i]))
+                return 0
+
+            def row_alloc(_ctx, kind):
+                try:
+                    return self.alloc_row(kind)
+                except RuntimeError:
+                    return -34
+
+            PUSH = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_float), ctypes.c_int)
+            ALLOC = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int)
+            self._sink_cbs = (PUSH(push), ALLOC(row_alloc))
+        cast = ctypes.cast
+        return (None, cast(self._sink_cbs[0], ctypes.c_void_p).value, cast(self._sink_cbs[1], ctypes.c_void_p).value)
 
     def configure(self, row, kind, gid, lr=None):
         for q in (range(self.local_ranks) if lr is None else (lr,)):

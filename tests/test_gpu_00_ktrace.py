@@ -48,24 +48,26 @@ y = torch.randn(1 << 20, device="cuda")
 Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n0")
 lib = ktrace.load()
 out["ready"] = int(lib.nvrx_ktrace_ready())
-out["pending_before"] = int(lib.nvrx_ktrace_pending())
+_ = Detector.rings                          # the device side exists: the tracer's thread appends to these rings from now on
+lib.nvrx_ktrace_tap(1)                      # test-only: a copy of every duration the rings are given
+c0 = ktrace.counters()
+out["pending_before"] = int(lib.nvrx_ktrace_pending())   # the warm-up matmul ran outside a section: nothing was recorded
 REPS = 24
 for i in range(REPS):
     with Detector.detection_section("step", profile_cuda=True):
         z = x @ x
         w = torch.relu(y) + 1.0
     torch.sigmoid(y)                        # between sections: not traced
-torch.cuda.synchronize()
-# raw durations straight from the tracer (test-only peek): drain, check, and hand them back to the profiler
+report = Detector.generate_report()         # waits for the sections' kernels (nvrx_ktrace_sync), not for the device
+c1 = ktrace.counters()
+out["counters"] = {k: c1[k] - c0[k] for k in ("enqueued", "arrived", "delivered", "lost_no_row", "sink_errors")}
+# the durations the tracer's thread handed to the rings (the tap), per key
 recs = ktrace.drain_all()
+lib.nvrx_ktrace_tap(0)
 names = {int(k): ktrace.key_name(int(k)) for k in np.unique(recs["key"])}
 out["names"] = sorted(names.values())
 per_key = {names[int(k)]: recs["us"][recs["key"] == k] for k in np.unique(recs["key"])}
 prof = Detector.cupti_manager.cupti_ext
-rings = Detector.rings
-for name, vals in per_key.items():
-    rings.push_many(rings.row_for(1, name), vals)
-report = Detector.generate_report()
 checks = []
 for name, vals in per_key.items():
     exp = oracle.kernel_stats(np.asarray(vals, dtype=np.float32))   # computeStats restated (f32)
@@ -111,7 +113,9 @@ def test_kernels_are_traced_by_name_and_scored():
     assert out["register_read_gb"] < 1.0 and out["first_hip_call_read_gb"] < 1.0, out
     assert out["hidden_libraries"] > 0
     assert out["ready"] == 1
-    assert out["pending_before"] == 0  # the warm-up matmul ran outside a section
+    assert out["pending_before"] == 0
+    c = out["counters"]
+    assert c["enqueued"] == c["arrived"] == c["delivered"] >= 3 * 24 and c["lost_no_row"] == c["sink_errors"] == 0, c
     names = out["names"]
     # reference key format (CuptiProfiler.cpp:186-189): <name>_blk_x_y_z_grid_x_y_z
     import re

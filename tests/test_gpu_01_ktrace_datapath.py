@@ -1,0 +1,236 @@
+"""GPU tests of the per-kernel tracer's native data path (VERDICT r4 "next" item 1).
+
+1. The scenario of tests/test_ktrace_datapath.py -- > 3 x cap launches per key, small batches, a second thread -- fed into
+   the DEVICE rings (``nvrx_ring_push_staged`` / ``nvrx_row_alloc`` behind the sink, ``k_scatter`` + ``k_row_stats`` on the
+   GPU) and compared with the reference's own ``CuptiProfiler`` (oracle/_ref) on the same launches.
+2. REAL kernels in a fresh interpreter (the tool must register before HIP starts): ring capacity 16, 60 launches per key
+   in 60 section entries; a tap hands the test the very durations the tracer's thread gave the rings; the reference
+   profiler fed with those durations (``statsMaxLenPerKernel`` = 16) must report the same statistics -- the NEWEST 16
+   survive (CircularBuffer.h:53-61).  The training thread's part of a report is ``nvrx_ktrace_sync``: timed.
+3. ``asynchronous=True`` in per-kernel mode: a report does not wait for the kernels of its window; what is still running
+   is counted in the next window, nothing is lost, nothing is counted twice.
+"""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_fed_launches_reach_the_device_rings_and_match_the_reference_profiler():
+    from nvrx_straggler import ktrace
+
+    import test_ktrace_datapath as cpu_twin
+
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    cap, K = 32, 40
+    rng = np.random.default_rng(5)
+    names = [f"_Z{7 + k}dev_kern{k:03d}Pfi" for k in range(K)]
+    ids = cpu_twin._fresh_kernel_ids(K)
+    for i, n in zip(ids.tolist(), names):
+        ktrace.feed_kernel_name(i, n)
+    idx, dur, start, blocks = cpu_twin._launches(rng, names, 3 * cap + 5)
+    disp = cpu_twin._as_dispatches(ids, idx, dur, start, blocks)
+    ktrace.KernelTraceProfiler._live = None
+    prof = ktrace.KernelTraceProfiler(statsMaxLenPerKernel=cap, max_keys=K + 8)   # private device rings
+    try:
+        before = ktrace.counters()
+
+        def feeder():
+            for lo in range(0, disp.size, 11):          # small batches: several staging flushes (stage_cap = cap = 32)
+                ktrace.feed(disp[lo:lo + 11])
+
+        t = threading.Thread(target=feeder)
+        t.start()
+        t.join()
+        assert prof.harvest(wait=True) == 0
+        after = ktrace.counters()
+        assert after["delivered"] - before["delivered"] == disp.size and after["sink_errors"] == before["sink_errors"]
+        got = prof.get_stats()
+        exp = cpu_twin._reference_stats(names, idx, dur, start, blocks, cap)
+        assert set(got) == set(exp) and len(got) == K
+        for key, (e, n) in exp.items():
+            g = got[key]
+            assert g.num_calls == n == cap, key
+            assert (np.float32(g.min), np.float32(g.max), np.float32(g.median)) == (e[0], e[1], e[2]), key
+            assert abs(g.avg - e[3]) <= 2e-4 * abs(e[3]) and abs(g.stddev - e[4]) <= 2e-3 * abs(e[4]), key   # reference sums in f32
+        rings = prof._rings
+        for k in range(0, K, 7):
+            mine = ((dur[idx == k]).astype(np.float32) / np.float32(1000.0))[-cap:]
+            row = rings.kernel_row_names[next(n for n in got if n.startswith(names[k] + "_blk_"))]
+            assert sorted(rings.read_row(row)[:cap].tolist()) == sorted(mine.tolist()), k
+    finally:
+        prof.close()
+        ktrace.KernelTraceProfiler._live = None
+
+
+REAL_SCRIPT = r'''
+import faulthandler, json, os, sys, time
+faulthandler.enable()
+faulthandler.dump_traceback_later(170, exit=True)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+os.environ["NVRX_GPU_TIMING"] = "kernels"
+import numpy as np
+import torch
+import nvrx_straggler                      # registers the tracer: no HIP call has happened yet
+from nvrx_straggler import Detector, Statistic, ktrace
+from nvrx_straggler.straggler import CustomSection
+from oracle import oracle
+
+CAP, REPS = 16, 60
+CustomSection.max_elapseds_len = CAP        # ring capacity of every row (straggler.py:80), read by Detector.initialize
+torch.cuda.set_device(0)
+x = torch.randn(512, 512, device="cuda")
+y = torch.randn(1 << 18, device="cuda")
+(x @ x).sum().item(); torch.relu(y); torch.sigmoid(y)      # warm-up outside sections
+Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n0")
+lib = ktrace.load()
+lib.nvrx_ktrace_set_max_pending(1 << 16)
+_ = Detector.rings                          # device side (and the sink) exist before the tap opens
+lib.nvrx_ktrace_tap(1)
+c0 = ktrace.counters()
+for i in range(REPS):
+    with Detector.detection_section("step", profile_cuda=True):
+        z = x @ x
+        w = torch.relu(y)
+        v = torch.sigmoid(y)
+t0 = time.perf_counter_ns()
+missing = Detector.cupti_manager.harvest(wait=True)          # what generate_report() does first: waits for the window's kernels
+t_wait = (time.perf_counter_ns() - t0) / 1e3
+t0 = time.perf_counter_ns()
+again = Detector.cupti_manager.harvest(wait=True)            # everything has arrived: the training thread's steady-state cost
+t_idle = (time.perf_counter_ns() - t0) / 1e3
+c1 = ktrace.counters()
+recs = ktrace.drain_all()                   # the tap: every duration the tracer's thread handed to the rings, in order
+lib.nvrx_ktrace_tap(0)
+report = Detector.generate_report()
+hist = {}
+for k in np.unique(recs["key"]):
+    hist[ktrace.key_name(int(k))] = recs["us"][recs["key"] == k]
+checks = []
+R = oracle.ref_lib()
+assert R is not None and R.ref_profiler_create(1 << 20, 8, CAP) == 0
+R.ref_profiler_initialize(); R.ref_profiler_start()
+t = 1000
+for k, u in zip(recs["key"].tolist(), recs["us"].tolist()):   # the reference's own profiler, fed with the same durations in the same order
+    name = ktrace.key_name(k)
+    base, dims = name.rsplit("_blk_", 1)
+    b, g = dims.split("_grid_")
+    bx, by, bz = (int(v) for v in b.split("_")); gx, gy, gz = (int(v) for v in g.split("_"))
+    ns = int(round(float(np.float32(u)) * 1000.0))
+    R.ref_profiler_launch(base.encode(), bx, by, bz, gx, gy, gz, t, t + ns)
+    t += ns + 10
+R.ref_profiler_stop()
+buf = np.empty(5, dtype=np.float32)
+ref = {}
+for i in range(R.ref_profiler_get_stats()):
+    n = R.ref_profiler_stats(i, buf.ctypes.data)
+    ref[R.ref_profiler_key(i).decode()] = ([float(v) for v in buf], int(n))
+R.ref_profiler_destroy()
+got = {k: [float(v[s]) for s in (Statistic.MIN, Statistic.MAX, Statistic.MED, Statistic.AVG, Statistic.STD, Statistic.NUM)]
+       for k, v in report.local_kernel_summaries.items()}
+newest = {k: sorted(float(np.float32(v)) for v in h[-CAP:]) for k, h in hist.items()}
+stored = {k: sorted(float(v) for v in Detector.rings.read_row(Detector.rings.kernel_row_names[k])[:CAP]) for k in hist}
+out = {"missing": [int(missing), int(again)], "wait_us": t_wait, "idle_us": t_idle, "counters": [c0, c1],
+       "hist_len": {k: int(h.size) for k, h in hist.items()}, "ref": ref, "got": got, "newest": newest, "stored": stored,
+       "section_num": int(report.local_section_summaries["step"][Statistic.NUM]),
+       "gpu_rel": float(report.gpu_relative_perf_scores[0])}
+Detector.shutdown()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _run(script, env_extra=None, timeout=200):
+    env = dict(os.environ)
+    for k in ("NVRX_GPU_TIMING", "WORLD_SIZE", "RANK"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\n" + script], capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+@pytest.mark.gpu
+def test_real_kernels_overflow_their_rings_and_the_newest_survive_like_the_reference():
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    out = _run(REAL_SCRIPT)
+    c0, c1 = out["counters"]
+    print(f"[ktrace datapath] harvest: {out['wait_us']:.1f} us waiting for the window's kernels, {out['idle_us']:.2f} us when "
+          f"everything has arrived; pump flushes {c1['pump_flushes'] - c0['pump_flushes']}, counted dispatches "
+          f"{c1['enqueued'] - c0['enqueued']}, own-kernel records left out {c1['own_skipped'] - c0['own_skipped']}")
+    assert out["missing"] == [0, 0]
+    assert c1["counting"] == 1
+    assert c1["enqueued"] - c0["enqueued"] == c1["arrived"] - c0["arrived"] >= 3 * 60
+    assert c1["sink_errors"] == c0["sink_errors"] and c1["lost_no_row"] == c0["lost_no_row"]
+    assert out["idle_us"] < 50.0, out["idle_us"]                   # a counter comparison + the ctypes call, no per-record work
+    assert out["section_num"] == 16                                   # the section's own ring is 16 deep as well
+    assert len(out["hist_len"]) >= 3 and all(n >= 60 for n in out["hist_len"].values()), out["hist_len"]   # > 3 x cap per key
+    assert set(out["got"]) == set(out["ref"]) == set(out["hist_len"])
+    for key, (e, n) in out["ref"].items():
+        g = out["got"][key]
+        assert g[5] == n == 16, (key, g, n)
+        assert g[0] == e[0] and g[1] == e[1] and g[2] == e[2], (key, g, e)          # MIN MAX MED bit-exact
+        assert abs(g[3] - e[3]) <= 2e-4 * abs(e[3]) and abs(g[4] - e[4]) <= 2e-3 * max(abs(e[4]), 1e-3), (key, g, e)
+        assert out["stored"][key] == out["newest"][key], key                         # the ring holds the NEWEST 16
+    assert abs(out["gpu_rel"] - 1.0) < 1e-6
+
+
+ASYNC_SCRIPT = r'''
+import faulthandler, json, os, sys, time
+faulthandler.enable()
+faulthandler.dump_traceback_later(170, exit=True)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+os.environ["NVRX_GPU_TIMING"] = "kernels"
+import torch
+import nvrx_straggler
+from nvrx_straggler import Detector, Statistic, ktrace
+
+torch.cuda.set_device(0)
+torch.cuda._sleep(1000); torch.cuda.synchronize()
+Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n0", asynchronous=True)
+N, CYCLES = 12, int(8.0e6)                  # 12 long one-block kernels: the report comes while most of them are still queued
+nums, waits, sync_s = [], [], 0.0
+for window in range(3):
+    if window < 2:
+        for i in range(N):
+            with Detector.detection_section("step", profile_cuda=True):
+                torch.cuda._sleep(CYCLES)
+    t0 = time.perf_counter()
+    report = Detector.generate_report()     # asynchronous: enqueues, does not wait for the sleeps
+    waits.append(time.perf_counter() - t0)
+    if window == 1:
+        t0 = time.perf_counter()
+        torch.cuda.synchronize()            # let the second window's kernels finish before the last report
+        sync_s = time.perf_counter() - t0
+        ktrace.load().nvrx_ktrace_sync(5.0)
+    ks = report.local_kernel_summaries      # first read waits for the report's own kernels only
+    key = [k for k in ks if "spin" in k.lower() or "sleep" in k.lower()]
+    nums.append(int(ks[key[0]][Statistic.NUM]) if key else 0)
+    if window == 0:
+        first_gpu = {str(k): float(v) for k, v in report.gpu_relative_perf_scores.items()}
+c = ktrace.counters()
+Detector.shutdown()
+print("RESULT " + json.dumps({"nums": nums, "waits": waits, "counters": c, "first_gpu": first_gpu, "sync_s": sync_s}))
+'''
+
+
+@pytest.mark.gpu
+def test_asynchronous_reports_in_per_kernel_mode_do_not_wait_and_lose_nothing():
+    out = _run(ASYNC_SCRIPT)
+    print("[ktrace async]", out["nums"], [round(w * 1e3, 2) for w in out["waits"]], "ms per generate_report()")
+    nums = out["nums"]
+    assert sum(nums) == 24, nums                       # every traced kernel is counted exactly once ...
+    assert nums[0] < 12, nums                          # ... the first report did not wait for its window's kernels
+    assert out["waits"][0] < out["sync_s"] / 4, out    # (the sleeps of two windows took sync_s to drain)
+    assert out["counters"]["enqueued"] == out["counters"]["arrived"] + out["counters"]["forgiven"]

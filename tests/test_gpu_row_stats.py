@@ -353,26 +353,36 @@ def test_bulk_append_of_row_value_pairs_matches_the_ring_of_the_reference(be, ca
         rings.close()
 
 
-def test_tracer_records_reach_their_rows_in_one_launch(be):
-    """KernelTraceProfiler.ingest (what harvest() does with the drained records) on synthetic records: 4096 kernel
-    keys x 100 durations; every key's statistics row equals the oracle's computeStats of its own durations."""
+def test_tracer_records_reach_their_rows_through_the_native_sink(be):
+    """The per-kernel tracer's path into the device rings (``nvrx_ktrace_feed`` -> key cache -> ``nvrx_ring_push_staged``;
+    what the rocprofiler-sdk callback thread does with its batches) on synthetic dispatches: 4096 kernel keys x 100
+    durations in batches of ~1000; every key's statistics row equals the oracle's computeStats of its own durations."""
     from nvrx_straggler import ktrace
 
     K, per = 4096, 100
     rng = np.random.default_rng(7)
-    recs = np.empty(K * per, dtype=ktrace.RECORD_DTYPE)
-    recs["key"] = rng.permutation(np.repeat(np.arange(K, dtype=np.uint32), per))
-    recs["us"] = rng.lognormal(3.0, 0.4, K * per).astype(np.float32)
+    base = 1 << 44
+    for k in range(K):
+        ktrace.feed_kernel_name(base + k, f"k{k:04d}")
+    d = np.zeros(K * per, dtype=ktrace.DISPATCH_DTYPE)
+    kid = rng.permutation(np.repeat(np.arange(K, dtype=np.uint64), per))
+    d["kernel_id"] = base + kid
+    d["workgroup"], d["grid"], d["start_ns"] = (64, 1, 1), (64 * 3, 1, 1), 1000
+    ns = (rng.lognormal(3.0, 0.4, K * per) * 1000.0).astype(np.uint64) + 1
+    d["end_ns"] = 1000 + ns
+    us = ns.astype(np.float32) / np.float32(1000.0)
+    ktrace.KernelTraceProfiler._live = None
     prof = ktrace.KernelTraceProfiler(statsMaxLenPerKernel=128, max_keys=K)
     try:
-        assert prof.ingest(recs[: K * per // 2]) == K * per // 2
-        assert prof.ingest(recs[K * per // 2:]) == K * per - K * per // 2
+        for lo in range(0, d.size, 1000):
+            ktrace.feed(d[lo:lo + 1000])
+        assert prof.harvest(wait=True) == 0
         stats = prof._rings.peek_stats()
-        assert len(prof._key_rows) == K and prof.keys_without_row == 0
+        rows = prof._rings.kernel_row_names
+        assert len(rows) == K and prof.keys_without_row == 0
         for k in rng.integers(0, K, 200).tolist():
-            mine = recs["us"][recs["key"] == k]
-            e = oracle.kernel_stats(mine)
-            row = prof._key_rows[k]
+            e = oracle.kernel_stats(us[kid == k])
+            row = rows[f"k{k:04d}_blk_64_1_1_grid_3_1_1"]
             assert stats[row][5] == per and stats[row][0] == e[0] and stats[row][1] == e[1] and stats[row][2] == e[2], k
     finally:
         prof.close()

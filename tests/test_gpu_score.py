@@ -57,10 +57,16 @@ def test_score_kernel_matches_oracle(be, R, K, S):
         assert np.allclose(got[ok], exp[ok], rtol=2e-6, atol=0), np.abs(got[ok] - exp[ok]).max()
         # section scores are a single f64 division rounded to f32: bit-exact
         assert np.array_equal(got[:, 2:][~np.isnan(exp[:, 2:])], exp[:, 2:][~np.isnan(exp[:, 2:])])
+        # flags: the ORACLE's scores against the thresholds (strict <, NaN never flagged: reporting.py:84-151).  Section
+        # columns are bit-exact, so their flags must be too; a GPU score (columns 0-1, 2e-6 apart from the oracle's serial
+        # sum) that sits within that distance of its threshold is the one case left out of the comparison
         thr_cols = np.concatenate([[0.9, 0.8], np.full(S, 0.6), np.full(S, 0.7)])
         with np.errstate(invalid="ignore"):
-            exp_flags = (got.astype(np.float64) < thr_cols[None, :]).astype(np.uint8)
-        assert np.array_equal(flags, exp_flags)
+            exp_flags = (exp.astype(np.float64) < thr_cols[None, :]).astype(np.uint8)
+            decided = ~(np.abs(exp.astype(np.float64) - thr_cols[None, :]) <= 4e-6 * thr_cols[None, :])
+        decided[:, 2:] = True
+        assert np.array_equal(flags[decided], exp_flags[decided])
+        assert decided.mean() > 0.999
         assert list(meta[:4]) == [1, R, K, S]
 
 

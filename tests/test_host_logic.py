@@ -49,15 +49,16 @@ def test_ktrace_library_exports_every_symbol_in_its_header():
 
     header = open(os.path.join(REPO, "include", "nvrx_ktrace.h")).read()
     declared = set(re.findall(r"^(?:int|uint64_t|const char \*)\s*(nvrx_ktrace_\w+)\s*\(", header, flags=re.M))
-    assert len(declared) == 13, declared
+    assert len(declared) == 23, declared
     lib = ktrace.load()
     assert declared == {name for name, _, _ in ktrace.SYMBOLS}
     for name in declared:
         assert hasattr(lib, name)
     assert hasattr(lib, "rocprofiler_configure")  # what ROCP_TOOL_LIBRARIES / force_configure bind
     assert lib.nvrx_ktrace_ready() == 0
-    assert lib.nvrx_ktrace_num_keys() == 0 and lib.nvrx_ktrace_pending() == 0 and lib.nvrx_ktrace_dropped() == 0
-    assert lib.nvrx_ktrace_key_name(0) is None
+    assert lib.nvrx_ktrace_key_name(1 << 30) is None and lib.nvrx_ktrace_key_row(1 << 30) == -2
+    assert lib.nvrx_ktrace_sync(0.0) == 0 and lib.nvrx_ktrace_forgive() == 0
+    assert ctypes.sizeof(ktrace.Sink) == 32 and ctypes.sizeof(ktrace.Dispatch) == 48   # the structs of the header
     assert lib.nvrx_ktrace_start() == -1 and b"not set up" in lib.nvrx_ktrace_last_error()
     assert lib.nvrx_ktrace_drain(None, 4) == -22
     buf = (ktrace.Record * 4)()
@@ -65,77 +66,67 @@ def test_ktrace_library_exports_every_symbol_in_its_header():
     assert ctypes.sizeof(ktrace.Record) == 8 and ktrace.RECORD_DTYPE.itemsize == 8
 
 
-def test_kernel_trace_profiler_host_logic_with_a_fake_tracer(monkeypatch):
-    """KernelTraceProfiler.harvest / get_stats / reset on CPU: drained (key, us) records are appended to one ring
-    row per kernel key in launch order, statistics follow computeStats (mean-of-middles median, population
-    stddev), a full ring table drops further keys with a warning instead of failing the report."""
-    import ctypes
-
+def test_kernel_trace_profiler_lifecycle_over_the_native_data_path(monkeypatch):
+    """KernelTraceProfiler on CPU: start / stop nest as "subsequent calls" (CuptiProfiler.cpp:116-133), only one instance
+    may live (CuptiProfiler.cpp:86-88), records reach one ring row per kernel key through the NATIVE path (fed through
+    ``nvrx_ktrace_feed``; tests/test_ktrace_datapath.py pins the path itself against the reference), statistics follow
+    computeStats (mean-of-middles median, population stddev), reset empties the rows."""
     from nvrx_straggler import backend, ktrace
     from oracle_backend import OracleBackend
 
-    class FakeLib:
-        def __init__(self):
-            self.started = 0
-            self.resets = 0
-
-        def nvrx_ktrace_ready(self):
-            return 1
-
-        def nvrx_ktrace_start(self):
-            self.started += 1
-            return 0
-
-        def nvrx_ktrace_stop(self):
-            self.started -= 1
-            return 0
-
-        def nvrx_ktrace_reset(self):
-            self.resets += 1
-            return 0
-
-        def nvrx_ktrace_dropped(self):
-            return 0
-
-    fake = FakeLib()
-    names = {0: "gemm_blk_256_1_1_grid_64_1_1", 1: "relu_blk_256_1_1_grid_1024_1_1", 2: "ncclDevKernel_blk_1_1_1_grid_1_1_1",
-             3: "late_blk_1_1_1_grid_1_1_1"}
-    recs = np.array([(0, 10.0), (1, 2.0), (0, 30.0), (2, 99.0), (1, 4.0), (0, 20.0), (0, 40.0)], dtype=ktrace.RECORD_DTYPE)
-    queue = [recs]
-    monkeypatch.setattr(ktrace, "load", lambda: fake)
-    monkeypatch.setattr(ktrace, "drain_all", lambda: queue.pop(0) if queue else np.empty(0, dtype=ktrace.RECORD_DTYPE))
-    monkeypatch.setattr(ktrace, "key_name", lambda k: names[int(k)])
+    calls = {"start": 0, "stop": 0}
+    lib = ktrace.load()
     monkeypatch.setattr(ktrace, "_setup_error", None)
+    monkeypatch.setattr(ktrace, "setup", lambda *a, **k: None)
     monkeypatch.setattr(ktrace.KernelTraceProfiler, "_live", None)
-    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)  # harvest(wait=True) on a box without a GPU
     backend.set_backend(OracleBackend())
     try:
         rings = backend.get_backend().make_rings(1, 3, 16)
         prof = ktrace.KernelTraceProfiler(statsMaxLenPerKernel=16, rings=rings)
         with pytest.raises(RuntimeError, match="Only one"):
             ktrace.KernelTraceProfiler(rings=rings)
-        prof.initialize()
+        with pytest.raises(RuntimeError):     # no HIP device here: the SDK never calls the tool's initialiser
+            prof.initialize()
+
+        class _Lib:                            # start / stop without the SDK: count the calls that reach the library
+            def __getattr__(self, name):
+                return getattr(lib, name)
+
+            def nvrx_ktrace_start(self):
+                calls["start"] += 1
+                return 0
+
+            def nvrx_ktrace_stop(self):
+                calls["stop"] += 1
+                return 0
+
+        prof._lib = _Lib()
         prof.start("ignored")
         prof.start("ignored")  # "subsequent call": no second enable
-        assert fake.started == 1
-        assert prof.stop(5, 1.0) is False and fake.started == 0
-        assert prof.stop() is False
-        stats = prof.get_stats()  # harvest(wait=True) needs no device with the fake
-        assert set(stats) == {names[0], names[1], names[2]}
-        g = stats[names[0]]
+        assert calls == {"start": 1, "stop": 0}
+        assert prof.stop(5, 1.0) is False and calls["stop"] == 1
+        assert prof.stop() is False and calls["stop"] == 1
+        base = 1 << 50
+        names = {base: "gemm", base + 1: "relu", base + 2: "ncclDevKernel"}
+        for kid, n in names.items():
+            ktrace.feed_kernel_name(kid, n)
+        d = np.zeros(7, dtype=ktrace.DISPATCH_DTYPE)
+        d["kernel_id"] = [base, base + 1, base, base + 2, base + 1, base, base]
+        d["workgroup"], d["grid"], d["start_ns"] = (256, 1, 1), (256 * 64, 1, 1), 1000
+        d["end_ns"] = 1000 + 1000 * np.array([10, 2, 30, 99, 4, 20, 40], dtype=np.uint64)
+        ktrace.feed(d)
+        stats = prof.get_stats()
+        key = lambda n: f"{n}_blk_256_1_1_grid_64_1_1"  # noqa: E731
+        assert set(stats) == {key("gemm"), key("relu"), key("ncclDevKernel")}
+        g = stats[key("gemm")]
         assert (g.num_calls, g.min, g.max, g.median, g.avg) == (4, 10.0, 40.0, 25.0, 25.0)  # mean of the two middles
         assert abs(g.stddev - np.std([10, 30, 20, 40])) < 1e-5                            # population
-        assert stats[names[1]].median == 3.0 and stats[names[1]].num_calls == 2
-        # the rings are full (3 rows): a fourth key is dropped with one warning, the others keep recording
-        queue.append(np.array([(3, 1.0), (0, 50.0)], dtype=ktrace.RECORD_DTYPE))
-        with pytest.warns(UserWarning, match="rings are full"):
-            prof.harvest(wait=False)
-        assert prof.keys_without_row == 1
-        assert prof.get_stats()[names[0]].num_calls == 5
+        assert stats[key("relu")].median == 3.0 and stats[key("relu")].num_calls == 2
         prof.reset()
-        assert fake.resets == 1 and prof.get_stats() == {}
+        assert prof.get_stats() == {}
         prof.shutdown()
         prof.close()
+        assert lib.nvrx_ktrace_key_row(0) == -2   # the sink is gone: no key has a row any more
     finally:
         backend.set_backend(None)
 
@@ -630,6 +621,18 @@ def test_folded_job_over_two_gloo_ranks():
     assert all(v == [3] for v in rep["stragglers"]["0.75"]["straggler_sections_relative"].values())
     assert len(rep["stragglers"]["0.75"]["straggler_sections_relative"]) == 4
     assert rep["rank_to_node"] == {r: f"node{r // 4}" for r in range(8)}
+
+
+def test_ranks_agree_on_one_gpu_timing_mode_at_their_first_collective_report():
+    """A rank that could not register the kernel tracer times per region while the others time per kernel: no key is shared
+    and every relative GPU score would be NaN without a word.  The ranks MIN-reduce their mode at the
+    first collective report; the per-kernel rank drops to region timing ONCE and says so; both log the mode."""
+    res = run_ranks(workers.detector_mode_agreement, 2)
+    assert res[0]["switched"] == 1 and res[0]["mode"] == "stamp" and "another rank" in res[0]["note"]
+    assert res[1]["switched"] == 0 and res[1]["mode"] == "stamp"
+    assert any("measured per" in m for m in res[0]["log"]) and any("measured per" in m for m in res[1]["log"])   # said once at initialize
+    assert sum("all ranks time GPU work per profiled region" in m for m in res[0]["log"]) == 1
+    assert not any("all ranks time GPU work" in m for m in res[1]["log"])
 
 
 def test_interval_tracker_ranks_agree():

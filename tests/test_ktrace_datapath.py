@@ -1,0 +1,246 @@
+"""The per-kernel tracer's NATIVE data path (libnvrx_ktrace.so) without a GPU: dispatch records fed through
+``nvrx_ktrace_feed`` take the path of the rocprofiler-sdk callback thread from ``consume()`` on -- key cache, sink,
+per-key overwrite-oldest rings, counters -- and are compared with the REFERENCE's own ``CuptiProfiler`` (compiled from
+/root/reference into ``oracle/_ref``, fake CUPTI feed) on the same launches.  The rings here are the checker's NumPy
+rings behind the same two function pointers the device rings offer (``tests/oracle_backend.py``); the ``-m gpu`` twin
+(``tests/test_gpu_01_ktrace_datapath.py``) runs the very same scenario into the device rings.
+
+What is pinned (reference: cupti_src/CuptiProfiler.cpp:168-207, CircularBuffer.h:53-61):
+  * key = "<name>_blk_x_y_z_grid_x_y_z", grid in workgroups; records with a zero timestamp are skipped;
+  * per key the NEWEST statsMaxLenPerKernel durations survive (the round-4 queue dropped the newest);
+  * duration = (end - start) / 1000.0f in f32;
+  * the training thread does nothing per record: ``harvest()`` is a counter comparison.
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from nvrx_straggler import backend, ktrace
+from oracle import oracle
+from oracle_backend import OracleBackend
+
+_uid = [1 << 40]
+
+
+def _fresh_kernel_ids(n):
+    """kernel ids nobody in this process has used (the tracer's tables are process-wide)."""
+    _uid[0] += n
+    return np.arange(_uid[0] - n, _uid[0], dtype=np.uint64)
+
+
+def _launches(rng, names, per_key, shapes=None):
+    """A shuffled launch sequence: (kernel index, block, grid-in-blocks, start_ns, end_ns) per launch."""
+    K = len(names)
+    idx = rng.permutation(np.repeat(np.arange(K), per_key))
+    dur = rng.integers(1_000, 5_000_000, idx.size).astype(np.uint64)
+    start = np.cumsum(dur) + np.uint64(10_000)
+    blocks = shapes if shapes is not None else [((64 << (k % 3)), 1 + (k % 2), 1, 1 + k, 1 + (k % 5), 1) for k in range(K)]
+    return idx, dur, start, blocks
+
+
+def _as_dispatches(ids, idx, dur, start, blocks):
+    d = np.zeros(idx.size, dtype=ktrace.DISPATCH_DTYPE)
+    d["kernel_id"] = ids[idx]
+    for i, k in enumerate(idx.tolist()):
+        bx, by, bz, gx, gy, gz = blocks[k]
+        d["workgroup"][i] = (bx, by, bz)
+        d["grid"][i] = (gx * bx - (bx // 2 if bx > 1 else 0), gy * by, gz * bz)  # work-items; x is NOT a multiple of the block
+    d["start_ns"] = start
+    d["end_ns"] = start + dur
+    return d
+
+
+def _reference_stats(names, idx, dur, start, blocks, cap):
+    """The same launches through the reference's CuptiProfiler (oracle/_ref): key -> (min max median avg stddev, n)."""
+    R = oracle.ref_lib()
+    assert R.ref_profiler_create(1 << 20, 8, cap) == 0
+    try:
+        R.ref_profiler_initialize()
+        R.ref_profiler_start()
+        for i, k in enumerate(idx.tolist()):
+            bx, by, bz, gx, gy, gz = blocks[k]
+            R.ref_profiler_launch(names[k].encode(), bx, by, bz, gx, gy, gz, int(start[i]), int(start[i] + dur[i]))
+        R.ref_profiler_stop()
+        out = {}
+        buf = np.empty(5, dtype=np.float32)
+        for i in range(R.ref_profiler_get_stats()):
+            n = R.ref_profiler_stats(i, buf.ctypes.data)
+            out[R.ref_profiler_key(i).decode()] = (buf.copy(), n)
+        return out
+    finally:
+        R.ref_profiler_destroy()
+
+
+@pytest.fixture
+def profiler(monkeypatch):
+    """A KernelTraceProfiler over the checker's rings, the SDK not involved (``nvrx_ktrace_ready`` is 0 on this box)."""
+    made = []
+
+    def make(rows, cap):
+        monkeypatch.setattr(ktrace, "_setup_error", None)
+        monkeypatch.setattr(ktrace, "setup", lambda *a, **k: None)
+        monkeypatch.setattr(ktrace.KernelTraceProfiler, "_live", None)
+        backend.set_backend(OracleBackend())
+        rings = backend.get_backend().make_rings(1, rows, cap)
+        prof = ktrace.KernelTraceProfiler(statsMaxLenPerKernel=cap, rings=rings)
+        made.append(prof)
+        return prof, rings
+
+    yield make
+    for p in made:
+        p.close()
+    backend.set_backend(None)
+
+
+def test_per_key_rings_keep_the_newest_durations_like_the_reference(profiler):
+    """> 3 x cap launches per key, fed in SMALL batches from a second thread while the 'training' thread only ever calls
+    harvest(): statistics of every key equal the reference profiler's on the same launches."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this box)")
+    cap, K = 32, 12
+    rng = np.random.default_rng(11)
+    names = [f"_Z{6 + k}kernel{k:03d}Pfi" for k in range(K)]
+    ids = _fresh_kernel_ids(K)
+    for i, n in zip(ids.tolist(), names):
+        ktrace.feed_kernel_name(i, n)
+    idx, dur, start, blocks = _launches(rng, names, 3 * cap + 9)
+    disp = _as_dispatches(ids, idx, dur, start, blocks)
+    # a record CUPTI would skip (CuptiProfiler.cpp:182-184): it is counted as arrived, not recorded
+    zero = disp[:1].copy()
+    zero["start_ns"] = 0
+    prof, rings = profiler(K + 4, cap)
+    before = ktrace.counters()
+
+    def feeder():
+        ktrace.feed(zero)
+        for lo in range(0, disp.size, 7):
+            ktrace.feed(disp[lo:lo + 7])
+
+    t = threading.Thread(target=feeder)
+    t.start()
+    t.join()
+    assert prof.harvest(wait=True) == 0
+    after = ktrace.counters()
+    assert after["enqueued"] - before["enqueued"] == disp.size + 1 == after["arrived"] - before["arrived"]
+    assert after["delivered"] - before["delivered"] == disp.size
+    got = prof.get_stats()
+    exp = _reference_stats(names, idx, dur, start, blocks, cap)
+    assert set(got) == set(exp) and len(got) == K
+    for key, (e, n) in exp.items():
+        g = got[key]
+        assert g.num_calls == n == cap, key
+        assert (np.float32(g.min), np.float32(g.max), np.float32(g.median)) == (e[0], e[1], e[2]), key
+        assert abs(g.avg - e[3]) <= 2e-6 * abs(e[3]) and abs(g.stddev - e[4]) <= 2e-5 * abs(e[4]), key
+    # and it is the NEWEST cap durations of each key, in the reference's f32 arithmetic
+    for k in range(K):
+        mine = ((dur[idx == k]).astype(np.float32) / np.float32(1000.0))[-cap:]
+        row = rings.kernel_row_names[next(n for n in got if n.startswith(names[k] + "_blk_"))]
+        stored = rings.samples[row]
+        assert sorted(stored.tolist()) == sorted(mine.tolist()), k
+
+
+def test_key_format_and_grid_in_workgroups(profiler):
+    prof, rings = profiler(8, 16)
+    (kid,) = _fresh_kernel_ids(1).tolist()
+    ktrace.feed_kernel_name(kid, "_Z4gemmPKfS0_Pf")
+    d = np.zeros(3, dtype=ktrace.DISPATCH_DTYPE)
+    d["kernel_id"] = kid
+    d["workgroup"] = (256, 2, 1)
+    d["grid"] = [(256 * 10, 2 * 3, 1), (256 * 10 - 255, 6, 1), (256 * 11, 6, 1)]  # 10, 10 (rounded up), 11 workgroups in x
+    d["start_ns"] = 1000
+    d["end_ns"] = [3000, 4500, 7000]
+    ktrace.feed(d)
+    got = prof.get_stats()
+    assert set(got) == {"_Z4gemmPKfS0_Pf_blk_256_2_1_grid_10_3_1", "_Z4gemmPKfS0_Pf_blk_256_2_1_grid_11_3_1"}
+    g = got["_Z4gemmPKfS0_Pf_blk_256_2_1_grid_10_3_1"]
+    assert (g.num_calls, g.min, g.max, g.median) == (2, 2.0, 3.5, 2.75)  # microseconds; mean of the two middles
+    # a kernel nobody named (its code object was loaded before the tool's name context ran)
+    (anon,) = _fresh_kernel_ids(1).tolist()
+    d2 = d[:1].copy()
+    d2["kernel_id"] = anon
+    ktrace.feed(d2)
+    assert "unknown_kernel_blk_256_2_1_grid_10_3_1" in prof.get_stats()
+
+
+def test_engine_kernels_are_left_out_and_full_rings_drop_new_keys_not_old_ones(profiler):
+    prof, rings = profiler(3, 8)
+    ids = _fresh_kernel_ids(5).tolist()
+    for i, n in zip(ids, ("a", "b", "c", "d", "k_scatter")):
+        ktrace.feed_kernel_name(i, n, own=(n == "k_scatter"))
+    d = np.zeros(5, dtype=ktrace.DISPATCH_DTYPE)
+    d["kernel_id"] = [ids[4], ids[0], ids[1], ids[2], ids[0]]
+    d["workgroup"], d["grid"] = (64, 1, 1), (64, 1, 1)
+    d["start_ns"], d["end_ns"] = 1000, 2000
+    before = ktrace.counters()
+    ktrace.feed(d)
+    assert prof.harvest() == 0
+    after = ktrace.counters()
+    assert after["own_skipped"] - before["own_skipped"] == 1
+    assert {k.split("_blk_")[0] for k in prof.get_stats()} == {"a", "b", "c"}
+    # a fourth key finds no row: one warning, its durations are counted as lost, the others keep recording
+    d4 = d[:2].copy()
+    d4["kernel_id"] = [ids[3], ids[0]]
+    ktrace.feed(d4)
+    with pytest.warns(UserWarning, match="rings are full"):
+        prof.harvest()
+    assert prof.keys_without_row == 1 and prof.dropped >= 1
+    stats = prof.get_stats()
+    assert {k.split("_blk_")[0] for k in stats} == {"a", "b", "c"}
+    assert stats["a_blk_64_1_1_grid_1_1_1"].num_calls == 3
+    prof.reset()
+    assert prof.get_stats() == {}
+
+
+def test_harvest_waits_for_dispatches_that_are_still_running(profiler, monkeypatch):
+    """``nvrx_ktrace_sync``: a dispatch that was enqueued (counted) and whose record has not arrived is MISSING; harvest
+    (wait=False) says so without blocking, harvest(wait=True) returns once another thread delivers the record."""
+    prof, rings = profiler(4, 8)
+    (kid,) = _fresh_kernel_ids(1).tolist()
+    ktrace.feed_kernel_name(kid, "late")
+    d = np.zeros(2, dtype=ktrace.DISPATCH_DTYPE)
+    d["kernel_id"], d["workgroup"], d["grid"], d["start_ns"], d["end_ns"] = kid, (1, 1, 1), (1, 1, 1), 5, 2005
+    lib = ktrace.load()
+    assert lib.nvrx_ktrace_feed(None, 2, 1) == 0      # two kernels enqueued, none finished
+    assert prof.harvest(wait=False) == 2
+    assert prof.get_stats.__self__ is prof and rings.count(0) == 0
+    timer = threading.Timer(0.15, lambda: ktrace.feed(d, counted=False))
+    timer.start()
+    monkeypatch.setenv("NVRX_KTRACE_SYNC_PATIENCE_S", "5")
+    assert prof.harvest(wait=True) == 0               # blocks ~0.15 s in C, GIL released
+    timer.join()
+    assert prof.get_stats()["late_blk_1_1_1_grid_1_1_1"].num_calls == 2
+    # a dispatch whose record never comes: after the patience runs out the device is synchronised (stubbed here), the
+    # SDK flushed, and the dispatch is forgiven with one warning -- the next report does not wait for it again
+    import torch
+
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(ktrace.load(), "nvrx_ktrace_flush", lambda: 0, raising=False)
+    monkeypatch.setenv("NVRX_KTRACE_SYNC_PATIENCE_S", "0.05")
+    assert lib.nvrx_ktrace_feed(None, 1, 1) == 0
+    assert prof.harvest(wait=True) == 1
+    assert ktrace.counters()["forgiven"] >= 1
+    assert prof.harvest(wait=True) == 0
+
+
+def test_without_a_sink_the_pending_queue_keeps_the_newest(monkeypatch):
+    """No live profiler: records wait in the bounded queue ``nvrx_ktrace_drain`` pops; beyond ``max_pending`` the OLDEST
+    are dropped (round 4 dropped the newest -- the tail where a developing straggler shows)."""
+    lib = ktrace.load()
+    lib.nvrx_ktrace_set_sink(None)
+    lib.nvrx_ktrace_reset()
+    assert lib.nvrx_ktrace_set_max_pending(16) == 0
+    (kid,) = _fresh_kernel_ids(1).tolist()
+    ktrace.feed_kernel_name(kid, "queued")
+    d = np.zeros(40, dtype=ktrace.DISPATCH_DTYPE)
+    d["kernel_id"], d["workgroup"], d["grid"], d["start_ns"] = kid, (1, 1, 1), (1, 1, 1), 1000
+    d["end_ns"] = 1000 + 1000 * np.arange(1, 41, dtype=np.uint64)
+    dropped0 = int(lib.nvrx_ktrace_dropped())
+    ktrace.feed(d)
+    assert lib.nvrx_ktrace_pending() == 16 and int(lib.nvrx_ktrace_dropped()) - dropped0 == 24
+    buf = (ktrace.Record * 64)()
+    n = lib.nvrx_ktrace_drain(buf, 64)
+    assert n == 16 and [buf[i].us for i in range(n)] == [float(v) for v in range(25, 41)]
+    assert ktrace.key_name(buf[0].key) == "queued_blk_1_1_1_grid_1_1_1"
+    lib.nvrx_ktrace_set_max_pending(0)

@@ -636,3 +636,39 @@ def route_fault_injection(rank, world, fault, scenario):
     gen.close()
     torch.cuda.synchronize()
     return {"reports": reports, "info": info, "direct": direct, "state": state, "first_report_s": t_first}
+
+
+def detector_mode_agreement(rank, world):
+    """Rank 0 believes it times GPU work per kernel, rank 1 per region: the first collective report MIN-reduces the mode
+    code and rank 0 follows (``Detector._agree_timing_mode``); the comparison is made once per process group."""
+    import logging
+
+    from nvrx_straggler import Detector, ktrace
+
+    records = []
+
+    class _Grab(logging.Handler):
+        def emit(self, record):
+            records.append(record.getMessage())
+
+    log = logging.getLogger("nvrx_straggler.straggler")
+    log.addHandler(_Grab())
+    log.setLevel(logging.INFO)
+    Detector.initialize(scores_to_compute=["relative_perf_scores"], gather_on_rank0=True, node_name=f"host{rank}")
+    try:
+        switched = []
+        if rank == 0:  # the host logic of the switch is what is under test: the profiler swap itself needs the tracer (GPU twin)
+            ktrace._mode, ktrace._mode_note = "kernels", "forced by the test"
+            mgr = Detector.cupti_manager
+            mgr.per_kernel = True
+            mgr.switch_to_regions = lambda: (switched.append(1), setattr(mgr, "per_kernel", False), True)[-1]
+        for _ in range(3):
+            for _ in range(4):
+                with Detector.detection_section("s", profile_cuda=False):
+                    time.sleep(0.001)
+            Detector.generate_report()
+        return {"switched": len(switched), "mode": ktrace.timing_mode(), "note": ktrace.mode_note(),
+                "log": [m for m in records if "nvrx straggler" in m]}
+    finally:
+        ktrace._reset_mode_for_tests()
+        Detector.shutdown()
