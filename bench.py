@@ -385,7 +385,7 @@ def _kernels_mode_child():
     before.  Prints one JSON object.  This is the mode every multi-rank job runs in (``ktrace.timing_mode``).
 
     * ``per_step_overhead_kernels`` -- BASELINE.json's second figure in that mode: a step with a realistic dispatch count
-      (8 pre-norm transformer layers, d_model 2048, 8 x 1024 tokens, bf16, forward + backward + SGD: > 500 kernel dispatches,
+      (10 pre-norm transformer layers, d_model 2048, 8 x 1024 tokens, bf16, forward + backward + SGD: > 500 kernel dispatches,
       GPU-bound so the host runs ahead) inside ONE ``detection_section(profile_cuda=True)``.  Legs, A/B blocks alternating in
       one process, medians over blocks: no detector / section every step, no report (production cadence between reports) at
       ``profiling_interval`` 1 and 10 / a synchronous report EVERY step / an asynchronous report every step.  The reference's
@@ -398,7 +398,7 @@ def _kernels_mode_child():
 
     torch.cuda.set_device(0)
     torch.manual_seed(0)
-    d_model, layers, batch, seq = 2048, 8, 8, 1024
+    d_model, layers, batch, seq = 2048, 10, 8, 1024
     blocks = torch.nn.ModuleList([torch.nn.TransformerEncoderLayer(d_model, 16, 4 * d_model, dropout=0.0, batch_first=True,
                                                                    norm_first=True) for _ in range(layers)])
     blocks = blocks.to("cuda", torch.bfloat16)
@@ -485,6 +485,16 @@ def _kernels_mode_child():
         try:
             t, t_late, t_harvest = [], [], []
             held = None
+            mgr = Detector.cupti_manager
+            plain_harvest = mgr.harvest
+
+            def timed_harvest(wait=True):  # the training thread's share of the tracer's work at report time
+                h0 = time.perf_counter_ns()
+                r = plain_harvest(wait)
+                t_harvest.append(time.perf_counter_ns() - h0)
+                return r
+
+            mgr.harvest = timed_harvest
             for i in range(reports + 2):
                 for _ in range(60):
                     with Detector.detection_section("train_step", profile_cuda=True):
@@ -504,7 +514,9 @@ def _kernels_mode_child():
                     t_late.append(t2 - t1)
             a = np.asarray(t, dtype=np.float64) / 1e3
             res = {"us_median": round(float(np.median(a)), 2), "us_p95": round(float(np.percentile(a, 95)), 2),
-                   "us_max": round(float(a.max()), 2), "reports": len(t)}
+                   "us_max": round(float(a.max()), 2), "reports": len(t),
+                   "of_which_harvest_us_median": round(float(np.median(t_harvest[2:])) / 1e3, 2),
+                   "kernel_keys": len(Detector.rings.kernel_row_names)}
             if asynchronous:
                 res["read_one_interval_later_us_median"] = round(float(np.median(t_late)) / 1e3, 2)
             return res

@@ -68,6 +68,11 @@ typedef struct nvrx_ktrace_sink {
 int nvrx_ktrace_setup(int max_pending);
 /* The bound of the pending queue alone (<= 0: 1 << 20); records beyond it are dropped right away, oldest first. */
 int nvrx_ktrace_set_max_pending(int max_pending);
+/* rocprofiler_force_configure leaves ROCPROFILER_REGISTER_FORCE_LOAD=1 (and five GLOG_* settings) in the process
+ * environment; they are needed until this process' HIP runtime has started and would make every child process load and
+ * configure rocprofiler-sdk on `import torch`.  Puts the variables back as they were before nvrx_ktrace_setup; returns how
+ * many changed.  Call once nvrx_ktrace_ready() is 1 (nvrx_ktrace_start does it by itself). */
+int nvrx_ktrace_release_env(void);
 /* Libraries whose names the last nvrx_ktrace_setup kept out of rocprofiler-sdk's tool search. */
 int nvrx_ktrace_hidden_libraries(void);
 /* 1 once the SDK has called the tool's initialiser and its context is valid (after the first HIP call). */

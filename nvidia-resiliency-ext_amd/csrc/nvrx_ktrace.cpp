@@ -231,6 +231,49 @@ int other_threads_awake() {
 
 std::atomic<int> g_hidden_last{0};
 
+// rocprofiler_force_configure writes into the process ENVIRONMENT: ROCPROFILER_REGISTER_FORCE_LOAD=1 (so that the HIP / HSA
+// runtimes hand their API tables to the SDK when they start) and five GLOG_* settings.  Every child the job starts later
+// inherits them -- a DataLoader worker, a spawned rank of a test -- and in such a child librocprofiler-register then loads
+// and configures the SDK the moment libamdhip64 is loaded: the full tool search on `import torch`, and "already
+// configured" for anybody who wants to register a tool there.  The variables are needed until this process' runtime has
+// come up; after that they are put back as they were (nvrx_ktrace_release_env, called at the first start).
+const char *const kSdkEnvNames[] = {"ROCPROFILER_REGISTER_FORCE_LOAD", "GLOG_minloglevel", "GLOG_logtostderr",
+                                    "GLOG_alsologtostderr", "GLOG_stderrthreshold", "GLOG_v"};
+struct EnvSnapshot {
+    std::mutex mu;
+    bool taken = false, released = false;
+    std::vector<std::pair<bool, std::string>> values;  // (was set, value) per kSdkEnvNames entry
+    void take() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (taken) return;
+        for (const char *n : kSdkEnvNames) {
+            const char *v = getenv(n);
+            values.emplace_back(v != nullptr, v ? v : "");
+        }
+        taken = true;
+    }
+    int release() {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!taken || released) return 0;
+        int changed = 0;
+        for (size_t i = 0; i < values.size(); i++) {
+            const char *now = getenv(kSdkEnvNames[i]);
+            if (values[i].first) {
+                if (!now || values[i].second != now) {
+                    setenv(kSdkEnvNames[i], values[i].second.c_str(), 1);
+                    changed++;
+                }
+            } else if (now) {
+                unsetenv(kSdkEnvNames[i]);
+                changed++;
+            }
+        }
+        released = true;
+        return changed;
+    }
+};
+EnvSnapshot g_env;
+
 // ---- names ------------------------------------------------------------------------------------------------------
 void on_code_object(rocprofiler_callback_tracing_record_t record, rocprofiler_user_data_t *, void *) {
     if (record.kind != ROCPROFILER_CALLBACK_TRACING_CODE_OBJECT || record.phase != ROCPROFILER_CALLBACK_PHASE_LOAD) return;
@@ -538,6 +581,7 @@ int nvrx_ktrace_setup(int max_pending) {
             hidden.hide((size_t)min_mb << 20);
         }
         g_hidden_last.store((int)hidden.items.size());
+        g_env.take();
         KT_DBG("setup: calling rocprofiler_force_configure");
         rs = rocprofiler_force_configure(&rocprofiler_configure);
     }
@@ -571,6 +615,8 @@ int nvrx_ktrace_set_sink(const nvrx_ktrace_sink *sink) {
     return NVRX_KTRACE_OK;
 }
 
+int nvrx_ktrace_release_env(void) { return g_env.release(); }
+
 int nvrx_ktrace_hold(int on) {
     State &s = st();
     uint64_t released = 0;
@@ -600,6 +646,7 @@ int nvrx_ktrace_start(void) {
     State &s = st();
     if (!s.ready.load(std::memory_order_acquire)) return fail(NVRX_KTRACE_ERR_STATE, "kernel tracing is not set up");
     if (s.running.exchange(1)) return NVRX_KTRACE_OK;  // "subsequent call", CuptiProfiler.cpp:121-123
+    g_env.release();  // (the runtime is up: children of this process need not inherit the SDK's start-up switches)
     int active = 0;
     SDK_TRY(rocprofiler_context_is_active(s.ctx, &active));
     if (!active) SDK_TRY(rocprofiler_start_context(s.ctx));

@@ -2016,7 +2016,10 @@ struct nvrx_ctx {
     struct OpenStamp {
         int row;
         int slot;
+        bool own;  // the slot is one of this context's own (d_stamps_own), not one of the device's argument-free ones
     };
+    unsigned long long *d_stamps_own = nullptr;  // [NSTAMP], allocated the first time every argument-free slot is open elsewhere
+    int stamp_next_own = 0;
     std::vector<OpenStamp> open_stamps;
     std::vector<hipStream_t> stamp_streams;  // user streams with stamp kernels the rings have not been ordered after
     std::vector<int> skipped_regions;        // rows of regions opened on a capturing stream: closed without a sample
@@ -2064,6 +2067,9 @@ struct nvrx_ctx {
 
     std::mutex mu;
 };
+
+static bool stream_is_capturing(hipStream_t st);
+static void stamp_slot_give(int slot);
 
 namespace {
 
@@ -2134,9 +2140,39 @@ int order_after_stamps(nvrx_ctx *ctx, hipStream_t stream, hipStream_t also = nul
 // reading d_counts (which stays marked dirty until a later flush uploads it).
 // A staging buffer is free again when the scatter that read it has stored its ticket (k_scatter): usually long ago; else
 // the host spins on the pinned word (cold paths only: new row metadata, or a pusher a whole rotation ahead of the GPU).
+// The wait is bounded (NVRX_STAGE_WAIT_S, default 30 s: the scatter is a microsecond kernel on a stream of our own) and
+// looks at the device between slices: a scatter that never runs (device fault, a destroyed stream) becomes a HIP error or
+// a timeout after seconds, not a host thread spinning for half an hour with the context locked.
+double stage_wait_s() {
+    static const double v = [] {
+        const char *e = getenv("NVRX_STAGE_WAIT_S");
+        const double d = e ? atof(e) : 0.0;
+        return d > 0.0 ? d : 30.0;
+    }();
+    return v;
+}
+
 int wait_stage_buffer(StageBuf &b) {
     if (!b.in_flight) return NVRX_OK;
-    int rc = nvrx_poll_u32(const_cast<const uint32_t *>(b.h_done), b.ticket, 1800.0);
+    const double total = stage_wait_s();
+    double waited = 0.0;
+    int rc = NVRX_ERR_TIMEOUT;
+    while (waited < total) {
+        const double slice = std::min(0.25, total - waited);
+        rc = nvrx_poll_u32(const_cast<const uint32_t *>(b.h_done), b.ticket, slice);
+        if (rc != NVRX_ERR_TIMEOUT) break;
+        waited += slice;
+        const hipError_t e = hipGetLastError();  // a faulted device says so here
+        if (e != hipSuccess) {
+            b.in_flight = false;  // (nothing will ever read the buffer again)
+            return fail(NVRX_ERR_HIP, "staging flush did not complete: %s", hipGetErrorString(e));
+        }
+    }
+    if (rc == NVRX_ERR_TIMEOUT) {
+        // give the buffer up for lost rather than relaunch on a half-counted ticket: its samples are gone with it
+        b.in_flight = false;
+        return fail(NVRX_ERR_TIMEOUT, "staging flush (ticket %u) did not complete within %.0f s", b.ticket, total);
+    }
     if (rc) return rc;
     b.in_flight = false;
     return NVRX_OK;
@@ -2149,6 +2185,9 @@ int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, in
         if (rc) return rc;
     }
     if (ctx->n_staged == 0 && !ctx->meta_dirty && !ctx->counts_dirty) return NVRX_OK;
+    // a scatter captured into a hipGraph would never store its ticket (and would replay stale staging entries): refuse
+    if (stream_is_capturing(stream))
+        return fail(NVRX_ERR_STATE, "staged samples cannot be flushed on a stream that is being captured into a hipGraph");
     if (uniform_n && ctx->n_staged == 0 && !ctx->meta_dirty) {
         const uint64_t cap = (uint64_t)ctx->ring_cap;
         const uint64_t first = std::min<uint64_t>(ctx->total[0], cap);
@@ -2528,6 +2567,9 @@ int nvrx_ctx_destroy(nvrx_ctx *ctx) {
     if (ctx->d_rowg) (void)hipFree(ctx->d_rowg);
     if (ctx->h_gather_err) (void)hipHostFree(ctx->h_gather_err);
     if (ctx->d_stamps && !ctx->stamps_argfree) (void)hipFree(ctx->d_stamps);
+    if (ctx->d_stamps_own) (void)hipFree(ctx->d_stamps_own);
+    for (const auto &o : ctx->open_stamps)  // regions still open when the context goes: their device slots are free again
+        if (!o.own) stamp_slot_give(o.slot);
     delete ctx;
     return NVRX_OK;
 }
@@ -2656,7 +2698,7 @@ int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values
         ctx->bulk_cnt[(size_t)r]++;
     }
     if (ctx->bulk_in_flight) {  // the previous call's scatter still reads the entry buffer
-        int wrc = nvrx_poll_u32(const_cast<const uint32_t *>(ctx->bulk_word), ctx->bulk_ticket, 1800.0);
+        int wrc = nvrx_poll_u32(const_cast<const uint32_t *>(ctx->bulk_word), ctx->bulk_ticket, stage_wait_s());
         if (wrc) return wrc;
         ctx->bulk_in_flight = false;
     }
@@ -2897,6 +2939,30 @@ static bool stream_is_capturing(hipStream_t st) {
     return cs != hipStreamCaptureStatusNone;
 }
 
+// Argument-free stamp slots (g_stamp_slots) that are held by an OPEN region of some context of this process.
+static std::mutex g_stamp_slot_mu;
+static uint64_t g_stamp_slot_open = 0;  // bit i: slot i is held
+static unsigned g_stamp_slot_next = 0;
+static_assert(NVRX_NSTAMP <= 64, "the open-slot mask is one 64-bit word");
+
+static int stamp_slot_take() {
+    std::lock_guard<std::mutex> lk(g_stamp_slot_mu);
+    for (int tries = 0; tries < NVRX_NSTAMP; tries++) {
+        const int cand = (int)(g_stamp_slot_next % (unsigned)NVRX_NSTAMP);
+        g_stamp_slot_next++;
+        if (!(g_stamp_slot_open >> cand & 1ull)) {
+            g_stamp_slot_open |= 1ull << cand;
+            return cand;
+        }
+    }
+    return -1;
+}
+
+static void stamp_slot_give(int slot) {
+    std::lock_guard<std::mutex> lk(g_stamp_slot_mu);
+    g_stamp_slot_open &= ~(1ull << slot);
+}
+
 static bool take_skipped_region(nvrx_ctx *ctx, int row) {
     for (int i = (int)ctx->skipped_regions.size() - 1; i >= 0; i--)
         if (ctx->skipped_regions[(size_t)i] == row) {
@@ -2980,19 +3046,46 @@ int nvrx_stamp_begin(nvrx_ctx *ctx, int row, void *stream) {
         ctx->regions_skipped++;
         return NVRX_REGION_SKIPPED;
     }
-    int slot;
+    int slot = -1;
+    bool own = false;
     if (ctx->stamps_argfree) {
-        // the slots are the device's, shared by every context of the process on it: handed out process-wide
-        static std::atomic<unsigned> g_next{0};
-        slot = (int)(g_next.fetch_add(1u, std::memory_order_relaxed) % (unsigned)nvrx_ctx::NSTAMP);
-        hipLaunchKernelGGL(g_stamp_begin_fn[slot], dim3(1), dim3(1), 0, as_stream(stream));
+        // The slots are the device's, shared by every context of the process on it, so they are handed out process-wide --
+        // and a slot is not handed out again while the region that holds it is OPEN (between its begin and its end call) in
+        // ANY context: 64 later entries of other regions (other contexts, regions nested through the C ABI) would otherwise
+        // overwrite a long region's begin timestamp.  (Regions that are closed follow each other in stream order, so the
+        // round-robin reuse of their slots is safe on one stream however far the host runs ahead.)
+        slot = stamp_slot_take();
+        if (slot >= 0) {
+            hipLaunchKernelGGL(g_stamp_begin_fn[slot], dim3(1), dim3(1), 0, as_stream(stream));
+        } else {
+            // every argument-free slot is held by an open region: this one gets a slot of the context's own (one-argument kernel)
+            if (!ctx->d_stamps_own) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->d_stamps_own), nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(ctx->d_stamps_own, 0, nvrx_ctx::NSTAMP * sizeof(unsigned long long)));
+            }
+            own = true;
+        }
     } else {
-        slot = ctx->stamp_next;
-        ctx->stamp_next = (ctx->stamp_next + 1) % nvrx_ctx::NSTAMP;
-        hipLaunchKernelGGL(k_stamp_begin, dim3(1), dim3(1), 0, as_stream(stream), ctx->d_stamps + slot);
+        own = true;
+    }
+    if (own) {
+        unsigned long long *base = ctx->stamps_argfree ? ctx->d_stamps_own : ctx->d_stamps;
+        int &next = ctx->stamps_argfree ? ctx->stamp_next_own : ctx->stamp_next;
+        // (the context's own slots: skip those its open regions hold; open_stamps.size() < NSTAMP / 2, so one is free)
+        for (int tries = 0; tries < nvrx_ctx::NSTAMP; tries++) {
+            const int cand = next;
+            next = (next + 1) % nvrx_ctx::NSTAMP;
+            bool held = false;
+            for (const auto &o : ctx->open_stamps) held = held || (o.own && o.slot == cand);
+            if (!held) {
+                slot = cand;
+                break;
+            }
+        }
+        hipLaunchKernelGGL(k_stamp_begin, dim3(1), dim3(1), 0, as_stream(stream), base + slot);
     }
     HIP_TRY(hipGetLastError());
-    ctx->open_stamps.push_back({row, slot});
+    ctx->open_stamps.push_back({row, slot, own});
     return NVRX_OK;
 }
 
@@ -3004,7 +3097,10 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
     for (int i = (int)ctx->open_stamps.size() - 1; i >= 0; i--) {
         if (ctx->open_stamps[(size_t)i].row != row) continue;
         const int slot = ctx->open_stamps[(size_t)i].slot;
+        const bool own = ctx->open_stamps[(size_t)i].own;
+        const unsigned long long *slot_ptr = (own && ctx->stamps_argfree ? ctx->d_stamps_own : ctx->d_stamps) + slot;
         ctx->open_stamps.erase(ctx->open_stamps.begin() + i);
+        if (!own) stamp_slot_give(slot);
         if (stream_is_capturing(as_stream(stream))) {  // opened before the capture began: no sample, nothing enqueued
             ctx->regions_skipped++;
             return NVRX_REGION_SKIPPED;
@@ -3024,8 +3120,7 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
             int grc = guard_ring_writer(ctx, st);
             if (grc) return grc;
         }
-        hipLaunchKernelGGL(k_stamp_end, dim3(1), dim3(1), 0, st, ctx->d_stamps + slot, ctx->us_per_tick, dst_gpu, dst_cpu,
-                           cpu_value);
+        hipLaunchKernelGGL(k_stamp_end, dim3(1), dim3(1), 0, st, slot_ptr, ctx->us_per_tick, dst_gpu, dst_cpu, cpu_value);
         HIP_TRY(hipGetLastError());
         if (std::find(ctx->stamp_streams.begin(), ctx->stamp_streams.end(), st) == ctx->stamp_streams.end())
             ctx->stamp_streams.push_back(st);

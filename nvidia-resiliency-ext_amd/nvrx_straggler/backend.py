@@ -601,7 +601,7 @@ class HipRings:
 
     def report_fused(self, ws: Workspace, rows_active: int, stats_rows: int, do_indiv: bool, do_rel: bool,
                      thresholds: Sequence[float], direct=None, names_ok: bool = True, wait: bool = True,
-                     order_after: Optional[int] = None, resident: bool = True) -> int:
+                     order_after: Optional[int] = None, resident: bool = True, prev_settled: bool = False) -> int:
         """The whole report in one C call (``nvrx_report``): flush -> statistics kernel -> [``ncclAllGather`` of the
         exchange rows through ``direct``] -> score kernel -> wait for the completion word.  On return
         ``ws.scores / flags / meta / stats`` hold this report's values.  ``wait=False`` only enqueues (asynchronous
@@ -623,14 +623,15 @@ class HipRings:
             d.timeout_s = report_timeout_s()
             d.h_seq_word = blk.h_seq if wait else None
             d.guard_rings = 0 if wait else 1
-            # an asynchronous generator polls its previous report's completion word before it comes here
-            # (ReportGenerator._settle_inflight): the library may then stop guarding the rings against that report and,
-            # when reports are rare, enqueue this one on the stream it has to follow
-            d.prev_settled = 0 if wait else 1
             # resident score kernel on a stream of its own: the library decides among the eligible shapes (no exchange or
             # peer windows, table fits one workgroup); off when ranks share a device
             d.resident = 1 if (wait and resident) else 0
             blk.desc_key = key
+        # prev_settled: the caller has SEEN this context's previous asynchronous report complete (ReportGenerator polls its
+        # completion word in _settle_inflight and says so only when that poll returned): the library may then stop guarding
+        # the rings against that report and, when reports are rare, enqueue this one on the stream it has to follow.  A wait
+        # that raised, or a caller that never looked, leaves it 0 and the guards stay.
+        d.prev_settled = 1 if (prev_settled and not wait) else 0
         if order_after is not None:  # the caller's current stream: the report follows what is enqueued there
             d.order_after_stream, d.order_after_enabled = order_after, 1
         elif d.order_after_enabled:

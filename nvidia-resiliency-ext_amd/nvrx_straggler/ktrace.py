@@ -74,6 +74,7 @@ assert DISPATCH_DTYPE.itemsize == ctypes.sizeof(Dispatch) == 48
 SYMBOLS = [
     ("nvrx_ktrace_setup", c_int, [c_int]),
     ("nvrx_ktrace_set_max_pending", c_int, [c_int]),
+    ("nvrx_ktrace_release_env", c_int, []),
     ("nvrx_ktrace_hidden_libraries", c_int, []),
     ("nvrx_ktrace_ready", c_int, []),
     ("nvrx_ktrace_set_sink", c_int, [POINTER(Sink)]),
@@ -118,13 +119,28 @@ def load() -> ctypes.CDLL:
         if _lib is None:
             if not os.path.exists(_LIB_PATH):
                 raise RuntimeError(f"{_LIB_NAME} not found at {_LIB_PATH}; build it with `make -C nvidia-resiliency-ext_amd/csrc`")
-            lib = ctypes.CDLL(_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+            lib = ctypes.CDLL(_LIB_PATH, mode=ctypes.RTLD_GLOBAL)  # (loads librocprofiler-sdk, whose start-up code sets GLOG_* variables)
             for name, restype, argtypes in SYMBOLS:
                 fn = getattr(lib, name)
                 fn.restype = restype
                 fn.argtypes = argtypes
             _lib = lib
     return _lib
+
+
+_GLOG_NAMES = ("GLOG_minloglevel", "GLOG_logtostderr", "GLOG_alsologtostderr", "GLOG_stderrthreshold", "GLOG_v")
+
+
+def release_env() -> None:
+    """Once this process' HIP runtime is up: take back what rocprofiler-sdk wrote into the process environment --
+    ``ROCPROFILER_REGISTER_FORCE_LOAD=1`` (``nvrx_ktrace_release_env``; a child that inherits it loads and configures the SDK
+    on ``import torch``: the full tool search, and no tool can register there any more) and the ``GLOG_*`` switches its
+    library sets when it is loaded (those the job itself had not set)."""
+    load().nvrx_ktrace_release_env()
+    libc = ctypes.CDLL(None)
+    for name in _GLOG_NAMES:
+        if name not in os.environ:  # (os.environ is the environment this interpreter STARTED with, plus the job's own changes)
+            libc.unsetenv(name.encode())
 
 
 def _check(rc: int) -> int:
@@ -397,6 +413,9 @@ class KernelTraceProfiler:
 
     def initialize(self) -> None:
         self._ensure_ready()
+        # the runtime is up: what rocprofiler_force_configure left in the environment (ROCPROFILER_REGISTER_FORCE_LOAD=1 ...) must
+        # not reach the children this process starts from now on (DataLoader workers, spawned ranks)
+        release_env()
         self._initialized = True
 
     def shutdown(self) -> None:
@@ -515,6 +534,9 @@ class KernelTraceProfiler:
         return out
 
     def reset(self) -> None:
+        """Forget every recorded duration (reference: flush + map.clear(), CuptiProfiler.cpp:148-152): what the kernels
+        enqueued so far have produced is waited for first -- a record that arrived after the reset would bring its key back."""
+        self.harvest(wait=True)  # (also learns the rows of keys nobody has asked about yet)
         _check(self._lib.nvrx_ktrace_reset())
         for row in self._rings.kernel_row_names.values():
             self._rings.set_count(row, 0)

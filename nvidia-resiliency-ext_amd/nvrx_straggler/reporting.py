@@ -841,6 +841,8 @@ class ReportGenerator:
         self.asynchronous = bool(asynchronous)
         self._inflight: Optional[_PendingBlock] = None
         self.exchange_info: Dict[str, Any] = {}
+        self._unreported_rows: list = []  # see take_unreported_rows
+        self._prev_async_settled = True  # no asynchronous report of this generator is unaccounted for (see _settle_inflight)
         self._wr_cache: list = [None]  # this generator's remembered (default group, group, (world, rank)): dist_utils.world_and_rank
 
     # ---- pieces kept from the reference's host logic ----------------------------------------------
@@ -931,6 +933,12 @@ class ReportGenerator:
             return self._direct.exchange(ws, be)
         with be.stream_context():  # the collective must queue behind the statistics kernel
             return dist_utils.all_gather_rows(ws.send, ws.table, self.group)
+
+    def take_unreported_rows(self) -> list:
+        """Ring rows that held samples at the last ``generate_report_from_rings`` but were in no report (an asynchronous
+        report that met a new name runs on the old tables): their samples belong to the next window.  Empty otherwise."""
+        rows, self._unreported_rows = self._unreported_rows, []
+        return rows
 
     def close(self) -> None:
         """Release the direct-exchange communicator (collective-free; safe to call more than once)."""
@@ -1087,6 +1095,7 @@ class ReportGenerator:
             return False
         self._inflight = None
         names_word = pend.complete()  # a poll; the block is copied only if / when somebody reads or outlives it
+        self._prev_async_settled = True  # observed, not assumed: the next report tells the library so (prev_settled)
         self._check_exchange()
         return names_word != 1
 
@@ -1120,8 +1129,10 @@ class ReportGenerator:
                                      self.is_computing_rel_scores, self.thresholds, self._direct if multi else None,
                                      names_ok=names_ok, wait=wait, order_after=order_after if multi else None,
                                      resident=not (multi and getattr(self._direct, "shared_device", False)
-                                                   and os.environ.get("NVRX_RESIDENT_SHARED_OK", "0") in ("", "0")))
+                                                   and os.environ.get("NVRX_RESIDENT_SHARED_OK", "0") in ("", "0")),
+                                     prev_settled=self._prev_async_settled)
             if not wait:
+                self._prev_async_settled = False  # until somebody has seen THIS report complete
                 pend = self._inflight = _PendingBlock(be, ws, seq)
                 if self.gather_on_rank0 and self.rank != 0:
                     return None
@@ -1248,7 +1259,11 @@ class ReportGenerator:
             # asynchronous + a name this rank has no id for: the other ranks will not wait inside this report, so the
             # name exchange cannot happen now.  Run the OLD plan (the new rows are not exchanged yet) with the
             # "ids missing" flag in this rank's row; every rank meets it when it settles this report and they all
-            # sync names at the start of the next one.
+            # sync names at the start of the next one.  The rows of the new names are in nobody's report this time: the caller
+            # keeps their samples for the next window instead of dropping them with the rest (take_unreported_rows).
+            known_k, known_s = plan.kernel_rows, plan.section_rows
+            self._unreported_rows = ([r for n, r in kernel_rows.items() if n not in known_k and not is_collective_kernel(n)]
+                                     + [r for n, r in section_rows.items() if n not in known_s])
             return self._report_from_plan(plan, rings, t0, order_after, names_ok=False)
         kernel_rows = {k: r for k, r in kernel_rows.items() if not is_collective_kernel(k)} if any(
             is_collective_kernel(k) for k in kernel_rows) else kernel_rows

@@ -390,7 +390,16 @@ class Detector(metaclass=_DeviceSideOnDemand):
         order_after = _backend_mod.get_backend().current_stream_handle() if reporter.world_size > 1 else None
         report = reporter.generate_report_from_rings(rings, cls._active_sections, cls._active_kernels,
                                                      order_after=order_after)
+        keep = reporter.take_unreported_rows() if reporter.asynchronous else None
+        if keep:
+            # an asynchronous report that met names it has no ids for ran on the old tables (the ranks sync names at the next
+            # report): the samples of those rows were in nobody's report and stay for the next window
+            counts = rings.counts()
+            keep = [(row, int(counts[row])) for row in keep]
         rings.reset()  # both the section rows and the GPU-time rows, like :241-242 of the reference
+        if keep:
+            for row, n in keep:
+                rings.set_count(row, n)
         return report
 
     @classmethod

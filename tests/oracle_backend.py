@@ -311,7 +311,7 @@ class OracleRingsFused(OracleRings):
     """Adds the product's one-call report; results are computed at enqueue time, ``wait=False`` just skips nothing."""
 
     def report_fused(self, ws, rows_active, stats_rows, do_indiv, do_rel, thresholds, direct=None, names_ok=True, wait=True,
-                     order_after=None, resident=True):
+                     order_after=None, resident=True, prev_settled=False):
         from nvrx_straggler import dist_utils
 
         ws.settle()

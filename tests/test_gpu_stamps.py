@@ -123,3 +123,55 @@ def test_synchronous_report_follows_the_regions_it_reads_without_a_host_wait(mon
             assert abs(rep.gpu_relative_perf_scores[0] - 1.0) < 1e-6
     finally:
         Detector.shutdown()
+
+
+def test_a_long_open_region_keeps_its_begin_timestamp_while_other_contexts_open_many_regions():
+    """The argument-free stamp slots are the DEVICE's (64 of them, shared by every context of the process).  A region that
+    stays open while 200 other regions -- in two other contexts -- open and close must keep its begin timestamp: a slot is
+    not handed out again while the region that holds it is open anywhere in the process (it used to be reused
+    after 64 further begins, and the long region then reported a far too small GPU time).  And when ALL 64 device slots
+    are held by open regions, further regions fall back to slots of their own context and still measure."""
+    from nvrx_straggler import _native
+    from nvrx_straggler.backend import get_backend
+
+    be = get_backend()
+    a, b, c = be.make_rings(1, 8, 256), be.make_rings(1, 80, 256), be.make_rings(1, 8, 256)
+    try:
+        st = be.current_stream_handle()
+        long_row = a.row_for(_native.KIND_KERNEL, "long")
+        rows_b = [b.row_for(_native.KIND_KERNEL, f"r{i}") for i in range(70)]
+        row_c = c.row_for(_native.KIND_KERNEL, "short")
+        _spin(0.1)
+        torch.cuda.synchronize()
+        assert a.stamp_begin(long_row, st)
+        for i in range(100):                       # 200 region entries in other contexts while "long" is open
+            b.stamp_begin(rows_b[0], st)
+            _spin(0.01)
+            b.stamp_end(rows_b[0], st)
+            c.stamp_begin(row_c, st)
+            c.stamp_end(row_c, st)
+        assert a.stamp_end(long_row, st)
+        long_us = float(a.read_row(long_row)[0])
+        short = b.read_row(rows_b[0])[:100]
+        assert long_us >= float(short.sum()) > 0.0, (long_us, float(short.sum()))      # it spans every one of them
+        # 30 regions open at once in b (the per-context limit is 32) + 30 in c + 10 in a: more than 64 in the process
+        held = []
+        for rings, n, names in ((b, 30, rows_b), (c, 30, None), (a, 10, None)):
+            rows = names[1:1 + n] if names else [rings.row_for(_native.KIND_KERNEL, f"x{i}") for i in range(n)] if n <= 6 else None
+            if rows is None:                       # (a and c have 8 rows: nest on the rows they have, LIFO per row)
+                rows = [rings.row_for(_native.KIND_KERNEL, f"x{i}") for i in range(6)] * 5
+                rows = rows[:n]
+            for r in rows:
+                assert rings.stamp_begin(r, st)
+                held.append((rings, r))
+        _spin(0.5)
+        for rings, r in reversed(held):
+            assert rings.stamp_end(r, st)
+        torch.cuda.synchronize()
+        for rings, r in {(id(x), y): (x, y) for x, y in held}.values():
+            n = rings.count(r)
+            vals = rings.read_row(r)[:n]
+            assert n >= 1 and (vals > 100.0).all(), (n, vals)   # every one of the 70 regions spans the 0.5 ms spin
+    finally:
+        for r in (a, b, c):
+            r.close()

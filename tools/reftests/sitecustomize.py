@@ -42,3 +42,30 @@ if _repo and os.environ.get("NVRX_REFTEST") == "1":
                 pass
 
         atexit.register(_dump_maps)
+
+    # a child of a multi-process test that hangs says where (the parent only sees its queue time out)
+    _hang = os.environ.get("NVRX_REFTEST_HANGDUMP_S")
+    if _hang:
+        import faulthandler
+
+        faulthandler.enable()
+        faulthandler.dump_traceback_later(float(_hang), exit=False)
+
+    # The sleep-timed scenarios (test_sections, test_wrap_callables, test_interval_tracker) draw their section times from
+    # seeded generators, so what they expect is deterministic -- what is not is time.sleep's overshoot on a loaded host
+    # (a 10 ms sleep that takes 12 ms moves a median across a threshold; seen once in ~20 runs with ANY implementation
+    # behind the API).  The runner therefore makes the sleeps exact: sleep most of the interval, spin the last
+    # millisecond.  The tests are untouched; NVRX_REFTEST_PRECISE_SLEEP=0 gives the plain time.sleep back.
+    if os.environ.get("NVRX_REFTEST_PRECISE_SLEEP", "1") != "0":
+        import time as _time
+
+        _plain_sleep = _time.sleep
+
+        def _precise_sleep(seconds):
+            deadline = _time.perf_counter() + seconds
+            if seconds > 0.002:
+                _plain_sleep(seconds - 0.0015)
+            while _time.perf_counter() < deadline:
+                pass
+
+        _time.sleep = _precise_sleep

@@ -7,6 +7,7 @@
 # Usage: tools/run_reference_tests_gpu.sh [out_dir]
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=${1:-$REPO/gpurun_out}
+case "$OUT" in /*) ;; *) OUT="$PWD/$OUT" ;; esac
 REF="$REPO/oracle/_ref/reference"
 T="$REF/tests/straggler"
 mkdir -p "$OUT"
@@ -20,7 +21,7 @@ for mode in kernels stamp; do
   log="$OUT/reference_suite_$mode.log"
   echo "==== reference unit suite, NVRX_GPU_TIMING=$mode, $(date -u +%FT%TZ) ====" > "$log"
   NVRX_GPU_TIMING=$mode NVRX_REFTEST_MAPS="$OUT/reference_suite_${mode}_maps.txt" timeout 1500 \
-    python -m pytest -p no:cacheprovider -rA -q --timeout=600 unit >> "$log" 2>&1 || rc=1
+    python -m pytest -p no:cacheprovider -p nvrx_reftest_plugin -rA -q --timeout=600 unit >> "$log" 2>&1 || rc=1
   tail -n 3 "$log"
 done
 exit $rc
