@@ -37,6 +37,7 @@ Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
                   dicts is timed next to it; the single-rank, no-collective figure is kept as a sub-object.
 """
 import argparse
+import ctypes
 import gc
 import json
 import os
@@ -379,8 +380,8 @@ def _per_kernel_leg(reports: int = 12):
     return out
 
 
-def _kernels_mode_child():
-    """``python bench.py --child kernels_mode``: the legs that need PER-KERNEL tracing, in a fresh interpreter -- the tracer
+def _kernels_mode_child(mode: str = "kernels"):
+    """``python bench.py --child kernels_mode`` (``--child stamp_mode``: the same legs on region stamps, as the comparison): the legs that need PER-KERNEL tracing, in a fresh interpreter -- the tracer
     registers with rocprofiler-sdk before the HIP runtime starts, and the bench's main process has selected its device long
     before.  Prints one JSON object.  This is the mode every multi-rank job runs in (``ktrace.timing_mode``).
 
@@ -392,7 +393,7 @@ def _kernels_mode_child():
       claim for kernel profiling: < 1 % (docs/source/straggler_det/usage_guide.rst:169).
     * ``report_at_cadence_kernels`` -- one report per 100 of those steps, each timed alone after the step's own device
       synchronisation: synchronous (call -> flagged set) and asynchronous (the enqueue; read one interval later)."""
-    os.environ["NVRX_GPU_TIMING"] = "kernels"
+    os.environ["NVRX_GPU_TIMING"] = mode
     import nvrx_straggler  # noqa: F401  (registers the tracer: nothing has touched HIP yet)
     from nvrx_straggler import Detector, ktrace
 
@@ -451,22 +452,32 @@ def _kernels_mode_child():
                     acc[name].append(timed(fn, steps))
                     if name == "section":
                         Detector.generate_report()   # empties the rings (not timed)
-            med = {k: float(np.median(v)) for k, v in acc.items()}
+            # PAIRED differences: every round times all legs back to back, so the round's own "without" is the reference of its
+            # other legs -- clock / thermal drift over the run (which moved the unpaired figure between 0.3 and 2.2 % from one
+            # box to the next) cancels inside a round; the median over rounds and the spread are reported
+            base = np.asarray(acc["without"])
+
+            def paired(name):
+                d = (np.asarray(acc[name]) - base) / base * 100.0
+                return {"pct_median": round(float(np.median(d)), 3), "pct_min": round(float(d.min()), 3), "pct_max": round(float(d.max()), 3),
+                        "added_us_per_step_median": round(float(np.median(np.asarray(acc[name]) - base)) * 1e6, 1)}
+
+            sec = paired("section")
             res = {"profiling_interval": interval, "dispatches_traced_per_profiled_step": int(dispatches),
-                   "step_ms_without": round(med["without"] * 1e3, 4),
-                   "section_every_step_no_report_pct": round((med["section"] - med["without"]) / med["without"] * 100.0, 3),
-                   "section_added_us_per_step": round((med["section"] - med["without"]) * 1e6, 1)}
-            if "report_every_step" in med:
-                res["report_every_step_pct"] = round((med["report_every_step"] - med["without"]) / med["without"] * 100.0, 3)
-                res["report_every_step_added_us"] = round((med["report_every_step"] - med["without"]) * 1e6, 1)
+                   "step_ms_without": round(float(np.median(base)) * 1e3, 4),
+                   "section_every_step_no_report_pct": sec["pct_median"], "section_every_step_no_report": sec}
+            if "report_every_step" in acc:
+                rep_ = paired("report_every_step")
+                res["report_every_step_pct"] = rep_["pct_median"]
+                res["report_every_step"] = rep_
             return res
         finally:
             Detector.shutdown()
 
-    steps, rounds = 20, 6
+    steps, rounds = (10, 14) if mode == "kernels" else (10, 8)
     try:
         o1 = overhead_legs(1, steps, rounds)
-        o10 = overhead_legs(10, steps, rounds)
+        o10 = overhead_legs(10, steps, rounds) if mode == "kernels" else o1
         # one report per 100 steps on top of the section: what a job at the reference's default cadence pays per step
         out["per_step_overhead_kernels"] = {
             "profiling_interval_1": o1, "profiling_interval_10": o10,
@@ -474,8 +485,8 @@ def _kernels_mode_child():
             "pct_at_profiling_interval_10": o10["section_every_step_no_report_pct"],
             "steps_per_block": steps, "blocks": rounds, "counters": ktrace.counters(),
             "workload": f"{layers} x TransformerEncoderLayer(d_model {d_model}, 16 heads, ffn {4 * d_model}, pre-norm, bf16), batch {batch} x "
-                        f"{seq} tokens, forward + backward + SGD inside ONE detection_section(profile_cuda=True), NVRX_GPU_TIMING=kernels "
-                        "(every dispatch of the section traced by name); pct = section every step, no report (what a step pays between "
+                        f"{seq} tokens, forward + backward + SGD inside ONE detection_section(profile_cuda=True), NVRX_GPU_TIMING={mode} "
+                        "(kernels: every dispatch of the section traced by name); pct = section every step, no report (what a step pays between "
                         "two reports); report_every_step_pct = a synchronous generate_report() + identify_stragglers() after every step"}
     except Exception as e:  # noqa: BLE001
         out["per_step_overhead_kernels"] = {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
@@ -483,7 +494,8 @@ def _kernels_mode_child():
     def cadence(asynchronous, reports):
         Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="node0", asynchronous=asynchronous)
         try:
-            t, t_late, t_harvest = [], [], []
+            t, t_late, t_harvest, stages = [], [], [], []
+            clk = (ctypes.c_double * 8)()
             held = None
             mgr = Detector.cupti_manager
             plain_harvest = mgr.harvest
@@ -502,6 +514,7 @@ def _kernels_mode_child():
                 torch.cuda.synchronize()
                 t0 = time.perf_counter_ns()
                 rep = Detector.generate_report()
+                tg = time.perf_counter_ns()
                 if not asynchronous:
                     rep.identify_stragglers()
                 t1 = time.perf_counter_ns()
@@ -509,14 +522,22 @@ def _kernels_mode_child():
                     held.identify_stragglers()
                 t2 = time.perf_counter_ns()
                 held = rep
+                Detector.rings.lib.nvrx_report_clocks(clk)
                 if i >= 2:
                     t.append(t1 - t0)
                     t_late.append(t2 - t1)
+                    stages.append([tg - t0, t1 - tg, (clk[1] - clk[0]) * 1e3, (clk[2] - clk[1]) * 1e3, (clk[3] - clk[2]) * 1e3,
+                                   (clk[5] - clk[3]) * 1e3, (clk[6] - clk[5]) * 1e3 if not asynchronous else 0.0,
+                                   (clk[6] - clk[0]) * 1e3 if not asynchronous else (clk[5] - clk[0]) * 1e3])
             a = np.asarray(t, dtype=np.float64) / 1e3
             res = {"us_median": round(float(np.median(a)), 2), "us_p95": round(float(np.percentile(a, 95)), 2),
                    "us_max": round(float(a.max()), 2), "reports": len(t),
                    "of_which_harvest_us_median": round(float(np.median(t_harvest[2:])) / 1e3, 2),
                    "kernel_keys": len(Detector.rings.kernel_row_names)}
+            st_ = np.median(np.asarray(stages, dtype=np.float64), axis=0) / 1e3
+            res["stages_us_median"] = dict(zip(("generate_report", "identify_stragglers", "c_stream_ordering", "c_flush_scatter",
+                                                "c_row_stats_launch", "c_score_launch", "c_wait_completion", "c_call_total"),
+                                               (round(float(v), 2) for v in st_)))
             if asynchronous:
                 res["read_one_interval_later_us_median"] = round(float(np.median(t_late)) / 1e3, 2)
             return res
@@ -536,14 +557,14 @@ def _kernels_mode_child():
     print("KERNELS_MODE " + json.dumps(out), flush=True)
 
 
-def _kernels_mode_leg(timeout_s: float = 420.0):
+def _kernels_mode_leg(child: str = "kernels_mode", timeout_s: float = 420.0):
     """Run ``_kernels_mode_child`` in a fresh interpreter on the same GPU (this process is idle meanwhile)."""
     import subprocess
 
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NVRX_GPU_TIMING"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "kernels_mode"], capture_output=True, text=True,
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", child], capture_output=True, text=True,
                        timeout=timeout_s, env=env)
     lines = [l for l in p.stdout.splitlines() if l.startswith("KERNELS_MODE ")]
     if p.returncode != 0 or not lines:
@@ -829,8 +850,8 @@ def main():
     ap.add_argument("--no-kernels-mode", action="store_true", help="skip the per-kernel-tracing legs (they run in a child interpreter)")
     ap.add_argument("--child", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    if args.child == "kernels_mode":
-        return _kernels_mode_child()
+    if args.child in ("kernels_mode", "stamp_mode"):
+        return _kernels_mode_child(args.child.split("_")[0])
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         if TOTAL_RANKS % args.gpus:
@@ -1013,13 +1034,14 @@ def main():
             torch.cuda.synchronize()
             direct = job.reporter._direct
             be_ = job.backend
+            from nvrx_straggler import dist_utils as _du
 
             def floor_once():
                 if direct is not None and hasattr(direct, "all_gather"):
                     direct.all_gather(f_send.data_ptr(), f_recv.data_ptr(), L1, be_.stream_handle)
                 else:
-                    with be_.stream_context():
-                        dist.all_gather_into_tensor(f_recv, f_send)
+                    with be_.stream_context():  # (RCCL group: all_gather_into_tensor; gloo: the host hop the reports take too)
+                        _du.all_gather_rows(f_send.view(1, L1), f_recv.view(world, L1), job.reporter.group)
                 be_.synchronize()
 
             for _ in range(10):
@@ -1097,6 +1119,11 @@ def main():
         job.backend.synchronize()
         torch.cuda.synchronize()
         kernels_mode = _side_leg(_kernels_mode_leg)
+        stamp_twin = _side_leg(_kernels_mode_leg, "stamp_mode")
+        if isinstance(kernels_mode, dict) and isinstance(stamp_twin, dict):
+            # the SAME workload on region stamps (single-process default): what of the figures above is the mode's doing
+            kernels_mode["same_workload_on_region_stamps"] = {k: stamp_twin.get(k) for k in
+                                                              ("per_step_overhead_kernels", "report_at_cadence_kernels", "error") if k in stamp_twin}
 
     overhead = overhead_async = None
     if not args.no_overhead:
@@ -1211,6 +1238,11 @@ def main():
             for k in ("per_step_overhead_kernels", "report_at_cadence_kernels", "error"):
                 if k in kernels_mode:
                     out[k if k != "error" else "kernels_mode_error"] = kernels_mode[k]
+            twin = kernels_mode.get("same_workload_on_region_stamps") or {}
+            if "per_step_overhead_kernels" in twin:
+                out["per_step_overhead_transformer_on_region_stamps"] = twin["per_step_overhead_kernels"]
+            if "report_at_cadence_kernels" in twin:
+                out["report_at_cadence_transformer_on_region_stamps"] = twin["report_at_cadence_kernels"]
             out["kernels_mode_registered_through"] = kernels_mode.get("registered_through")
         if host_inputs is not None:
             out["host_inputs"] = host_inputs

@@ -317,3 +317,90 @@ def test_a_step_that_ends_in_a_collective_per_kernel_default_sees_the_slow_gpu_r
     assert r0["report_keys"] == ["hipevent::train_step"] and len(r0["keys"]) == 1
     assert min(r0["gpu_rel"].values()) > 0.9, r0["gpu_rel"]                   # the slow GPU is invisible ...
     assert r0["flagged"] == []                                                 # ... and not flagged
+
+
+AGREE_SCRIPT = r'''
+import faulthandler, json, logging, os, sys
+faulthandler.enable()
+faulthandler.dump_traceback_later(170, exit=True)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+records = []
+class _Grab(logging.Handler):
+    def emit(self, record):
+        records.append(record.getMessage())
+logging.getLogger("nvrx_straggler").addHandler(_Grab())
+logging.getLogger("nvrx_straggler").setLevel(logging.INFO)
+import nvrx_straggler                      # rank 0: WORLD_SIZE=2 -> kernels; rank 1: NVRX_GPU_TIMING=stamp in its environment
+from nvrx_straggler import Detector, Statistic, ktrace
+import torch
+import torch.distributed as dist
+
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method=os.environ["NVRX_TEST_INIT"], rank=rank, world_size=2)
+Detector.initialize(scores_to_compute=["relative_perf_scores"], gather_on_rank0=True, node_name=f"node{rank}")
+mode_before = ktrace.timing_mode()
+cycles = int(float(os.environ["NVRX_TEST_CYCLES"]) * (1.25 if rank == 1 else 1.0))
+reports = []
+for window in range(3):
+    for i in range(12):
+        with Detector.detection_section("train_step", profile_cuda=True):
+            torch.cuda._sleep(cycles)       # (no collective inside: a region's time is this rank's own compute)
+    rep = Detector.generate_report()
+    if rank == 0:
+        reports.append({"gpu_rel": {str(k): float(v) for k, v in rep.gpu_relative_perf_scores.items()},
+                        "keys": sorted(rep.local_kernel_summaries)})
+    dist.barrier()
+out = {"mode_before": mode_before, "mode_after": ktrace.timing_mode(), "note": ktrace.mode_note(), "reports": reports,
+       "log": [m for m in records if "nvrx straggler" in m]}
+Detector.shutdown()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.gpu
+def test_ranks_that_time_gpu_work_differently_agree_on_one_mode_at_their_first_report():
+    """VERDICT r4 weak 1(c): one rank on region stamps (here: ``NVRX_GPU_TIMING=stamp`` in ITS environment, the stand-in for
+    "its HIP runtime was up before the import"), the other on per-kernel keys -- no key in common, every relative GPU score
+    NaN, not a word.  Now the ranks MIN-reduce their mode at the first collective report: the per-kernel rank swaps its
+    profiler for the region one (the tracer's sink comes off the rings), both log it, and from the next window on the
+    relative GPU scores are finite and see the 25 % slower rank."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ)
+        env.pop("NVRX_GPU_TIMING", None)
+        env.update({"RANK": str(rank), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "NVRX_TEST_INIT": f"tcp://127.0.0.1:{port}",
+                    "NVRX_TEST_CYCLES": "4.0e6", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        if rank == 1:
+            env["NVRX_GPU_TIMING"] = "stamp"
+        procs.append(subprocess.Popen([sys.executable, "-c", f"REPO = {REPO!r}\n" + AGREE_SCRIPT], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=env))
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=200)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, so[-2000:] + "\n" + se[-3000:]
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]))
+    r0, r1 = outs
+    print("[ktrace agree]", r0["mode_before"], "->", r0["mode_after"], r0["reports"][-1])
+    assert (r0["mode_before"], r1["mode_before"]) == ("kernels", "stamp")
+    assert r0["mode_after"] == r1["mode_after"] == "stamp" and "another rank" in r0["note"]
+    assert any("measured per kernel" in m for m in r0["log"]) and any("measured per profiled region" in m for m in r1["log"])
+    assert sum("all ranks time GPU work per profiled region" in m for m in r0["log"]) == 1
+    assert any("they fall back to region timing as well" in m for m in r1["log"])
+    import math
+
+    last = r0["reports"][-1]
+    assert last["keys"] == ["hipevent::train_step"]
+    assert all(math.isfinite(v) for v in last["gpu_rel"].values()), last
+    assert abs(last["gpu_rel"]["0"] - 1.0) < 0.03 and abs(last["gpu_rel"]["1"] - 0.8) < 0.04, last
