@@ -374,7 +374,7 @@ def _per_kernel_leg(reports: int = 12):
             ktrace.KernelTraceProfiler._live = None
     out["workload"] = ("K kernel keys x 100 durations per report, fed as dispatch records through the tracer's native path by a "
                        "feeder thread (the SDK callback thread's part: key cache -> sink -> staged ring appends, a scatter launch "
-                       "per 128 samples here); ingest_us = what the TRAINING thread does at report time (harvest = "
+                       "per 4096 samples); ingest_us = what the TRAINING thread does at report time (harvest = "
                        "nvrx_ktrace_sync), report_us = one report over the K kernel rows with its GPU score read; round 4: "
                        "K256 85.7 + 30.1 us, K4096 1310 + 196 us with the ingest on the training thread in Python")
     return out

@@ -1972,6 +1972,12 @@ struct nvrx_ctx {
     StageBuf buf[NBUF];
     int cur = 0;
     int n_staged = 0;
+    // One scatter launch has no order inside it, so two staged samples must never aim at the same (row, slot): a row
+    // may hold at most ring_cap samples of the current staging buffer.  Counted per row, valid for the flush generation
+    // it was written in (nothing is cleared at a flush) -- so the buffer is 4096 deep whatever the ring capacity, and a
+    // tracer that feeds thousands of short rings launches one scatter per 4096 samples, not one per ring_cap.
+    std::vector<uint32_t> stage_cnt, stage_gen;
+    uint32_t flush_gen = 1;
 
     hipStream_t default_stream = nullptr;
 
@@ -2229,16 +2235,24 @@ int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, in
     ctx->meta_dirty = false;
     ctx->counts_dirty = false;
     ctx->n_staged = 0;
+    ctx->flush_gen++;
     ctx->cur = (ctx->cur + 1) % nvrx_ctx::NBUF;
     return wait_stage_buffer(ctx->buf[ctx->cur]);  // (a pusher a whole rotation ahead of the GPU waits here)
 }
 
 inline int push_locked(nvrx_ctx *ctx, int row, float value) {
-    if (ctx->n_staged == ctx->stage_cap) {
+    if (ctx->stage_gen[(size_t)row] != ctx->flush_gen) {
+        ctx->stage_gen[(size_t)row] = ctx->flush_gen;
+        ctx->stage_cnt[(size_t)row] = 0;
+    }
+    if (ctx->n_staged == ctx->stage_cap || ctx->stage_cnt[(size_t)row] >= (uint32_t)ctx->ring_cap) {
         int rc = flush_locked(ctx, ctx->default_stream);
         if (rc) return rc;
         mark_side_work(ctx);
+        ctx->stage_gen[(size_t)row] = ctx->flush_gen;
+        ctx->stage_cnt[(size_t)row] = 0;
     }
+    ctx->stage_cnt[(size_t)row]++;
     const uint32_t slot = (uint32_t)(ctx->total[row] % (uint64_t)ctx->ring_cap);
     StagedSample &e = ctx->buf[ctx->cur].h_entries[ctx->n_staged++];
     e.row_slot = ((uint32_t)row << 16) | slot;
@@ -2430,8 +2444,10 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     ctx->rows = local_ranks * rows_per_rank;
     ctx->ring_cap = ring_cap;
     ctx->row_stride = (ring_cap + 3) & ~3;
-    ctx->stage_cap = std::min(4096, ring_cap);
+    ctx->stage_cap = 4096;
     ctx->total.assign((size_t)ctx->rows, 0);
+    ctx->stage_cnt.assign((size_t)ctx->rows, 0);
+    ctx->stage_gen.assign((size_t)ctx->rows, 0);
     ctx->resident_mode = resident_scorer_mode_from_env();
     ctx->poll_naps = poll_naps_from_env();
     {
@@ -2657,7 +2673,7 @@ int nvrx_ring_push_many(nvrx_ctx *ctx, int row, const float *values, int n) {
 
 // The per-kernel tracer's path into the rings (nvrx_ktrace_sink.push): n (row, value) pairs appended one by one under
 // ONE lock, staged in pinned memory like nvrx_ring_push -- nothing is launched unless a staging buffer fills up (one
-// scatter per min(4096, ring_cap) samples, on the context's stream), and what is still staged when a report comes is
+// scatter per 4096 staged samples, or as soon as ONE row has gathered ring_cap of them; on the context's stream), and what is still staged when a report comes is
 // flushed by the report.  Called on the tracer's thread, so the device is selected first.
 int nvrx_ring_push_staged(nvrx_ctx *ctx, const int32_t *rows, const float *values, int n) {
     if (!ctx || (n > 0 && (!rows || !values)) || n < 0) return fail(NVRX_ERR_INVALID, "bad arguments");
@@ -2847,6 +2863,7 @@ int nvrx_ring_set_count(nvrx_ctx *ctx, int row, int n) {
     for (int i = 0; i < ctx->n_staged; i++)
         if ((int)(e[i].row_slot >> 16) != row) e[kept++] = e[i];
     ctx->n_staged = kept;
+    ctx->stage_cnt[(size_t)row] = 0;
     ctx->total[row] = (uint64_t)n;
     ctx->counts_dirty = true;
     return NVRX_OK;
@@ -2857,6 +2874,7 @@ int nvrx_ring_set_count_all(nvrx_ctx *ctx, int n) {
     if (n < 0 || n > ctx->ring_cap) return fail(NVRX_ERR_INVALID, "count %d outside [0,%d]", n, ctx->ring_cap);
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->n_staged = 0;
+    ctx->flush_gen++;
     std::fill(ctx->total.begin(), ctx->total.end(), (uint64_t)n);
     ctx->counts_dirty = true;
     return NVRX_OK;
@@ -2880,6 +2898,7 @@ int nvrx_ring_reset(nvrx_ctx *ctx) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     // staged samples belong to the window being dropped
     ctx->n_staged = 0;
+    ctx->flush_gen++;
     std::fill(ctx->total.begin(), ctx->total.end(), 0);
     ctx->counts_dirty = true;
     return NVRX_OK;

@@ -439,6 +439,7 @@ class HipRings:
         self.ctx = ctx
         _native.check(self.lib.nvrx_ctx_set_stream(ctx, backend.stream_handle))
         self._counts_buf = np.zeros(64, dtype=np.int32)
+        self._rows_used = 0
         #: every name that ever got a ring row (rows are never recycled; a reset only empties them)
         self.section_row_names = {}
         self.kernel_row_names = {}
@@ -458,12 +459,21 @@ class HipRings:
     # ---- rows ----------------------------------------------------------------------------------
     @property
     def rows_used(self) -> int:
-        """Rows handed out so far.  The count lives in the library (``nvrx_row_alloc``): the per-kernel tracer's thread
-        takes rows for new kernel keys on its own (``ktrace_sink``)."""
-        return self.lib.nvrx_ctx_info(self.ctx, 8)
+        """Rows handed out so far, as far as the host has been TOLD: the count lives in the library (``nvrx_row_alloc``),
+        because the per-kernel tracer's thread takes rows for new kernel keys on its own (``ktrace_sink``); the host's copy
+        moves when it allocates a row itself and when the tracer's profiler learns new keys (``note_rows_used``, at
+        report time) -- a report covers the rows whose names are known, and reads no C state for it."""
+        return self._rows_used
+
+    def note_rows_used(self) -> int:
+        """Re-read the library's count (rows the tracer's thread has taken since)."""
+        self._rows_used = max(self._rows_used, self.lib.nvrx_ctx_info(self.ctx, 8))
+        return self._rows_used
 
     def alloc_row(self, kind: int = _native.KIND_SECTION) -> int:
         row = self.lib.nvrx_row_alloc(self.ctx, kind)
+        if row >= self._rows_used:
+            self._rows_used = row + 1
         if row < 0:
             if row == _native.ERR_RANGE:
                 raise RuntimeError(

@@ -502,6 +502,9 @@ class KernelTraceProfiler:
                     rings.kernel_row_names[key_name(k)] = row
                     learnt[k] = 1
                     self._rows_known += 1
+        note = getattr(rings, "note_rows_used", None)
+        if note is not None:
+            note()  # the rows the tracer's thread took for these keys now count as used (reports cover them)
         lost = int(lib.nvrx_ktrace_counter(6))
         if lost > self.keys_without_row:
             if self.keys_without_row == 0:
