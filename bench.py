@@ -477,7 +477,7 @@ def _kernels_mode_child(mode: str = "kernels"):
     steps, rounds = (10, 14) if mode == "kernels" else (10, 8)
     try:
         o1 = overhead_legs(1, steps, rounds)
-        o10 = overhead_legs(10, steps, rounds) if mode == "kernels" else o1
+        o10 = overhead_legs(10, steps, 8) if mode == "kernels" else o1
         # one report per 100 steps on top of the section: what a job at the reference's default cadence pays per step
         out["per_step_overhead_kernels"] = {
             "profiling_interval_1": o1, "profiling_interval_10": o10,
@@ -508,7 +508,7 @@ def _kernels_mode_child(mode: str = "kernels"):
 
             mgr.harvest = timed_harvest
             for i in range(reports + 2):
-                for _ in range(60):
+                for _ in range(40):
                     with Detector.detection_section("train_step", profile_cuda=True):
                         train_step()
                 torch.cuda.synchronize()
@@ -546,8 +546,8 @@ def _kernels_mode_child(mode: str = "kernels"):
 
     try:
         out["report_at_cadence_kernels"] = {
-            "synchronous": cadence(False, 5), "asynchronous": cadence(True, 5),
-            "workload": "the transformer step above in a GPU-timed section, 60 steps between reports, tens of thousands of traced dispatches per "
+            "synchronous": cadence(False, 4), "asynchronous": cadence(True, 4),
+            "workload": "the transformer step above in a GPU-timed section, 40 steps between reports, tens of thousands of traced dispatches per "
                         "window appended to their rings by the tracer's thread as they complete; each generate_report() timed alone "
                         "after the step's device synchronisation (synchronous: call -> identify_stragglers() returned)"}
     except Exception as e:  # noqa: BLE001

@@ -447,6 +447,9 @@ class HipRings:
     # ---- lifecycle -----------------------------------------------------------------------------
     def close(self) -> None:
         if self.ctx is not None:
+            from . import ktrace as _ktrace
+
+            _ktrace.detach_sink_of(self.ctx.value)  # (the kernel tracer's thread must not append to a destroyed context)
             self.lib.nvrx_ctx_destroy(self.ctx)
             self.ctx = None
 

@@ -359,6 +359,18 @@ def feed_kernel_name(kernel_id: int, name: str, own: bool = False) -> None:
     _check(load().nvrx_ktrace_feed_kernel_name(int(kernel_id), name.encode(), int(own)))
 
 
+_sink_ctx: Optional[int] = None  # address of the ring context the tracer's thread currently appends to (None: no sink)
+
+
+def detach_sink_of(ctx_address: Optional[int]) -> None:
+    """Rings that are about to be destroyed call this: if the tracer's thread is appending to THEM, it lets go first
+    (``nvrx_ktrace_set_sink(NULL)`` returns once a batch in progress is through).  No-op for any other rings."""
+    global _sink_ctx
+    if _lib is not None and ctx_address is not None and _sink_ctx == ctx_address:
+        _lib.nvrx_ktrace_set_sink(None)
+        _sink_ctx = None
+
+
 def _sync_patience_s() -> float:
     try:
         return float(os.environ.get("NVRX_KTRACE_SYNC_PATIENCE_S", "2.0"))
@@ -394,8 +406,10 @@ class KernelTraceProfiler:
         self._warned_leak = False
         # from now on the tracer's thread appends every kernel duration to these rings
         ctx, push, row_alloc = rings.ktrace_sink()
+        global _sink_ctx
         self._sink = Sink(ctx, push, row_alloc, _native.KIND_KERNEL)
         _check(self._lib.nvrx_ktrace_set_sink(ctypes.byref(self._sink)))
+        _sink_ctx = ctx
         KernelTraceProfiler._live = weakref.ref(self)
 
     # ---- lifecycle -----------------------------------------------------------------------------
@@ -427,7 +441,9 @@ class KernelTraceProfiler:
         if not self._closed:
             self._closed = True
             # the tracer's thread lets go of the rings before they are destroyed (returns once a batch in progress is through)
+            global _sink_ctx
             self._lib.nvrx_ktrace_set_sink(None)
+            _sink_ctx = None
             if self._owns_rings:
                 self._rings.close()
 

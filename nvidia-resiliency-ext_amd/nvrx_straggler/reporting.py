@@ -890,10 +890,6 @@ class ReportGenerator:
             return
         self._direct_tried = True
         be = _backend_mod.get_backend()
-        maker = getattr(be, "create_direct_exchange", None)  # a test backend may bring its own in-call exchange
-        if maker is not None:
-            self._direct = maker(self.group)
-            return
         from . import peer_exchange, rccl_direct
 
         mode = peer_exchange.exchange_mode()
@@ -904,6 +900,10 @@ class ReportGenerator:
             self.exchange_info = {"route": "torch.distributed all-gather on the job's own process group (NVRX_EXCHANGE=c10d)"}
             if self.rank == 0:
                 _LOG.info("straggler report exchange route: %s", self.exchange_info["route"])
+            return
+        maker = getattr(be, "create_direct_exchange", None)  # a test backend may bring its own in-call exchange
+        if maker is not None:
+            self._direct = maker(self.group)
             return
         index = getattr(be.device, "index", None)
         # the exchange kernel gives up a little BEFORE the host's wait for the completion word does: a peer that is

@@ -635,6 +635,16 @@ def test_ranks_agree_on_one_gpu_timing_mode_at_their_first_collective_report():
     assert not any("all ranks time GPU work" in m for m in res[1]["log"])
 
 
+def test_c10d_exchange_route_is_taken_by_every_rank_when_one_asks_for_it():
+    """``NVRX_EXCHANGE=c10d`` (the report's all-gather on the JOB's own process group, no communicator of ours) is a
+    collective decision: one rank's environment is enough to keep every rank on it."""
+    res = run_ranks(workers.detector_c10d_route, 2)
+    for r in range(2):
+        assert "NVRX_EXCHANGE=c10d" in res[r]["route"] and res[r]["direct"] is False, res[r]
+    assert res[0]["scores"][1] == {0: 1.0}                                      # (gather_on_rank0=False: each rank reports itself)
+    assert res[1]["scores"][1][1] == pytest.approx(0.5, abs=0.15), res[1]["scores"]
+
+
 def test_interval_tracker_ranks_agree():
     res = run_ranks(workers.interval_tracker_agreement, 2)
     assert res[0] == res[1] and res[0] >= 1

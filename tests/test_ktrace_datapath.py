@@ -244,3 +244,46 @@ def test_without_a_sink_the_pending_queue_keeps_the_newest(monkeypatch):
     assert n == 16 and [buf[i].us for i in range(n)] == [float(v) for v in range(25, 41)]
     assert ktrace.key_name(buf[0].key) == "queued_blk_1_1_1_grid_1_1_1"
     lib.nvrx_ktrace_set_max_pending(0)
+
+
+def test_random_launch_sequences_match_the_reference_profiler(profiler):
+    """Property check of the whole native path against the reference's own profiler: random key counts, ring capacities,
+    launches per key (from none to > 4 x cap), launch geometries and batch sizes -- the statistics per key are the
+    reference's, the newest ``cap`` durations are what the rings hold."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this box)")
+    rng = np.random.default_rng(2024)
+    for case in range(25):
+        K = int(rng.integers(1, 9))
+        cap = int(rng.integers(1, 24))
+        names = [f"_Z5case{case:02d}k{k}Pf" for k in range(K)]
+        ids = _fresh_kernel_ids(K)
+        for i, n in zip(ids.tolist(), names):
+            ktrace.feed_kernel_name(i, n)
+        counts = rng.integers(0, 4 * cap + 3, K)
+        idx = rng.permutation(np.repeat(np.arange(K), counts))
+        if idx.size == 0:
+            continue
+        dur = rng.integers(500, 9_000_000, idx.size).astype(np.uint64)
+        start = np.cumsum(dur) + np.uint64(77)
+        blocks = [(int(rng.choice([1, 32, 64, 256, 1024])), int(rng.integers(1, 3)), 1, int(rng.integers(1, 5000)), int(rng.integers(1, 4)), 1)
+                  for _ in range(K)]
+        disp = _as_dispatches(ids, idx, dur, start, blocks)
+        prof, rings = profiler(K + 1, cap)
+        lo = 0
+        while lo < disp.size:
+            n = int(rng.integers(1, 40))
+            ktrace.feed(disp[lo:lo + n])
+            lo += n
+        got = prof.get_stats()
+        exp = _reference_stats(names, idx, dur, start, blocks, cap)
+        assert set(got) == set(exp), (case, sorted(got), sorted(exp))
+        for key, (e, n) in exp.items():
+            g = got[key]
+            assert g.num_calls == n, (case, key, g.num_calls, n)
+            assert (np.float32(g.min), np.float32(g.max), np.float32(g.median)) == (e[0], e[1], e[2]), (case, key)
+            assert abs(g.avg - e[3]) <= 2e-6 * abs(e[3]) + 1e-12, (case, key)
+            assert abs(g.stddev - e[4]) <= 2e-5 * max(abs(e[4]), 1e-3 * abs(e[3])), (case, key)
+        prof.shutdown()
+        prof.close()
+        backend.set_backend(None)

@@ -1,4 +1,5 @@
 """Worker functions for the multi-process CPU tests (must be importable by spawned processes)."""
+import os
 import time
 from unittest import mock
 
@@ -671,4 +672,25 @@ def detector_mode_agreement(rank, world):
                 "log": [m for m in records if "nvrx straggler" in m]}
     finally:
         ktrace._reset_mode_for_tests()
+        Detector.shutdown()
+
+
+def detector_c10d_route(rank, world):
+    """``NVRX_EXCHANGE=c10d`` in ONE rank's environment: every rank keeps the report's exchange on torch.distributed."""
+    if rank == 1:
+        os.environ["NVRX_EXCHANGE"] = "c10d"
+    from nvrx_straggler import Detector
+
+    Detector.initialize(scores_to_compute=["relative_perf_scores"], gather_on_rank0=False, node_name=f"host{rank}")
+    try:
+        out = []
+        for _ in range(2):
+            for _ in range(6):
+                with Detector.detection_section("s", profile_cuda=False):
+                    time.sleep(0.002 if rank == 0 else 0.004)
+            rep = Detector.generate_report()
+            out.append({r: round(v, 2) for r, v in rep.section_relative_perf_scores["s"].items()})
+        return {"route": Detector.reporter.exchange_info.get("route", ""), "direct": Detector.reporter._direct is not None, "scores": out}
+    finally:
+        os.environ.pop("NVRX_EXCHANGE", None)
         Detector.shutdown()

@@ -6,7 +6,7 @@ TAG=${1:-measure}
 O=gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.log 2>&1; tail -1 $O/bench_driver.log > $O/bench_driver.json; cat $O/bench_driver.json
+T0=$(date +%s); timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.log 2>&1; echo "bench wall $(( $(date +%s) - T0 )) s" | tee $O/bench_wall.txt; tail -1 $O/bench_driver.log > $O/bench_driver.json; cut -c1-600 $O/bench_driver.json
 P="python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-overhead --no-host-inputs --no-cadence"
 echo "$P" > $O/command.txt
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $P > $O/prof_stats.log 2>&1; echo "stats rc=$?"
