@@ -22,7 +22,7 @@ export UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 cd "$REPO"
 if [ $# -eq 0 ]; then
-  set -- tests/test_host_logic.py -k "abi or symbol or exports or header or ktrace or kernel_trace or never_imports or c_dict_builders or c_flag_decoder or flag_memo or inplace_filled or recycled or beyond_their_stack or non_finite or tool_search_guard or gpu_timing_mode" -m "not gpu"
+  set -- tests/test_host_logic.py tests/test_ktrace_datapath.py -k "datapath or per_key or key_format or engine_kernels or harvest_waits or pending_queue or random_launch or abi or symbol or exports or header or ktrace or kernel_trace or never_imports or c_dict_builders or c_flag_decoder or flag_memo or inplace_filled or recycled or beyond_their_stack or non_finite or tool_search_guard or gpu_timing_mode" -m "not gpu"
 fi
 LD_PRELOAD="$RT" PYTHONPATH="$REPO/nvidia-resiliency-ext_amd" python -c "from nvrx_straggler import _native, ktrace; assert 'lib_$SAN' in _native.lib_path() and 'lib_$SAN' in ktrace.lib_path(); print('sanitized libraries:', _native.lib_path())"
 if [ "$SAN" = asan ]; then
