@@ -140,7 +140,6 @@ struct State {
     std::mutex pump_mu;
     std::condition_variable pump_cv;
     bool pump_kick = false;
-    std::atomic<int> pump_idle{1};
     std::once_flag pump_once;
     bool pump_enabled = true;
 };
@@ -223,7 +222,10 @@ int other_threads_awake() {
         buf[n] = 0;
         const char *p = strrchr(buf, ')');  // "pid (comm) S ..." -- comm may hold anything, the state follows the LAST ')'
         const char state = (p && p[1] == ' ') ? p[2] : '?';
-        if (!(state == 'S' || state == 'D' || state == 'I' || state == 'Z' || state == 'X' || state == 'T' || state == 't')) awake++;
+        // asleep: interruptible sleep (a parked pool worker on its futex), idle kernel thread, stopped, dead.  RUNNING and
+        // UNINTERRUPTIBLE sleep ('D': disk / network I/O -- what a thread inside dlopen looks like while the library is read)
+        // count as awake.
+        if (!(state == 'S' || state == 'I' || state == 'Z' || state == 'X' || state == 'T' || state == 't')) awake++;
     }
     closedir(dir);
     return awake;
@@ -495,10 +497,8 @@ void pump_main() {
     State &s = st();
     std::unique_lock<std::mutex> lk(s.pump_mu);
     for (;;) {
-        s.pump_idle.store(1, std::memory_order_release);
         s.pump_cv.wait(lk, [&] { return s.pump_kick; });
         s.pump_kick = false;
-        s.pump_idle.store(0, std::memory_order_release);
         lk.unlock();
         int pause_us = 100;
         const auto give_up = std::chrono::steady_clock::now() + std::chrono::seconds(5);
@@ -516,8 +516,9 @@ void pump_main() {
 void kick_pump(State &s) {
     if (!s.pump_enabled || !s.counting.load(std::memory_order_acquire)) return;
     std::call_once(s.pump_once, [] { std::thread(pump_main).detach(); });
-    if (!s.pump_idle.load(std::memory_order_acquire)) return;  // already flushing: it re-reads the counters every round
     {
+        // (always: a pump that is just leaving its loop would otherwise miss this window; the lock is held for two stores
+        //  and a notify without a waiter is a no-op)
         std::lock_guard<std::mutex> lk(s.pump_mu);
         s.pump_kick = true;
     }

@@ -30,7 +30,7 @@ import os
 import threading
 import warnings
 import weakref
-from ctypes import CFUNCTYPE, POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_uint32, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_uint32, c_uint64, c_void_p
 from typing import Dict, Optional
 
 import numpy as np

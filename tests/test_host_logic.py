@@ -1451,7 +1451,7 @@ def test_stream_priority_default_is_high_for_a_single_process_and_normal_for_a_m
     assert prio({"NVRX_STREAM_PRIORITY": "off"})[0] == 0
 
 
-def test_children_of_a_process_that_registered_the_tracer_can_register_theirs():
+def test_children_of_a_process_that_registered_the_tracer_can_register_theirs(tmp_path):
     """``rocprofiler_force_configure`` leaves ``ROCPROFILER_REGISTER_FORCE_LOAD=1`` in the process environment.  A child
     that inherits it (a spawned rank, a DataLoader worker) loads and CONFIGURES rocprofiler-sdk the moment libamdhip64 is
     loaded -- the full tool search on ``import torch``, and "already configured" for its own tracer: on the MI355X box
@@ -1460,30 +1460,30 @@ def test_children_of_a_process_that_registered_the_tracer_can_register_theirs():
     import subprocess
     import sys
 
-    script = r'''
+    script = tmp_path / "register.py"
+    script.write_text(f"REPO = {REPO!r}\n" + r"""
 import ctypes, os, subprocess, sys
 sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO]
 os.environ["NVRX_GPU_TIMING"] = "kernels"
 from nvrx_straggler import ktrace
-libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p
-err = None
+libc = ctypes.CDLL(None)
+libc.getenv.restype = ctypes.c_char_p
+role, err = sys.argv[1], None
 try:
-    ktrace.timing_mode(); ktrace.setup()
+    ktrace.timing_mode()
+    ktrace.setup()
 except Exception as e:
     err = str(e)
-print("STATE", sys.argv[-1], err, ktrace._setup_route, libc.getenv(b"ROCPROFILER_REGISTER_FORCE_LOAD"))
-if sys.argv[-1] == "parent":
+print("STATE", role, err, ktrace._setup_route, libc.getenv(b"ROCPROFILER_REGISTER_FORCE_LOAD"))
+if role == "parent":
     ktrace.release_env()
     print("AFTER", libc.getenv(b"ROCPROFILER_REGISTER_FORCE_LOAD"), libc.getenv(b"GLOG_v"))
-    r = subprocess.run([sys.executable, "-c", "REPO = %r\n" % REPO + open(__file__).read() if False else SRC, "child"], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, __file__, "child"], capture_output=True, text=True)   # inherits the C environment
     print(r.stdout, r.stderr[-500:])
-'''
-    src = f"REPO = {REPO!r}\n" + script
-    src = src.replace('"REPO = %r\\n" % REPO + open(__file__).read() if False else SRC', "SRC")
-    src = f"SRC = {src!r}\n" + src
+""")
     env = {k: v for k, v in os.environ.items() if k not in ("NVRX_GPU_TIMING", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCP_TOOL_LIBRARIES")
            and not k.startswith("GLOG_")}
-    p = subprocess.run([sys.executable, "-c", src, "parent"], capture_output=True, text=True, timeout=300, env=env)
+    p = subprocess.run([sys.executable, str(script), "parent"], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stdout + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith(("STATE", "AFTER"))]
     assert lines[0] == "STATE parent None force_configure b'1'", lines       # the SDK wrote it ...

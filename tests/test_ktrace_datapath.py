@@ -11,7 +11,6 @@ What is pinned (reference: cupti_src/CuptiProfiler.cpp:168-207, CircularBuffer.h
   * duration = (end - start) / 1000.0f in f32;
   * the training thread does nothing per record: ``harvest()`` is a counter comparison.
 """
-import os
 import threading
 
 import numpy as np
