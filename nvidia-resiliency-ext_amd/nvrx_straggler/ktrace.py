@@ -141,6 +141,14 @@ def release_env() -> None:
     for name in _GLOG_NAMES:
         if name not in os.environ:  # (os.environ is the environment this interpreter STARTED with, plus the job's own changes)
             libc.unsetenv(name.encode())
+    if _added_to_tool_libraries:
+        # the SDK's own route (taken when the link-map guard refused): the library has been loaded by now; a child that
+        # inherited the variable would run the SDK's full tool search at ITS first HIP call whether it traces or not
+        libs = [p for p in os.environ.get("ROCP_TOOL_LIBRARIES", "").split(":") if p and p != _LIB_PATH]
+        if libs:
+            os.environ["ROCP_TOOL_LIBRARIES"] = ":".join(libs)
+        else:
+            os.environ.pop("ROCP_TOOL_LIBRARIES", None)
 
 
 def _check(rc: int) -> int:
@@ -156,12 +164,17 @@ def counters() -> Dict[str, int]:
     return {name: int(lib.nvrx_ktrace_counter(i)) for i, name in enumerate(COUNTERS)}
 
 
+_added_to_tool_libraries = False
+
+
 def _name_in_tool_libraries() -> None:
+    global _added_to_tool_libraries
     libs = [p for p in os.environ.get("ROCP_TOOL_LIBRARIES", "").split(":") if p]
     if _LIB_PATH not in libs:
         if not os.path.exists(_LIB_PATH):
             raise RuntimeError(f"{_LIB_NAME} not found at {_LIB_PATH}; build it with `make -C nvidia-resiliency-ext_amd/csrc`")
         os.environ["ROCP_TOOL_LIBRARIES"] = ":".join(libs + [_LIB_PATH])
+        _added_to_tool_libraries = True
 
 
 def setup(max_pending: int = 0) -> None:
@@ -371,6 +384,34 @@ def detach_sink_of(ctx_address: Optional[int]) -> None:
         _sink_ctx = None
 
 
+_exit_hook_registered = False
+
+
+def _register_exit_hook() -> None:
+    """At interpreter exit (before the HIP runtime is torn down): stop tracing and take the sink off the rings, so that the
+    SDK's thread does not append a late record to a context that is going away."""
+    global _exit_hook_registered
+    if _exit_hook_registered:
+        return
+    _exit_hook_registered = True
+    import atexit
+
+    def _quiesce():
+        global _sink_ctx
+        lib = _lib
+        if lib is None:
+            return
+        try:
+            if lib.nvrx_ktrace_ready():
+                lib.nvrx_ktrace_stop()
+            lib.nvrx_ktrace_set_sink(None)
+            _sink_ctx = None
+        except Exception:  # noqa: BLE001
+            pass
+
+    atexit.register(_quiesce)
+
+
 def _sync_patience_s() -> float:
     try:
         return float(os.environ.get("NVRX_KTRACE_SYNC_PATIENCE_S", "2.0"))
@@ -410,6 +451,7 @@ class KernelTraceProfiler:
         self._sink = Sink(ctx, push, row_alloc, _native.KIND_KERNEL)
         _check(self._lib.nvrx_ktrace_set_sink(ctypes.byref(self._sink)))
         _sink_ctx = ctx
+        _register_exit_hook()
         KernelTraceProfiler._live = weakref.ref(self)
 
     # ---- lifecycle -----------------------------------------------------------------------------

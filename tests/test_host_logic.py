@@ -1489,3 +1489,42 @@ if role == "parent":
     assert lines[0] == "STATE parent None force_configure b'1'", lines       # the SDK wrote it ...
     assert lines[1] == "AFTER None None", lines                              # ... release_env took it (and the GLOG switches) back
     assert lines[2].startswith("STATE child None force_configure"), lines    # the child registers its own tracer
+
+
+def test_tool_search_guard_is_refused_while_another_thread_runs_and_the_sdks_own_route_is_taken(tmp_path):
+    """The link-map guard of ``nvrx_ktrace_setup`` touches loader state, so the library applies it only while every OTHER
+    thread of the process is asleep.  With a busy thread: ``NVRX_KTRACE_ERR_UNSAFE`` (-16), nothing registered, and
+    ``ktrace.setup`` falls back to naming the library in ``ROCP_TOOL_LIBRARIES`` (the SDK's own, slower route) -- and
+    ``release_env`` takes that variable back again once the runtime is up."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "busy.py"
+    script.write_text(f"REPO = {REPO!r}\n" + r"""
+import os, sys, threading, time
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO]
+os.environ["NVRX_GPU_TIMING"] = "kernels"
+os.environ["NVRX_KTRACE_AT_IMPORT"] = "0"
+stop = []
+def spin():
+    while not stop:
+        pass
+t = threading.Thread(target=spin, daemon=True)
+from nvrx_straggler import ktrace           # (imports torch: before the busy thread starts, or the import crawls)
+lib = ktrace.load()
+t.start(); time.sleep(0.05)
+rc = lib.nvrx_ktrace_setup(0)
+print("RC", rc, lib.nvrx_ktrace_last_error().decode()[:60], lib.nvrx_ktrace_hidden_libraries())
+ktrace.setup()
+print("ROUTE", ktrace._setup_route, ktrace.lib_path() in os.environ.get("ROCP_TOOL_LIBRARIES", ""))
+ktrace.release_env()
+print("AFTER", os.environ.get("ROCP_TOOL_LIBRARIES"))
+stop.append(1)
+""")
+    env = {k: v for k, v in os.environ.items() if k not in ("NVRX_GPU_TIMING", "ROCP_TOOL_LIBRARIES", "NVRX_KTRACE_SCAN_GUARD")}
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr[-2000:]
+    out = dict(l.split(" ", 1) for l in p.stdout.splitlines() if l.startswith(("RC", "ROUTE", "AFTER")))
+    assert out["RC"].startswith("-16 ") and "other thread" in out["RC"] and out["RC"].endswith(" 0"), out
+    assert out["ROUTE"] == "ROCP_TOOL_LIBRARIES True", out
+    assert out["AFTER"] == "None", out
