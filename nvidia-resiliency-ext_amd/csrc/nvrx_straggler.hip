@@ -2883,12 +2883,14 @@ int nvrx_ring_set_count_all(nvrx_ctx *ctx, int n) {
 int nvrx_ring_count(const nvrx_ctx *ctx, int row) {
     if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
     if (row < 0 || row >= ctx->rows) return fail(NVRX_ERR_INVALID, "row %d out of range [0,%d)", row, ctx->rows);
+    std::lock_guard<std::mutex> lk(const_cast<nvrx_ctx *>(ctx)->mu);  // (the kernel tracer's thread appends concurrently)
     return (int)std::min<uint64_t>(ctx->total[(size_t)row], (uint64_t)ctx->ring_cap);
 }
 
 int nvrx_ring_counts(const nvrx_ctx *ctx, int32_t *out, int n) {
     if (!ctx || !out) return fail(NVRX_ERR_INVALID, "null argument");
     if (n < 0 || n > ctx->rows) return fail(NVRX_ERR_INVALID, "n %d outside [0,%d]", n, ctx->rows);
+    std::lock_guard<std::mutex> lk(const_cast<nvrx_ctx *>(ctx)->mu);  // (the kernel tracer's thread appends concurrently)
     for (int r = 0; r < n; r++) out[r] = (int32_t)std::min<uint64_t>(ctx->total[(size_t)r], (uint64_t)ctx->ring_cap);
     return NVRX_OK;
 }
