@@ -15,6 +15,8 @@ timeout -s KILL 1800 python -m pytest tests -m gpu -x -q --durations=10 > $O/pyt
 timeout 1700 bash tools/run_reference_tests_gpu.sh $O; echo "reference suite rc=$?"
 grep -h "^FAILED\|^ERROR" $O/reference_suite_kernels.log $O/reference_suite_stamp.log | cut -c1-160
 bash tools/run_gpu_measure.sh $TAG 2>&1 | tail -n 12 | cut -c1-3000
+# the N > 1 flow on this ONE GPU (two ranks over gloo share it): not a scaling point, it shows the exchange fields of the line
+timeout 600 python bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 --no-cpu-baseline --no-overhead --no-host-inputs --no-extra-legs --no-cadence 2>/dev/null | tail -n 1 > $O/bench_gloo_shared_gpu_n2.json; cut -c1-300 $O/bench_gloo_shared_gpu_n2.json
 for cnt in 1 0; do
   NVRX_GPU_TIMING=kernels NVRX_KTRACE_COUNT=$cnt timeout 300 python tools/ktrace_attached_cost.py 2>&1 | tail -n 1 > $O/attached_cost_count$cnt.txt; cat $O/attached_cost_count$cnt.txt
 done
