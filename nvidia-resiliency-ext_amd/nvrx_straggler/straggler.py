@@ -12,10 +12,13 @@ What changed underneath:
 * a section's elapsed times are appended to a DEVICE ring (pinned staging + one scatter kernel per
   flush) instead of a Python deque, so a report never converts thousands of Python floats into a
   tensor (the reference's dominant cost, straggler.py:185);
-* ``profile_cuda=True`` brackets the section with a hipEvent pair on the current stream (GPU time of
-  the region, microseconds) instead of enabling CUPTI kernel tracing;
-* ``generate_report`` waits only for the recorded event pairs (not ``torch.cuda.synchronize()``),
-  then runs statistics -> all-gather -> scoring on the detector's own HIP stream.
+* ``profile_cuda=True`` measures GPU time in one of two ways (``ktrace.timing_mode``): per KERNEL, by kernel name,
+  through rocprofiler-sdk -- the reference's CUPTI data model, the default of multi-rank jobs, fed into the device rings
+  by the tracer's own thread -- or per REGION, with two device-timestamp kernels around the section on the current stream
+  (single-process default).  The ranks of a job agree on one of the two at their first collective report;
+* ``generate_report`` waits only for what it needs -- the traced kernels of the window (``nvrx_ktrace_sync``) or the
+  region stamps -- not ``torch.cuda.synchronize()``, then runs statistics -> all-gather -> scoring on the detector's own
+  HIP stream; ``asynchronous=True`` does not even wait for that.
 """
 from __future__ import annotations
 
