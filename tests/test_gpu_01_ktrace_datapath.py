@@ -234,3 +234,77 @@ def test_asynchronous_reports_in_per_kernel_mode_do_not_wait_and_lose_nothing():
     assert nums[0] < 12 and nums[1] < 24, nums         # ... no report waited for its window's kernels
     assert out["waits"][1] < out["sync_s"] / 4, out    # (the sleeps still queued at the second report took sync_s to drain)
     assert out["counters"]["enqueued"] == out["counters"]["arrived"] + out["counters"]["forgiven"]
+
+
+SOAK_SCRIPT = r'''
+import faulthandler, json, os, sys, threading, time
+faulthandler.enable()
+faulthandler.dump_traceback_later(170, exit=True)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+os.environ["NVRX_GPU_TIMING"] = "kernels"
+import torch
+import nvrx_straggler
+from nvrx_straggler import Detector, Statistic, ktrace
+from nvrx_straggler.straggler import CustomSection
+
+CustomSection.max_elapseds_len = 64          # small rings: the tracer's thread flushes often (a scatter launch from ITS thread)
+torch.cuda.set_device(0)
+xs = [torch.randn(64 * (i + 1), 64, device="cuda") for i in range(6)]   # six shapes: a few dozen kernel keys
+side = torch.cuda.Stream()
+Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n0", asynchronous=(os.environ["SOAK_ASYNC"] == "1"))
+t_end = time.time() + float(os.environ["SOAK_SECONDS"])
+reports = nums = windows = 0
+launched = 0
+stop = []
+def other_thread():                           # launches of a second thread land in whatever section is open: counted and traced alike
+    y = torch.randn(4096, device="cuda")
+    while not stop:
+        torch.tanh(y)
+        time.sleep(0.0005)
+th = threading.Thread(target=other_thread, daemon=True)
+th.start()
+i = 0
+while time.time() < t_end:
+    with Detector.detection_section("a", profile_cuda=True):
+        for x in xs[: 1 + i % 6]:
+            (x @ x.t()).relu_()
+        with torch.cuda.stream(side):        # a second stream inside the section
+            torch.sigmoid(xs[0])
+    with Detector.detection_section("b", profile_cuda=(i % 3 == 0)):
+        xs[i % 6].mul_(1.0001)
+    i += 1
+    if i % 37 == 0:
+        rep = Detector.generate_report()
+        reports += 1
+        ks = rep.local_kernel_summaries
+        nums += sum(int(v[Statistic.NUM]) for v in ks.values())
+        assert all(v[Statistic.MIN] <= v[Statistic.MED] <= v[Statistic.MAX] for v in ks.values())
+        assert rep.local_section_summaries["a"][Statistic.NUM] >= 1
+stop.append(1); th.join()
+torch.cuda.synchronize()
+ktrace.load().nvrx_ktrace_sync(5.0)
+last = Detector.generate_report()
+nums += sum(int(v[Statistic.NUM]) for v in last.local_kernel_summaries.values())
+c = ktrace.counters()
+keys = len(Detector.rings.kernel_row_names)
+Detector.shutdown()
+print("RESULT " + json.dumps({"entries": i, "reports": reports, "kernel_samples_reported": nums, "keys": keys, "counters": c}))
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("asynchronous", [False, True])
+def test_tracer_soak_threads_streams_small_rings(asynchronous):
+    """A few seconds of everything at once in per-kernel mode: 64-deep rings (the tracer's thread launches a scatter every few
+    dozen records), six launch geometries, a second stream and a second launching thread inside the sections, a report
+    every 37 entries, synchronous and asynchronous.  Nothing may be lost on the way (every counted dispatch arrives, the
+    sink never fails, no row runs out) and the process must come down cleanly."""
+    out = _run(SOAK_SCRIPT, {"SOAK_SECONDS": "4", "SOAK_ASYNC": "1" if asynchronous else "0"})
+    c = out["counters"]
+    print("[ktrace soak]", "async" if asynchronous else "sync", {k: out[k] for k in ("entries", "reports", "kernel_samples_reported", "keys")},
+          {k: c[k] for k in ("enqueued", "arrived", "delivered", "own_skipped", "forgiven", "pump_flushes")})
+    assert out["entries"] > 200 and out["reports"] >= 5 and out["keys"] >= 8
+    assert c["enqueued"] == c["arrived"] + c["forgiven"] and c["forgiven"] == 0, c
+    assert c["sink_errors"] == 0 and c["lost_no_row"] == 0 and c["keys_without_row"] == 0, c
+    assert c["delivered"] + c["own_skipped"] == c["arrived"], c        # (no record with a zero timestamp on this path)
+    assert 0 < out["kernel_samples_reported"] <= c["delivered"]         # (rings are 64 deep: windows with more launches keep the newest)
