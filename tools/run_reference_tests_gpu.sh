@@ -24,4 +24,20 @@ for mode in kernels stamp; do
     python -m pytest -p no:cacheprovider -p nvrx_reftest_plugin -rA -q --timeout=600 unit >> "$log" 2>&1 || rc=1
   tail -n 3 "$log"
 done
+# The reference's FUNCTIONAL run (tests/straggler/func/ddp_test.py, unmodified): a DDP model on an NCCL (= RCCL) process
+# group, Detector.wrap_callables on its forward, a report every 400 iterations, judged by the reference's own
+# check_log.py.  One rank here (the box has one GPU; the script hard-codes backend='nccl', and RCCL refuses two ranks on
+# one device): it exercises the real RCCL group, DDP's collectives next to the sections and the whole report path, not the
+# cross-GPU exchange.
+if [ -f "$T/func/ddp_test.py" ] && ( cd "$T" && sha256sum -c SHA256SUMS.func >/dev/null ); then
+  for mode in kernels stamp; do
+    log="$OUT/reference_func_ddp_$mode.log"
+    NVRX_GPU_TIMING=$mode timeout 600 python -m torch.distributed.run --standalone --nnodes=1 --nproc-per-node=1 --local-addr 127.0.0.1 \
+      func/ddp_test.py --iters 1500 --report_iter_interval 400 --max_runtime 200 > "$log" 2>&1 || rc=1
+    for check in "num_reports --min 3 --max 3" "relative_gpu_stragglers" "individual_gpu_stragglers"; do
+      python func/check_log.py --log "$log" $check >> "$log.checks" 2>&1 && echo "func ddp_test [$mode] check_log $check: ok" || { echo "func ddp_test [$mode] check_log $check: FAILED"; rc=1; }
+    done
+    grep -c "STRAGGLER REPORT" "$log" | sed "s/^/func ddp_test [$mode] reports: /"
+  done
+fi
 exit $rc

@@ -10,6 +10,8 @@ DST="$REPO/oracle/_ref/reference/tests/straggler"
 rm -rf "$DST"
 mkdir -p "$DST"
 cp -r "$SRC/unit" "$DST/unit"
+cp -r "$SRC/func" "$DST/func"     # the functional DDP run (ddp_test.py + check_log.py)
 find "$DST" -name __pycache__ -type d -prune -exec rm -rf {} +
 ( cd "$SRC/unit" && sha256sum *.py ) > "$DST/SHA256SUMS"
-echo "staged $(ls "$DST/unit"/test_*.py | wc -l) reference test modules under $DST"
+( cd "$SRC" && sha256sum func/*.py ) > "$DST/SHA256SUMS.func"
+echo "staged $(ls "$DST/unit"/test_*.py | wc -l) reference test modules + func/ under $DST"
