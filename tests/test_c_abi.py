@@ -34,3 +34,35 @@ def test_a_plain_c_host_runs_one_report_through_the_abi_and_matches_the_oracle()
     p = subprocess.run([HOST], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
     assert "ABI HOST OK" in p.stdout
+
+
+KHOST = os.path.join(REPO, "tests", "c_abi", "_build", "ktrace_host")
+
+
+def _need_ktrace_host(target="all", path=KHOST):
+    if not os.path.exists(path):
+        p = subprocess.run(["make", "-C", os.path.join(REPO, "tests", "c_abi"), target], capture_output=True, text=True)
+        if p.returncode != 0 or not os.path.exists(path):
+            pytest.skip(f"{path} is not built and could not be built here: " + (p.stderr or p.stdout)[-300:])
+
+
+def test_a_plain_c_host_with_threads_drives_the_kernel_tracer_abi():
+    """``tests/c_abi/ktrace_host.c`` (C11 + pthreads, only ``include/nvrx_ktrace.h``): two feeder threads play the
+    rocprofiler-sdk callback thread, a sink of two C callbacks plays the engine's rings, the main thread plays the training
+    thread (looks, holds, waits).  60 000 records: every key's ring ends with exactly the newest 16 durations in order, the
+    counters add up, nothing is lost.  No GPU, no Python in the loop."""
+    _need_ktrace_host()
+    p = subprocess.run([KHOST], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "KTRACE HOST OK" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+def test_the_kernel_tracer_is_clean_under_thread_sanitizer():
+    """The same host and the same library source built with ``-fsanitize=thread`` (``make -C tests/c_abi tsan``): the mutex
+    discipline of ``nvrx_ktrace.cpp`` -- feeders, sink, holds, counters, key tables read from another thread -- checked by
+    ThreadSanitizer instead of by reading."""
+    host = os.path.join(REPO, "tests", "c_abi", "_build", "tsan", "ktrace_host")
+    _need_ktrace_host("tsan", host)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    for _ in range(3):
+        p = subprocess.run([host], capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0 and "KTRACE HOST OK" in p.stdout and "ThreadSanitizer" not in p.stderr, p.stdout[-800:] + p.stderr[-3000:]
