@@ -65,4 +65,6 @@ def test_the_kernel_tracer_is_clean_under_thread_sanitizer():
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
     for _ in range(3):
         p = subprocess.run([host], capture_output=True, text=True, timeout=300, env=env)
+        if "unexpected memory mapping" in p.stderr:  # (the TSan runtime cannot lay out its shadow under this kernel's ASLR settings)
+            pytest.skip("ThreadSanitizer cannot start on this host: " + p.stderr.strip()[-200:])
         assert p.returncode == 0 and "KTRACE HOST OK" in p.stdout and "ThreadSanitizer" not in p.stderr, p.stdout[-800:] + p.stderr[-3000:]
