@@ -1,5 +1,10 @@
 #!/bin/bash
-# same-box A/B of the cold report path: round-4 head (oracle/_ref/r04tree) against this tree, alternating
+# same-box A/B of the cold report path: round-4 head (oracle/_ref/r04tree) against this tree, alternating.
+# The round-4 tree is not kept: build it where git is available, then run this through gpurun --
+#   mkdir /tmp/r04tree && git archive 28aa94f | tar -x -C /tmp/r04tree && make -C /tmp/r04tree/nvidia-resiliency-ext_amd/csrc
+#   mkdir -p oracle/_ref/r04tree/profiles && cp -r /tmp/r04tree/{bench.py,nvidia-resiliency-ext_amd,tests} oracle/_ref/r04tree/ \
+#     && cp /tmp/r04tree/profiles/pmc_row_stats.json oracle/_ref/r04tree/profiles/
+# (oracle/_ref/ is git-ignored and travels with gpurun).  Result: profiles/r05_ab_r04_r05.txt
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=$PWD/gpurun_out/r05ab; mkdir -p $O
