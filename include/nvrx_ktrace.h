@@ -47,8 +47,8 @@ typedef struct nvrx_ktrace_record {
 } nvrx_ktrace_record;
 
 /* Where the durations go.  push(ctx, rows, values, n) appends values[i] to ring row rows[i] for all i, in order,
- * overwrite-oldest (nvrx_ring_push_staged of nvrx_straggler.h has this signature); row_alloc(ctx, kind) hands out the
- * ring row of a key seen for the first time, negative when none is left (nvrx_row_alloc).  Both are called on the
+ * overwrite-oldest (nvrx_sink_push of nvrx_straggler.h: nvrx_ring_push_staged with this exact type); row_alloc(ctx, kind) hands
+ * out the ring row of a key seen for the first time, negative when none is left (nvrx_sink_row_alloc: nvrx_row_alloc).  Both are called on the
  * SDK's callback thread, never on the thread that launches kernels. */
 typedef struct nvrx_ktrace_sink {
     void *ctx;

@@ -158,6 +158,10 @@ int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values
  * appends every kernel record to its key's ring as the records arrive, the way the reference does on CUPTI's thread
  * (CuptiProfiler.cpp:168-207) -- the newest ring_cap durations per key survive (CircularBuffer.h:53-61). */
 int nvrx_ring_push_staged(nvrx_ctx *ctx, const int32_t *rows, const float *values, int n);
+/* nvrx_ring_push_staged / nvrx_row_alloc with the exact C types of nvrx_ktrace_sink's two function pointers (`void *ctx`):
+ * these are the addresses to put into a sink. */
+int nvrx_sink_push(void *ctx, const int32_t *rows, const float *values, int n);
+int nvrx_sink_row_alloc(void *ctx, int kind);
 /* Append n samples that already live in device memory (device-to-device, wraps as needed). */
 int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, void *stream);
 /* The same for n_rows consecutive rows at once: row first_row + r gets the n samples at d_values + r * ld (ld >= n).  Rows

@@ -2691,6 +2691,15 @@ int nvrx_ring_push_staged(nvrx_ctx *ctx, const int32_t *rows, const float *value
     return NVRX_OK;
 }
 
+// The two functions a kernel tracer's sink (nvrx_ktrace_sink, include/nvrx_ktrace.h) is given: nvrx_ring_push_staged and
+// nvrx_row_alloc with the sink's EXACT C types (a `void *` context) -- calling a function through a pointer of another
+// function type is undefined behaviour even where the ABI is the same, and UBSan's function check says so.
+int nvrx_sink_push(void *ctx, const int32_t *rows, const float *values, int n) {
+    return nvrx_ring_push_staged(static_cast<nvrx_ctx *>(ctx), rows, values, n);
+}
+
+int nvrx_sink_row_alloc(void *ctx, int kind) { return nvrx_row_alloc(static_cast<nvrx_ctx *>(ctx), kind); }
+
 // Bulk append of (row, value) pairs in arrival order: ONE scatter launch however many rows the pairs touch.  This is how
 // the per-kernel tracer's drained records reach the rings (hundreds to thousands of kernel keys per report,
 // CuptiProfiler.cpp:186-207 appends the same records to one CircularBuffer per key on the host).  Ring semantics are

@@ -61,6 +61,8 @@ SYMBOLS = [
     ("nvrx_ring_push_many", c_int, [c_void_p, c_int, c_void_p, c_int]),
     ("nvrx_ring_push_pairs", c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     ("nvrx_ring_push_staged", c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    ("nvrx_sink_push", c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    ("nvrx_sink_row_alloc", c_int, [c_void_p, c_int]),
     ("nvrx_ring_push_device", c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     ("nvrx_ring_push_device_rows", c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     ("nvrx_ring_set_count", c_int, [c_void_p, c_int, c_int]),

@@ -499,8 +499,8 @@ class HipRings:
         """``(ctx, push, row_alloc)`` as plain addresses: what ``nvrx_ktrace_set_sink`` needs to append kernel durations to
         these rings from the tracer's thread (include/nvrx_ktrace.h)."""
         cast = ctypes.cast
-        return (self.ctx.value, cast(self.lib.nvrx_ring_push_staged, ctypes.c_void_p).value,
-                cast(self.lib.nvrx_row_alloc, ctypes.c_void_p).value)
+        return (self.ctx.value, cast(self.lib.nvrx_sink_push, ctypes.c_void_p).value,
+                cast(self.lib.nvrx_sink_row_alloc, ctypes.c_void_p).value)
 
     def configure(self, row: int, kind: int, gid: int, lr: Optional[int] = None) -> None:
         lrs = range(self.local_ranks) if lr is None else (lr,)
