@@ -286,3 +286,91 @@ def test_random_launch_sequences_match_the_reference_profiler(profiler):
         prof.shutdown()
         prof.close()
         backend.set_backend(None)
+
+
+@pytest.mark.parametrize("asynchronous", [False, True])
+def test_detector_in_per_kernel_mode_conserves_every_duration_under_bursty_delivery(monkeypatch, asynchronous):
+    """The Detector's per-kernel flow on CPU, tracer emulated at the ABI: a section "launches kernels" by counting
+    dispatches as enqueued (``nvrx_ktrace_feed(NULL, n, counted)``); a feeder thread delivers their records later, in
+    BURSTS of hundreds (what a lazily flushed SDK buffer looks like), while the training thread enters sections and
+    reports -- synchronously (each report waits for its window) or asynchronously (reports do not wait, late durations are
+    held on the tracer's thread across "statistics launch + ring reset", a report that meets a new kernel name runs on the
+    old tables and KEEPS that row for the next one).  New kernel keys keep appearing.  With rings deep enough not to
+    overflow, every duration must be reported exactly once: sum of NUM over all reports == records delivered, per key."""
+    import queue
+    import time
+
+    from nvrx_straggler import Detector, Statistic
+    from nvrx_straggler.straggler import CustomSection
+
+    monkeypatch.setattr(ktrace, "_mode", "kernels")
+    monkeypatch.setattr(ktrace, "_mode_note", "forced by the test")
+    monkeypatch.setattr(ktrace, "_setup_error", None)
+    monkeypatch.setattr(ktrace, "setup", lambda *a, **k: None)
+    monkeypatch.setattr(ktrace.KernelTraceProfiler, "_live", None)
+    monkeypatch.setattr(ktrace.KernelTraceProfiler, "_ensure_ready", lambda self: None)
+    monkeypatch.setattr(ktrace.KernelTraceProfiler, "start", lambda self, key="": setattr(self, "_started", True))
+    monkeypatch.setattr(ktrace.KernelTraceProfiler, "stop", lambda self, *a: (setattr(self, "_started", False), False)[1])
+    monkeypatch.setenv("NVRX_KTRACE_SYNC_PATIENCE_S", "20")
+    monkeypatch.setattr(CustomSection, "max_elapseds_len", 4096)
+    backend.set_backend(OracleBackend(emulate_fused=True))
+    lib = ktrace.load()
+    rng = np.random.default_rng(9)
+    ids = _fresh_kernel_ids(12)
+    for i, kid in enumerate(ids.tolist()):
+        ktrace.feed_kernel_name(kid, f"burst_kernel_{i:02d}")
+    inbox: "queue.Queue" = queue.Queue()
+    stop = []
+    delivered = {}
+
+    def tracer_thread():                         # delivers in bursts: waits until a few hundred records are due
+        backlog = []
+        while not (stop and inbox.empty() and not backlog):
+            try:
+                backlog.append(inbox.get(timeout=0.002))
+            except queue.Empty:
+                pass
+            n = sum(b.size for b in backlog)
+            if n >= 300 or (stop and backlog) or (backlog and rng.random() < 0.02):
+                ktrace.feed(np.concatenate(backlog), counted=False)
+                backlog = []
+
+    th = threading.Thread(target=tracer_thread)
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n0", asynchronous=asynchronous, max_rows=64)
+    try:
+        th.start()
+        reported = {}
+        reports = []
+        for step in range(400):
+            live = 3 + step // 40                # a new kernel key every 40 steps
+            with Detector.detection_section("train_step", profile_cuda=True):
+                k = rng.integers(0, min(live, 12), int(rng.integers(1, 9)))
+                d = np.zeros(k.size, dtype=ktrace.DISPATCH_DTYPE)
+                d["kernel_id"] = ids[k]
+                d["workgroup"], d["grid"], d["start_ns"] = (64, 1, 1), (640, 1, 1), 1000
+                d["end_ns"] = 1000 + rng.integers(1_000, 90_000, k.size).astype(np.uint64)
+                assert lib.nvrx_ktrace_feed(None, int(k.size), 1) == 0       # "launched": counted, not finished
+                inbox.put(d)                                                 # the tracer's thread will see them finish
+                for kk in k.tolist():
+                    delivered[kk] = delivered.get(kk, 0) + 1
+            if step % 17 == 16:
+                reports.append(Detector.generate_report())
+        stop.append(1)
+        th.join()
+        assert lib.nvrx_ktrace_sync(10.0) == 0
+        reports.append(Detector.generate_report())
+        reports.append(Detector.generate_report())   # (asynchronous: a report that met a new name ran on the old tables; the next one has it)
+        for rep in reports:
+            for key, v in rep.local_kernel_summaries.items():
+                assert v[Statistic.MIN] <= v[Statistic.MED] <= v[Statistic.MAX], (key, v)
+                reported[key] = reported.get(key, 0) + int(v[Statistic.NUM])
+        want = {f"burst_kernel_{kk:02d}_blk_64_1_1_grid_10_1_1": n for kk, n in delivered.items()}
+        assert reported == want, {k: (reported.get(k), want.get(k)) for k in set(reported) | set(want) if reported.get(k) != want.get(k)}
+        assert sum(int(r.local_section_summaries["train_step"][Statistic.NUM]) for r in reports if "train_step" in r.local_section_summaries) == 400
+    finally:
+        stop.append(1)
+        if th.is_alive():
+            th.join()
+        Detector.shutdown()
+        backend.set_backend(None)
+        ktrace._reset_mode_for_tests()
