@@ -442,7 +442,8 @@ class KernelTraceProfiler:
         self._started = False
         self._closed = False
         self._rows_known = 0  # keys of the tracer whose ring row (and name) this object has learnt
-        self._key_learnt = bytearray()  # ... which ones, by key id
+        self._keys_seen = 0  # key ids [0, _keys_seen) have been looked at ...
+        self._key_pending: list = []  # ... and these of them have no row under this sink (yet)
         self.keys_without_row = 0
         self._warned_leak = False
         # from now on the tracer's thread appends every kernel duration to these rings
@@ -550,16 +551,18 @@ class KernelTraceProfiler:
         """Kernel keys the tracer's thread has met since the last look: their names and ring rows (cold path)."""
         lib, rings = self._lib, self._rings
         n = lib.nvrx_ktrace_num_keys()
-        learnt = self._key_learnt
-        if len(learnt) < n:
-            learnt.extend(bytes(n - len(learnt)))
-        for k in range(n):
-            if not learnt[k]:
-                row = lib.nvrx_ktrace_key_row(k)  # (-2: no record of this key has come under this sink yet; -1: no row was left)
-                if row >= 0:
-                    rings.kernel_row_names[key_name(k)] = row
-                    learnt[k] = 1
-                    self._rows_known += 1
+        pending = self._key_pending
+        pending.extend(range(self._keys_seen, n))  # key ids nobody has looked at yet
+        self._keys_seen = n
+        still = []
+        for k in pending:  # (only the keys without a known row: a job with thousands of keys does not re-ask about all of them)
+            row = lib.nvrx_ktrace_key_row(k)  # (-2: no record of this key has come under this sink yet; -1: no row was left)
+            if row >= 0:
+                rings.kernel_row_names[key_name(k)] = row
+                self._rows_known += 1
+            else:
+                still.append(k)
+        self._key_pending = still
         note = getattr(rings, "note_rows_used", None)
         if note is not None:
             note()  # the rows the tracer's thread took for these keys now count as used (reports cover them)
