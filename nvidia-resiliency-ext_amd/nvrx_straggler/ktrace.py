@@ -135,7 +135,9 @@ def release_env() -> None:
     """Once this process' HIP runtime is up: take back what rocprofiler-sdk wrote into the process environment --
     ``ROCPROFILER_REGISTER_FORCE_LOAD=1`` (``nvrx_ktrace_release_env``; a child that inherits it loads and configures the SDK
     on ``import torch``: the full tool search, and no tool can register there any more) and the ``GLOG_*`` switches its
-    library sets when it is loaded (those the job itself had not set)."""
+    library sets when it is loaded (those the job itself had not set).  ``unsetenv`` is not safe against a ``getenv``
+    running in another thread at that very moment (glibc); it is done ONCE, right after the runtime has come up -- the SDK
+    wrote the variables under the same conditions -- and the alternative is every child process misbehaving."""
     load().nvrx_ktrace_release_env()
     libc = ctypes.CDLL(None)
     for name in _GLOG_NAMES:
