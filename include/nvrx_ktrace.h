@@ -86,6 +86,12 @@ int nvrx_ktrace_set_sink(const nvrx_ktrace_sink *sink);
  * duration arriving in between lands in the NEXT window instead of being wiped with the old one.  Never blocks the
  * tracer's thread. */
 int nvrx_ktrace_hold(int on);
+/* The reference accepts only CUPTI_ACTIVITY_KIND_CONCURRENT_KERNEL records (CuptiProfiler.cpp:118,179): a cudaMemset or
+ * cudaMemcpy never becomes a key.  ROCm carries hipMemset / device-to-device hipMemcpy (and libraries' workspace fills) out
+ * with ROCclr's built-in blit KERNELS (__amd_rocclr_fillBufferAligned, __amd_rocclr_copyBuffer, ...), which arrive as
+ * kernel dispatches; they are left out by default (counter 11 counts them) so that the keys are the ones CUPTI would have
+ * produced.  on != 0 records them like any other kernel (the decision applies to records that arrive from now on). */
+int nvrx_ktrace_include_blits(int on);
 /* Diagnostics: while on, a copy of every duration handed to the sink is also queued for nvrx_ktrace_drain (bounded by
  * max_pending, oldest dropped): how a test reads the very durations the rings were given. */
 int nvrx_ktrace_tap(int on);
@@ -102,7 +108,8 @@ int nvrx_ktrace_stop(void);
  * "flush until two flushes bring nothing new" (the caller then has to synchronise the device first). */
 int nvrx_ktrace_sync(double timeout_s);
 /* Give up on the dispatches nvrx_ktrace_sync is still missing (call after the device has been synchronised and
- * nvrx_ktrace_flush has run: whatever has not arrived by then never will). */
+ * nvrx_ktrace_flush has run: whatever has not arrived by then never will).  Should such a record arrive after all, the
+ * forgiveness is taken back (counter 7 goes down again), so later syncs do not under-wait. */
 int nvrx_ktrace_forgive(void);
 /* Make every completed dispatch visible (cuptiActivityFlushAll, CuptiProfiler.cpp:138): flushes the SDK's buffer
  * until two consecutive flushes bring nothing new. */
@@ -115,8 +122,9 @@ uint64_t nvrx_ktrace_dropped(void);
 /* Counters, monotonic over the process: 0 dispatches enqueued while tracing, 1 dispatch records arrived, 2 durations
  * handed to the sink, 3 durations lost because the sink had no row left for their key, 4 sink errors, 5 records
  * of this library's own engine kernels left out, 7 forgiven dispatches, 8 SDK buffer flushes issued by the pump
- * thread, 9 = 1 if dispatches are counted; under the CURRENT sink: 6 keys that found no row left, 10 keys that were
- * given a row (a host polls this one to learn when new names have turned up). */
+ * thread, 9 = 1 if dispatches are counted, 11 records of the runtime's memset / memcpy (blit) kernels left out; under the
+ * CURRENT sink: 6 keys that found no row left, 10 keys that were given a row (a host polls this one to learn when new
+ * names have turned up). */
 uint64_t nvrx_ktrace_counter(int what);
 /* Keys seen so far, and the name of one: "<kernel name>_blk_x_y_z_grid_x_y_z" (CuptiProfiler.cpp:186-189;
  * grid counts workgroups like CUDA's gridDim, not work-items).  The pointer stays valid for the process. */

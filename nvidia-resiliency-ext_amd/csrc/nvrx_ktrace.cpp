@@ -43,6 +43,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <iterator>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -93,8 +94,19 @@ struct ShapeHash {
     }
 };
 
-constexpr int32_t KEY_IGNORED = -1;
+constexpr int32_t KEY_IGNORED = -1;  // one of the engine's own kernels
+constexpr int32_t KEY_BLIT = -2;     // a memset / memcpy the runtime runs as a kernel (see is_blit_name)
 constexpr int ROW_NOT_ASKED = -2;
+
+// The reference enables and accepts ONLY CUPTI_ACTIVITY_KIND_CONCURRENT_KERNEL (CuptiProfiler.cpp:118,179): a cudaMemset
+// or cudaMemcpy never becomes a key.  On ROCm hipMemset / hipMemsetAsync / device-to-device hipMemcpy (and the fills a
+// library issues for its workspaces, e.g. hipBLASLt's at a matmul's first call) are carried out by ROCclr's built-in
+// "blit" program, whose kernels arrive as ordinary KERNEL_DISPATCH records: __amd_rocclr_fillBufferAligned,
+// __amd_rocclr_copyBuffer, __amd_rocclr_copyBufferAligned, __amd_rocclr_fillImage ...  They are left out by that
+// reserved name prefix, decided once per kernel when its symbol is registered; their durations are host / PCIe driven and
+// would enter the kernel-weighted GPU score (reporting.py:237-253) as noise the reference never sees.
+// nvrx_ktrace_include_blits(1) records them like any other kernel.
+bool is_blit_name(const std::string &name) { return name.compare(0, 13, "__amd_rocclr_") == 0; }
 
 struct State {
     std::mutex mu;
@@ -103,6 +115,9 @@ struct State {
     // code objects that come out of libnvrx_straggler_hip.so, and the kernels in them: the engine's own launches (a
     // staging flush inside a user's section) are the measuring apparatus, not the job
     std::unordered_set<uint64_t> own_code_objects, own_kernels;
+    // the runtime's memset / memcpy kernels (KEY_BLIT unless include_blits)
+    std::unordered_set<uint64_t> blit_kernels;
+    bool include_blits = false;
     // (kernel, geometry) -> key id (KEY_IGNORED: left out); key string -> key id; names are never moved once created
     // (nvrx_ktrace_key_name hands out pointers)
     std::unordered_map<Shape, int32_t, ShapeHash> shape_keys;
@@ -134,7 +149,7 @@ struct State {
 
     // counters (include/nvrx_ktrace.h, nvrx_ktrace_counter)
     std::atomic<uint64_t> enqueued{0}, arrived{0}, delivered{0}, lost_no_row{0}, sink_errors{0}, own_skipped{0},
-        keys_without_row{0}, forgiven{0}, pump_flushes{0}, dropped{0}, rows_assigned{0};
+        keys_without_row{0}, forgiven{0}, pump_flushes{0}, dropped{0}, rows_assigned{0}, blit_skipped{0};
 
     // pump thread
     std::mutex pump_mu;
@@ -296,11 +311,13 @@ void on_code_object(rocprofiler_callback_tracing_record_t record, rocprofiler_us
     if (name.size() > 3 && name.compare(name.size() - 3, 3, ".kd") == 0) name.resize(name.size() - 3);
     std::lock_guard<std::mutex> lk(s.mu);
     if (s.own_code_objects.count(data->code_object_id)) s.own_kernels.insert(data->kernel_id);
+    if (is_blit_name(name)) s.blit_kernels.insert(data->kernel_id);
     s.kernel_names[data->kernel_id] = std::move(name);
 }
 
 // ---- records ----------------------------------------------------------------------------------------------------
-// Key id of a dispatch (KEY_IGNORED: one of the engine's own kernels).  Called with s.mu held.
+// Key id of a dispatch (KEY_IGNORED: one of the engine's own kernels; KEY_BLIT: a runtime memset / memcpy kernel).
+// Called with s.mu held.
 int32_t key_of(State &s, const nvrx_ktrace_dispatch &d) {
     Shape sh;
     sh.kernel_id = d.kernel_id;
@@ -315,6 +332,8 @@ int32_t key_of(State &s, const nvrx_ktrace_dispatch &d) {
     int32_t id;
     if (s.own_kernels.count(d.kernel_id)) {
         id = KEY_IGNORED;
+    } else if (!s.include_blits && s.blit_kernels.count(d.kernel_id)) {
+        id = KEY_BLIT;
     } else {
         auto nit = s.kernel_names.find(d.kernel_id);
         const char *name = nit != s.kernel_names.end() ? nit->second.c_str() : "unknown_kernel";
@@ -357,8 +376,8 @@ void consume(const nvrx_ktrace_dispatch *recs, size_t n) {
             const nvrx_ktrace_dispatch &d = recs[i];
             if (d.start_ns == 0 || d.end_ns == 0) continue;  // CuptiProfiler.cpp:182-184
             const int32_t key = key_of(s, d);
-            if (key == KEY_IGNORED) {
-                s.own_skipped.fetch_add(1, std::memory_order_relaxed);
+            if (key < 0) {
+                (key == KEY_BLIT ? s.blit_skipped : s.own_skipped).fetch_add(1, std::memory_order_relaxed);
                 continue;
             }
             // nanoseconds -> microseconds exactly as the reference: integer difference, one f32 division
@@ -398,7 +417,16 @@ void consume(const nvrx_ktrace_dispatch *recs, size_t n) {
         }
         push_batch(s, s.batch_rows, s.batch_vals);
     }
-    s.arrived.fetch_add(n, std::memory_order_release);
+    const uint64_t have = s.arrived.fetch_add(n, std::memory_order_release) + n;
+    // A dispatch that was given up on (nvrx_ktrace_forgive) and whose record came after all: the forgiveness is taken back,
+    // or arrived + forgiven would stay above enqueued for good and every later nvrx_ktrace_sync would under-wait by that many.
+    uint64_t f = s.forgiven.load(std::memory_order_acquire);
+    while (f) {
+        const uint64_t enq = s.enqueued.load(std::memory_order_acquire);
+        if (have + f <= enq) break;
+        const uint64_t back = std::min(f, have + f - enq);
+        if (s.forgiven.compare_exchange_weak(f, f - back, std::memory_order_acq_rel)) break;
+    }
 }
 
 void on_records(rocprofiler_context_id_t, rocprofiler_buffer_id_t, rocprofiler_record_header_t **headers,
@@ -636,6 +664,17 @@ int nvrx_ktrace_hold(int on) {
     return NVRX_KTRACE_OK;
 }
 
+int nvrx_ktrace_include_blits(int on) {
+    State &s = st();
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (s.include_blits == (on != 0)) return NVRX_KTRACE_OK;
+    s.include_blits = on != 0;
+    // the decision is cached per (kernel, geometry): forget it for the blit kernels only
+    for (auto it = s.shape_keys.begin(); it != s.shape_keys.end();)
+        it = s.blit_kernels.count(it->first.kernel_id) ? s.shape_keys.erase(it) : std::next(it);
+    return NVRX_KTRACE_OK;
+}
+
 int nvrx_ktrace_tap(int on) {
     State &s = st();
     std::lock_guard<std::mutex> lk(s.mu);
@@ -758,6 +797,7 @@ uint64_t nvrx_ktrace_counter(int what) {
         case 8: return s.pump_flushes.load();
         case 9: return (uint64_t)s.counting.load();
         case 10: return s.rows_assigned.load();
+        case 11: return s.blit_skipped.load();
         default: return 0;
     }
 }
@@ -797,6 +837,7 @@ int nvrx_ktrace_feed_kernel_name(uint64_t kernel_id, const char *name, int own) 
     std::lock_guard<std::mutex> lk(s.mu);
     s.kernel_names[kernel_id] = name;
     if (own) s.own_kernels.insert(kernel_id);
+    if (is_blit_name(name)) s.blit_kernels.insert(kernel_id);
     return NVRX_KTRACE_OK;
 }
 

@@ -79,6 +79,7 @@ SYMBOLS = [
     ("nvrx_ktrace_ready", c_int, []),
     ("nvrx_ktrace_set_sink", c_int, [POINTER(Sink)]),
     ("nvrx_ktrace_hold", c_int, [c_int]),
+    ("nvrx_ktrace_include_blits", c_int, [c_int]),
     ("nvrx_ktrace_tap", c_int, [c_int]),
     ("nvrx_ktrace_start", c_int, []),
     ("nvrx_ktrace_stop", c_int, []),
@@ -98,7 +99,7 @@ SYMBOLS = [
     ("nvrx_ktrace_feed", c_int, [c_void_p, c_int, c_int]),
 ]
 COUNTERS = ("enqueued", "arrived", "delivered", "lost_no_row", "sink_errors", "own_skipped", "keys_without_row", "forgiven",
-            "pump_flushes", "counting", "rows_assigned")
+            "pump_flushes", "counting", "rows_assigned", "blit_skipped")
 
 _lib = None
 _lock = threading.Lock()
@@ -448,6 +449,9 @@ class KernelTraceProfiler:
         self._key_pending: list = []  # ... and these of them have no row under this sink (yet)
         self.keys_without_row = 0
         self._warned_leak = False
+        self._counting = True  # dispatches are counted at enqueue (read back in initialize)
+        # memsets / memcpys are not kernels to CUPTI; NVRX_KTRACE_BLITS=1 records ROCm's blit kernels all the same
+        self._lib.nvrx_ktrace_include_blits(1 if os.environ.get("NVRX_KTRACE_BLITS", "0") == "1" else 0)
         # from now on the tracer's thread appends every kernel duration to these rings
         ctx, push, row_alloc = rings.ktrace_sink()
         global _sink_ctx
@@ -472,6 +476,9 @@ class KernelTraceProfiler:
 
     def initialize(self) -> None:
         self._ensure_ready()
+        # (settled by the tool's initialiser, which has run by now; without the SDK -- records fed through nvrx_ktrace_feed --
+        #  the feeder does the counting)
+        self._counting = bool(self._lib.nvrx_ktrace_counter(9)) or not self._lib.nvrx_ktrace_ready()
         # the runtime is up: what rocprofiler_force_configure left in the environment (ROCPROFILER_REGISTER_FORCE_LOAD=1 ...) must
         # not reach the children this process starts from now on (DataLoader workers, spawned ranks)
         release_env()
@@ -521,6 +528,12 @@ class KernelTraceProfiler:
         reports) only looks: what has not arrived yet counts in the next window.  One C call; names of kernel keys seen
         for the first time are fetched on top (cold).  Returns the number of dispatches still missing."""
         lib = self._lib
+        if wait and not self._counting:
+            # dispatches are not counted (NVRX_KTRACE_COUNT=0, or the SDK refused the ENQUEUE callback): nvrx_ktrace_sync can
+            # only flush what HAS completed, so the device is waited for first, as the reference does (straggler.py:234)
+            import torch
+
+            torch.cuda.synchronize()
         missing = lib.nvrx_ktrace_sync(_sync_patience_s() if wait else 0.0)
         if missing < 0:
             _check(missing)

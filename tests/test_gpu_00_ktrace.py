@@ -219,6 +219,83 @@ def test_kernels_of_a_replayed_graph_are_recorded_like_the_same_kernels_launched
         assert 0.2 < a / b < 5.0, (k, a, b)
 
 
+BASIC_SCRIPT = r'''
+import faulthandler, json, os, sys
+faulthandler.enable()
+faulthandler.dump_traceback_later(140, exit=True)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+os.environ["NVRX_GPU_TIMING"] = "kernels"
+import nvrx_straggler                      # registers the tracer before HIP starts
+import nvrx_cupti_module as cupti_module
+from nvrx_straggler import ktrace
+import torch
+
+plain = lambda st: {k: int(v.num_calls) for k, v in st.items()}
+out = {}
+prof = cupti_module.CuptiProfiler()
+a = torch.randn(1000, 1000, device="cuda")
+b = torch.randn(1000, 1000, device="cuda")
+torch.cuda.synchronize()
+prof.initialize()
+prof.start()
+c0 = ktrace.counters()
+torch.matmul(a, b)                          # the FIRST matmul of the process: the BLAS library sets its workspace up
+torch.cuda.synchronize()
+out["first"] = plain(prof.get_stats())
+prof.stop()
+out["after_stop"] = plain(prof.get_stats())
+prof.reset()
+out["after_reset"] = plain(prof.get_stats())
+# explicit memsets / device-to-device copies inside a traced window: hipMemsetAsync and hipMemcpyAsync run as ROCclr blit kernels
+prof.start()
+raw = torch.empty(1 << 22, dtype=torch.uint8, device="cuda")
+raw.zero_()                                 # fill
+dst = torch.empty_like(a)
+dst.copy_(a)                                # device-to-device copy
+torch.matmul(a, b)
+torch.cuda.synchronize()
+out["with_memops"] = plain(prof.get_stats())
+c1 = ktrace.counters()
+out["blit_skipped"] = c1["blit_skipped"] - c0["blit_skipped"]
+prof.reset()
+# on request the runtime's blit kernels are recorded like any other kernel
+ktrace.load().nvrx_ktrace_include_blits(1)
+raw.zero_()
+dst.copy_(a)
+torch.cuda.synchronize()
+out["blits_included"] = plain(prof.get_stats())
+ktrace.load().nvrx_ktrace_include_blits(0)
+prof.stop()
+prof.shutdown()
+prof.close()
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.gpu
+def test_memsets_and_memcpys_are_not_kernels_only_the_matmul_is_a_key():
+    """Twin of the reference's tests/straggler/unit/test_cupti_ext.py:22-47 (``test_basic_kernel_tracking``): profiler on,
+    ONE matmul, ``len(get_stats()) == 1`` with ``num_calls == 1``, still there after ``stop()``, gone after ``reset()``.
+    CUPTI's CONCURRENT_KERNEL activity kind (the only one the reference enables, CuptiProfiler.cpp:118,179) has no memset or
+    memcpy records; ROCm runs those as ROCclr blit kernels (``__amd_rocclr_fillBufferAligned`` for the BLAS workspace at the
+    first matmul was the second key that failed this scenario in round 5) and the tracer leaves them out -- counted, and
+    recorded when asked for (``nvrx_ktrace_include_blits``)."""
+    out = _run(BASIC_SCRIPT)
+    print("[ktrace basic]", json.dumps(out))
+    first = out["first"]
+    assert len(first) == 1, first                                   # the reference's assertion
+    (name, calls), = first.items()
+    assert calls == 1 and ("Cijk" in name or "gemm" in name.lower()), first
+    assert out["after_stop"] == first and out["after_reset"] == {}
+    memops = out["with_memops"]
+    assert not any("__amd_rocclr_" in k for k in memops), memops
+    assert memops.get(name) == 1, memops
+    # fills and copies went by inside the window (whether the runtime carries one out as a blit kernel or on an SDMA engine is its
+    # choice; whatever was a kernel was counted as left out)
+    assert out["blit_skipped"] >= 1, out
+    assert any("__amd_rocclr_" in k for k in out["blits_included"]), out["blits_included"]
+
+
 COLLECTIVE_SCRIPT = r'''
 import faulthandler, json, os, sys
 faulthandler.enable()

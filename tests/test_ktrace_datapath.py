@@ -192,6 +192,68 @@ def test_engine_kernels_are_left_out_and_full_rings_drop_new_keys_not_old_ones(p
     assert prof.get_stats() == {}
 
 
+def test_runtime_memset_and_memcpy_kernels_are_not_keys_as_with_cupti(profiler):
+    """CUPTI_ACTIVITY_KIND_CONCURRENT_KERNEL is the only record kind the reference accepts (CuptiProfiler.cpp:118,179): a
+    memset or memcpy never becomes a key -- its own test expects ONE key after "fill + matmul"
+    (tests/straggler/unit/test_cupti_ext.py:22-36).  ROCm's hipMemset / device-to-device hipMemcpy are ROCclr blit KERNELS
+    and arrive as kernel dispatches: left out by name prefix, counted, and recorded on request."""
+    prof, rings = profiler(8, 16)
+    ids = _fresh_kernel_ids(4).tolist()
+    names = ("__amd_rocclr_fillBufferAligned", "__amd_rocclr_copyBuffer", "Cijk_Ailk_Bljk_gemm", "my__amd_rocclr_lookalike")
+    for i, n in zip(ids, names):
+        ktrace.feed_kernel_name(i, n)
+    d = np.zeros(6, dtype=ktrace.DISPATCH_DTYPE)
+    d["kernel_id"] = [ids[0], ids[2], ids[1], ids[0], ids[3], ids[2]]
+    d["workgroup"], d["grid"], d["start_ns"], d["end_ns"] = (256, 1, 1), (512, 1, 1), 1000, 3000
+    before = ktrace.counters()
+    ktrace.feed(d)
+    assert prof.harvest() == 0                       # the blit records count as ARRIVED: nobody waits for them
+    after = ktrace.counters()
+    assert after["blit_skipped"] - before["blit_skipped"] == 3 and after["own_skipped"] == before["own_skipped"]
+    assert after["arrived"] - before["arrived"] == 6 and after["delivered"] - before["delivered"] == 3
+    got = prof.get_stats()
+    assert set(got) == {"Cijk_Ailk_Bljk_gemm_blk_256_1_1_grid_2_1_1", "my__amd_rocclr_lookalike_blk_256_1_1_grid_2_1_1"}
+    assert got["Cijk_Ailk_Bljk_gemm_blk_256_1_1_grid_2_1_1"].num_calls == 2
+    # on request they are kernels like any other (same geometry: the cached decision is forgotten) ...
+    lib = ktrace.load()
+    assert lib.nvrx_ktrace_include_blits(1) == 0
+    try:
+        ktrace.feed(d[:1])
+        assert "__amd_rocclr_fillBufferAligned_blk_256_1_1_grid_2_1_1" in prof.get_stats()
+        assert ktrace.counters()["blit_skipped"] == after["blit_skipped"]
+    finally:
+        assert lib.nvrx_ktrace_include_blits(0) == 0
+    # ... and left out again afterwards
+    ktrace.feed(d[:1])
+    assert prof.get_stats()["__amd_rocclr_fillBufferAligned_blk_256_1_1_grid_2_1_1"].num_calls == 1
+    assert ktrace.counters()["blit_skipped"] == after["blit_skipped"] + 1
+
+
+def test_a_forgiven_dispatch_whose_record_arrives_after_all_is_not_forgiven_twice(profiler):
+    """``nvrx_ktrace_forgive`` stops waiting for a dispatch; if its record then arrives, arrived + forgiven would exceed
+    enqueued for good and every later sync would under-wait by one.  The forgiveness is taken back."""
+    prof, rings = profiler(4, 8)
+    lib = ktrace.load()
+    assert lib.nvrx_ktrace_sync(5.0) == 0
+    (kid,) = _fresh_kernel_ids(1).tolist()
+    ktrace.feed_kernel_name(kid, "straggling_record")
+    d = np.zeros(1, dtype=ktrace.DISPATCH_DTYPE)
+    d["kernel_id"], d["workgroup"], d["grid"], d["start_ns"], d["end_ns"] = kid, (1, 1, 1), (1, 1, 1), 5, 1005
+    c0 = ktrace.counters()
+    if c0["arrived"] + c0["forgiven"] > c0["enqueued"]:
+        pytest.skip("earlier tests of this process fed uncounted records: the counters cannot show the invariant")
+    assert lib.nvrx_ktrace_feed(None, 1, 1) == 0     # enqueued, record outstanding
+    assert lib.nvrx_ktrace_sync(0.0) == 1
+    assert lib.nvrx_ktrace_forgive() == 1 and lib.nvrx_ktrace_sync(0.0) == 0
+    ktrace.feed(d, counted=False)                    # ... and there it is after all
+    c1 = ktrace.counters()
+    assert c1["forgiven"] == c0["forgiven"], (c0, c1)
+    assert lib.nvrx_ktrace_feed(None, 1, 1) == 0     # the NEXT outstanding dispatch is waited for again
+    assert lib.nvrx_ktrace_sync(0.0) == 1
+    ktrace.feed(d, counted=False)
+    assert lib.nvrx_ktrace_sync(0.0) == 0
+
+
 def test_harvest_waits_for_dispatches_that_are_still_running(profiler, monkeypatch):
     """``nvrx_ktrace_sync``: a dispatch that was enqueued (counted) and whose record has not arrived is MISSING; harvest
     (wait=False) says so without blocking, harvest(wait=True) returns once another thread delivers the record."""
