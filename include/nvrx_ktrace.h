@@ -8,8 +8,9 @@
  * (end - start) / 1000.0f microseconds, appended to that key's overwrite-oldest CircularBuffer
  * (CuptiProfiler.cpp:168-207, CircularBuffer.h:53-61).  Here a rocprofiler-sdk context with the buffered
  * KERNEL_DISPATCH tracing service does the same job: start/stop map to rocprofiler_start_context /
- * rocprofiler_stop_context (cuptiActivityEnable / Disable, CuptiProfiler.cpp:116-133), records arrive on the
- * SDK's callback thread, and THAT thread appends every duration to its key's ring: the rings are the device
+ * rocprofiler_stop_context (cuptiActivityEnable / Disable, CuptiProfiler.cpp:116-133), finished dispatches arrive
+ * from the SDK (completion callbacks by default, buffered records with NVRX_KTRACE_DELIVERY=buffer), and a thread
+ * of the tracer -- never the one that trains -- appends every duration to its key's ring: the rings are the device
  * rings of libnvrx_straggler_hip.so, reached through a SINK of two plain function pointers
  * (nvrx_ktrace_set_sink), so the two libraries do not link against each other.  Overflow keeps the NEWEST
  * ring_cap durations per key, memory is bounded by the rings, and the thread that trains does no per-record
@@ -122,7 +123,9 @@ uint64_t nvrx_ktrace_dropped(void);
 /* Counters, monotonic over the process: 0 dispatches enqueued while tracing, 1 dispatch records arrived, 2 durations
  * handed to the sink, 3 durations lost because the sink had no row left for their key, 4 sink errors, 5 records
  * of this library's own engine kernels left out, 7 forgiven dispatches, 8 SDK buffer flushes issued by the pump
- * thread, 9 = 1 if dispatches are counted, 11 records of the runtime's memset / memcpy (blit) kernels left out; under the
+ * thread (callback delivery: drains of the inbox), 9 = 1 if dispatches are counted, 11 records of the runtime's memset /
+ * memcpy (blit) kernels left out, 12 = 1 if finished dispatches are delivered by completion callbacks (0: buffered
+ * records, NVRX_KTRACE_DELIVERY=buffer); under the
  * CURRENT sink: 6 keys that found no row left, 10 keys that were given a row (a host polls this one to learn when new
  * names have turned up). */
 uint64_t nvrx_ktrace_counter(int what);
@@ -148,9 +151,11 @@ typedef struct nvrx_ktrace_dispatch {
 } nvrx_ktrace_dispatch;
 /* Name a kernel id as a code-object callback would ("<mangled name>"; own != 0: one of the engine's kernels). */
 int nvrx_ktrace_feed_kernel_name(uint64_t kernel_id, const char *name, int own);
-/* counted != 0: the dispatches also count as enqueued (as if the ENQUEUE callback had seen them); recs == NULL with
- * counted != 0 only counts n dispatches as enqueued -- their records follow in a later call with counted == 0 (a kernel
- * that is still running when somebody calls nvrx_ktrace_sync). */
+/* counted & 1: the dispatches also count as enqueued (as if the ENQUEUE callback had seen them); recs == NULL with
+ * counted & 1 only counts n dispatches as enqueued -- their records follow in a later call with counted == 0 (a kernel
+ * that is still running when somebody calls nvrx_ktrace_sync).  counted & 2: the records are left in the tracer's INBOX,
+ * exactly as the SDK's completion callback leaves them, instead of being consumed on the calling thread -- the pump
+ * thread or the next nvrx_ktrace_sync / nvrx_ktrace_flush brings them in. */
 int nvrx_ktrace_feed(const nvrx_ktrace_dispatch *recs, int n, int counted);
 
 #ifdef __cplusplus

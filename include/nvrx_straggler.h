@@ -176,6 +176,10 @@ int nvrx_ring_set_count_all(nvrx_ctx *ctx, int n);
 int nvrx_ring_count(const nvrx_ctx *ctx, int row);
 /* Valid-sample counts of rows [0, n) in one call. */
 int nvrx_ring_counts(const nvrx_ctx *ctx, int32_t *out, int n);
+/* 1 if the SET of rows among [0, n) that hold samples differs from what the previous call saw (or n does, or this is the
+ * first call), else 0: a report's name tables -- which sections / kernels have a summary this window, straggler.py:185-195
+ * leaves out what holds no samples -- only need rebuilding when this says so.  One call, nothing copied. */
+int nvrx_ring_occupancy_changed(nvrx_ctx *ctx, int n);
 /* Drop all samples of every row: deque.clear (straggler.py:223-225) / reset (CuptiProfiler.cpp:148-152).
  * History minima and row configuration are kept, as in the reference (reporting.py:186-191). */
 int nvrx_ring_reset(nvrx_ctx *ctx);

@@ -9,12 +9,25 @@
 // appends the batch to the rings through the installed sink with ONE call.  The rings and their statistics live
 // on the device (libnvrx_straggler_hip.so).  What the training thread does at report time is nvrx_ktrace_sync().
 //
+// How the records get here (NVRX_KTRACE_DELIVERY, default `callback`):
+//   * callback: the SDK's KERNEL_DISPATCH callback service with the COMPLETE operation -- the runtime's completion
+//     handler hands every finished dispatch (with its timestamps) to on_dispatch(), which does nothing but append 48
+//     bytes to an INBOX under a mutex nobody holds for longer than a memcpy (the handler also forwards the job's own
+//     completion signals: it must never wait for a lock somebody holds across a device wait).  The inbox is drained
+//     into consume() by the pump thread every couple of milliseconds while a window is open or has dispatches
+//     outstanding, and by nvrx_ktrace_sync() on its caller's thread.  There is no SDK buffer and nothing to flush: a
+//     report waits exactly until the last kernel of its window has completed (rounds 4-5 paid ~90 us per synchronous
+//     report for rocprofiler_flush_buffer's hand-over to the SDK's callback thread, profiles/r06a_kernels_mode_breakdown.txt);
+//   * buffer: the buffered KERNEL_DISPATCH service of rounds 4-5 (records arrive in batches on the SDK's callback
+//     thread when its 256 KB buffer fills or is flushed); kept for comparison and as the fallback if the callback
+//     service cannot be configured.
 // Threads:
-//   * launching threads: on_dispatch_enqueue() -- one relaxed atomic increment per traced dispatch;
-//   * the SDK's callback thread: on_records() -> consume(); code-object callbacks arrive on whichever thread
+//   * launching threads: on_dispatch(), ENQUEUE phase -- one relaxed atomic increment per traced dispatch;
+//   * the runtime's completion handler (callback delivery): on_dispatch(), COMPLETE -- the inbox append; or the SDK's
+//     callback thread (buffer delivery): on_records() -> consume().  Code-object callbacks arrive on whichever thread
 //     loads the code object;
-//   * the pump thread (ours): after nvrx_ktrace_stop() it flushes the SDK's buffer until every dispatch of the
-//     window has arrived, so that the records reach the rings while the job trains on;
+//   * the pump thread (ours): drains the inbox (callback) / flushes the SDK's buffer (buffer) until every dispatch of
+//     the window has arrived, so that the records reach the rings while the job trains on;
 //   * the application thread: the exported functions.
 // One mutex guards the shared state (the reference: _kernelDurationsMutex, CuptiProfiler.cpp:174); it is held for
 // a whole batch, including the sink's push.  rocprofiler_flush_buffer is always called WITHOUT it, as the
@@ -150,6 +163,14 @@ struct State {
     // counters (include/nvrx_ktrace.h, nvrx_ktrace_counter)
     std::atomic<uint64_t> enqueued{0}, arrived{0}, delivered{0}, lost_no_row{0}, sink_errors{0}, own_skipped{0},
         keys_without_row{0}, forgiven{0}, pump_flushes{0}, dropped{0}, rows_assigned{0}, blit_skipped{0};
+
+    // callback delivery: completed dispatches wait here for a drainer (in_mu is only ever held for an append or a swap;
+    // drain_mu serialises the drainers so that batches reach the rings in the order they were taken)
+    std::atomic<int> by_callback{0};
+    std::mutex in_mu, drain_mu;
+    std::vector<nvrx_ktrace_dispatch> inbox, inbox_spare;
+    std::atomic<uint64_t> inbox_dropped{0};
+    size_t max_inbox = 1u << 20;  // (48 MB: only reached if nobody drains -- pump off and no report for ~1e6 kernels)
 
     // pump thread
     std::mutex pump_mu;
@@ -449,11 +470,55 @@ void on_records(rocprofiler_context_id_t, rocprofiler_buffer_id_t, rocprofiler_r
     consume(batch.data(), batch.size());
 }
 
-// On the launching thread, before the packet is written: the dispatch WILL produce a record (the contexts active now are
-// captured with it, fwd.h ROCPROFILER_KERNEL_DISPATCH_ENQUEUE), so it is counted as expected.
-void on_dispatch_enqueue(rocprofiler_callback_tracing_record_t record, rocprofiler_user_data_t *, void *) {
-    if (record.phase == ROCPROFILER_CALLBACK_PHASE_ENTER && record.operation == ROCPROFILER_KERNEL_DISPATCH_ENQUEUE)
-        st().enqueued.fetch_add(1, std::memory_order_relaxed);
+// Everything waiting in the inbox -> consume(), on the calling thread.  Returns how many records that were.
+size_t drain_inbox(State &s) {
+    std::lock_guard<std::mutex> dl(s.drain_mu);
+    {
+        std::lock_guard<std::mutex> il(s.in_mu);
+        if (s.inbox.empty()) return 0;
+        s.inbox.swap(s.inbox_spare);
+    }
+    const size_t n = s.inbox_spare.size();
+    consume(s.inbox_spare.data(), n);
+    s.inbox_spare.clear();
+    return n;
+}
+
+void inbox_append(State &s, const nvrx_ktrace_dispatch &d) {
+    bool dropped = false;
+    {
+        std::lock_guard<std::mutex> il(s.in_mu);
+        if (s.inbox.size() >= s.max_inbox)
+            dropped = true;  // (nobody drains: keep what is there, count this one as arrived-and-lost below)
+        else
+            s.inbox.push_back(d);
+    }
+    if (dropped) {
+        s.inbox_dropped.fetch_add(1, std::memory_order_relaxed);
+        s.dropped.fetch_add(1, std::memory_order_relaxed);
+        s.arrived.fetch_add(1, std::memory_order_release);
+    }
+}
+
+// ENQUEUE, on the launching thread, before the packet is written: the dispatch WILL produce a record (the contexts active
+// now are captured with it, fwd.h ROCPROFILER_KERNEL_DISPATCH_ENQUEUE), so it is counted as expected.
+// COMPLETE (callback delivery), on the runtime's completion handler: the finished dispatch with its timestamps.
+void on_dispatch(rocprofiler_callback_tracing_record_t record, rocprofiler_user_data_t *, void *) {
+    if (record.operation == ROCPROFILER_KERNEL_DISPATCH_ENQUEUE) {
+        if (record.phase == ROCPROFILER_CALLBACK_PHASE_ENTER) st().enqueued.fetch_add(1, std::memory_order_relaxed);
+        return;
+    }
+    if (record.operation != ROCPROFILER_KERNEL_DISPATCH_COMPLETE || !record.payload) return;
+    State &s = st();
+    if (!s.by_callback.load(std::memory_order_relaxed)) return;
+    auto *rec = static_cast<rocprofiler_callback_tracing_kernel_dispatch_data_t *>(record.payload);
+    const auto &di = rec->dispatch_info;
+    nvrx_ktrace_dispatch d;
+    d.kernel_id = di.kernel_id;
+    d.workgroup[0] = di.workgroup_size.x, d.workgroup[1] = di.workgroup_size.y, d.workgroup[2] = di.workgroup_size.z;
+    d.grid[0] = di.grid_size.x, d.grid[1] = di.grid_size.y, d.grid[2] = di.grid_size.z;
+    d.start_ns = rec->start_timestamp, d.end_ns = rec->end_timestamp;
+    inbox_append(s, d);
 }
 
 #define KT_DBG(msg)                                                        \
@@ -478,29 +543,47 @@ int tool_init(rocprofiler_client_finalize_t, void *) {
         return -1;
     KT_DBG("tool_init: names context configured");
     if (rocprofiler_create_context(&s.ctx) != ROCPROFILER_STATUS_SUCCESS) return -1;
-    constexpr size_t kBufBytes = 256 * 1024;
-    if (rocprofiler_create_buffer(s.ctx, kBufBytes, kBufBytes - kBufBytes / 8, ROCPROFILER_BUFFER_POLICY_LOSSLESS,
-                                  on_records, nullptr, &s.buffer) != ROCPROFILER_STATUS_SUCCESS)
-        return -1;
-    if (rocprofiler_configure_buffer_tracing_service(s.ctx, ROCPROFILER_BUFFER_TRACING_KERNEL_DISPATCH, nullptr, 0,
-                                                     s.buffer) != ROCPROFILER_STATUS_SUCCESS)
-        return -1;
-    if (!env_is("NVRX_KTRACE_COUNT", "0")) {
-        rocprofiler_tracing_operation_t dops[] = {ROCPROFILER_KERNEL_DISPATCH_ENQUEUE};
-        if (rocprofiler_configure_callback_tracing_service(s.ctx, ROCPROFILER_CALLBACK_TRACING_KERNEL_DISPATCH, dops, 1,
-                                                           on_dispatch_enqueue, nullptr) == ROCPROFILER_STATUS_SUCCESS)
-            s.counting.store(1, std::memory_order_release);
-        else
-            KT_DBG("tool_init: the ENQUEUE callback could not be configured; nvrx_ktrace_sync settles by flushing");
+    const bool want_callback = !env_is("NVRX_KTRACE_DELIVERY", "buffer");
+    const bool count = !env_is("NVRX_KTRACE_COUNT", "0");
+    if (want_callback) {
+        // ENQUEUE counts the dispatches a window expects, COMPLETE brings each one's timestamps: no buffer, no flush
+        rocprofiler_tracing_operation_t dops[] = {ROCPROFILER_KERNEL_DISPATCH_ENQUEUE, ROCPROFILER_KERNEL_DISPATCH_COMPLETE};
+        if (rocprofiler_configure_callback_tracing_service(s.ctx, ROCPROFILER_CALLBACK_TRACING_KERNEL_DISPATCH, count ? dops : dops + 1,
+                                                           count ? 2 : 1, on_dispatch, nullptr) == ROCPROFILER_STATUS_SUCCESS) {
+            s.by_callback.store(1, std::memory_order_release);
+            s.counting.store(count ? 1 : 0, std::memory_order_release);
+            s.inbox.reserve(4096);
+            s.inbox_spare.reserve(4096);
+        } else {
+            KT_DBG("tool_init: the dispatch callback service could not be configured; falling back to the buffered service");
+        }
     }
-    KT_DBG("tool_init: dispatch service configured");
-    rocprofiler_callback_thread_t thr{};
-    if (rocprofiler_create_callback_thread(&thr) != ROCPROFILER_STATUS_SUCCESS) return -1;
-    if (rocprofiler_assign_callback_thread(s.buffer, thr) != ROCPROFILER_STATUS_SUCCESS) return -1;
+    if (!s.by_callback.load(std::memory_order_acquire)) {
+        constexpr size_t kBufBytes = 256 * 1024;
+        if (rocprofiler_create_buffer(s.ctx, kBufBytes, kBufBytes - kBufBytes / 8, ROCPROFILER_BUFFER_POLICY_LOSSLESS,
+                                      on_records, nullptr, &s.buffer) != ROCPROFILER_STATUS_SUCCESS)
+            return -1;
+        if (rocprofiler_configure_buffer_tracing_service(s.ctx, ROCPROFILER_BUFFER_TRACING_KERNEL_DISPATCH, nullptr, 0,
+                                                         s.buffer) != ROCPROFILER_STATUS_SUCCESS)
+            return -1;
+        if (count) {
+            rocprofiler_tracing_operation_t dops[] = {ROCPROFILER_KERNEL_DISPATCH_ENQUEUE};
+            if (rocprofiler_configure_callback_tracing_service(s.ctx, ROCPROFILER_CALLBACK_TRACING_KERNEL_DISPATCH, dops, 1,
+                                                               on_dispatch, nullptr) == ROCPROFILER_STATUS_SUCCESS)
+                s.counting.store(1, std::memory_order_release);
+            else
+                KT_DBG("tool_init: the ENQUEUE callback could not be configured; nvrx_ktrace_sync settles by flushing");
+        }
+        rocprofiler_callback_thread_t thr{};
+        if (rocprofiler_create_callback_thread(&thr) != ROCPROFILER_STATUS_SUCCESS) return -1;
+        if (rocprofiler_assign_callback_thread(s.buffer, thr) != ROCPROFILER_STATUS_SUCCESS) return -1;
+    }
+    KT_DBG(s.by_callback.load() ? "tool_init: dispatch service configured (completion callbacks)"
+                                : "tool_init: dispatch service configured (buffered records)");
     int valid = 0;
     if (rocprofiler_context_is_valid(s.names_ctx, &valid) != ROCPROFILER_STATUS_SUCCESS || !valid) return -1;
     if (rocprofiler_context_is_valid(s.ctx, &valid) != ROCPROFILER_STATUS_SUCCESS || !valid) return -1;
-    KT_DBG("tool_init: callback thread assigned, starting names context");
+    KT_DBG("tool_init: starting names context");
     if (rocprofiler_start_context(s.names_ctx) != ROCPROFILER_STATUS_SUCCESS) return -1;
     s.pump_enabled = !env_is("NVRX_KTRACE_PUMP", "0");
     s.ready.store(1, std::memory_order_release);
@@ -518,9 +601,25 @@ int flush_once(State &s) {
     return NVRX_KTRACE_OK;
 }
 
-// After a window closes: flush the SDK's buffer until every dispatch enqueued so far has arrived -- as the kernels
-// finish -- so the durations are in the rings long before anybody asks for a report.  Backs off from 100 us to 2 ms
-// and gives up after 5 s (a window whose kernels run longer is completed by the next kick or by nvrx_ktrace_sync).
+// Bring what has completed so far into the rings, on the calling thread: the inbox (callback delivery, and records fed
+// "through the inbox" by a test), else one flush of the SDK's buffer.  *got: records the inbox held.
+int gather_once(State &s, size_t *got = nullptr) {
+    const size_t n = drain_inbox(s);
+    if (got) *got = n;
+    if (s.ready.load(std::memory_order_acquire) && !s.by_callback.load(std::memory_order_acquire)) return flush_once(s);
+    return NVRX_KTRACE_OK;
+}
+
+bool inbox_waiting(State &s) {
+    std::lock_guard<std::mutex> il(s.in_mu);
+    return !s.inbox.empty();
+}
+
+// Keeps the rings current while the job trains on, so that a report finds (nearly) nothing left to wait for.
+// Callback delivery: while a window is open, and after it closes until every dispatch of it has arrived, the inbox is
+// drained every couple of milliseconds.  Buffer delivery: after a window closes the SDK's buffer is flushed until every
+// dispatch enqueued so far has arrived.  Backs off from 100 us to 2 ms (20 ms while an open window brings nothing) and
+// gives up on a CLOSED window after 5 s (kernels that run longer are completed by the next kick or by nvrx_ktrace_sync).
 void pump_main() {
     State &s = st();
     std::unique_lock<std::mutex> lk(s.pump_mu);
@@ -530,19 +629,25 @@ void pump_main() {
         lk.unlock();
         int pause_us = 100;
         const auto give_up = std::chrono::steady_clock::now() + std::chrono::seconds(5);
-        while (s.ready.load(std::memory_order_acquire) && outstanding(s) && std::chrono::steady_clock::now() < give_up) {
-            flush_once(s);
+        for (;;) {
+            const bool cb = s.by_callback.load(std::memory_order_acquire) != 0;
+            const bool open = cb && s.running.load(std::memory_order_acquire) != 0;
+            const bool due = outstanding(s) || (cb && inbox_waiting(s));
+            if (!s.ready.load(std::memory_order_acquire) || (!open && !due)) break;
+            if (!open && std::chrono::steady_clock::now() >= give_up) break;
+            gather_once(s);
             s.pump_flushes.fetch_add(1, std::memory_order_relaxed);
-            if (!outstanding(s)) break;
+            if (!open && !outstanding(s) && !(cb && inbox_waiting(s))) break;
             std::this_thread::sleep_for(std::chrono::microseconds(pause_us));
-            pause_us = std::min(pause_us * 2, 2000);
+            pause_us = std::min(pause_us * 2, (open && !due) ? 20000 : 2000);
         }
         lk.lock();
     }
 }
 
 void kick_pump(State &s) {
-    if (!s.pump_enabled || !s.counting.load(std::memory_order_acquire)) return;
+    if (!s.pump_enabled) return;
+    if (!s.by_callback.load(std::memory_order_acquire) && !s.counting.load(std::memory_order_acquire)) return;
     std::call_once(s.pump_once, [] { std::thread(pump_main).detach(); });
     {
         // (always: a pump that is just leaving its loop would otherwise miss this window; the lock is held for two stores
@@ -690,6 +795,7 @@ int nvrx_ktrace_start(void) {
     int active = 0;
     SDK_TRY(rocprofiler_context_is_active(s.ctx, &active));
     if (!active) SDK_TRY(rocprofiler_start_context(s.ctx));
+    if (s.by_callback.load(std::memory_order_acquire)) kick_pump(s);  // (the window is open: the inbox is looked after from now on)
     return NVRX_KTRACE_OK;
 }
 
@@ -700,13 +806,24 @@ int nvrx_ktrace_stop(void) {
     int active = 0;
     SDK_TRY(rocprofiler_context_is_active(s.ctx, &active));
     if (active) SDK_TRY(rocprofiler_stop_context(s.ctx));
-    if (outstanding(s)) kick_pump(s);
+    if (outstanding(s) || s.by_callback.load(std::memory_order_acquire)) kick_pump(s);
     return NVRX_KTRACE_OK;
 }
 
 int nvrx_ktrace_flush(void) {
     State &s = st();
-    if (!s.ready.load(std::memory_order_acquire)) return fail(NVRX_KTRACE_ERR_STATE, "kernel tracing is not set up");
+    const bool ready = s.ready.load(std::memory_order_acquire) != 0;
+    if (!ready || s.by_callback.load(std::memory_order_acquire)) {
+        // A completion callback may run a moment after the stream that launched the kernel reports it finished: drain until
+        // two looks in a row find the inbox empty.  (Not ready: only records fed by hand can be waiting.)
+        if (!ready && !inbox_waiting(s)) return fail(NVRX_KTRACE_ERR_STATE, "kernel tracing is not set up");
+        int empty = 0;
+        for (int i = 0; i < 50 && empty < 2; i++) {
+            empty = drain_inbox(s) ? 0 : empty + 1;
+            if (empty < 2 && ready) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+        return NVRX_KTRACE_OK;
+    }
     // A dispatch record is written by the SDK's completion handler, which may run a moment after the stream that
     // launched the kernel reports it finished: flush until two consecutive flushes bring nothing new.
     uint64_t last = ~0ull;
@@ -740,16 +857,18 @@ int nvrx_ktrace_sync(double timeout_s) {
     const auto t0 = std::chrono::steady_clock::now();
     int round = 0;
     for (;;) {
-        if (ready) {
-            int rc = flush_once(s);
-            if (rc < 0) return rc;
-        }
+        int rc = gather_once(s);  // (callback delivery: what the completion handler has left in the inbox; buffer: one SDK flush)
+        if (rc < 0) return rc;
         uint64_t m = missing();
         if (!m) return 0;
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (waited >= timeout_s) return (int)std::min<uint64_t>(m, 0x7FFFFFFF);
-        // the kernels are still running (or their completion handlers are): short pauses first, then 100 us
-        if (++round < 50)
+        // the kernels are still running (or their completion handlers are): a completion callback lags its stream by
+        // microseconds, so the first looks only yield (a sleep, however short, costs ~60 us of timer slack), then short
+        // pauses, then 100 us
+        if (++round < 64)
+            std::this_thread::yield();
+        else if (round < 114)
             std::this_thread::sleep_for(std::chrono::microseconds(10));
         else
             std::this_thread::sleep_for(std::chrono::microseconds(100));
@@ -798,6 +917,7 @@ uint64_t nvrx_ktrace_counter(int what) {
         case 9: return (uint64_t)s.counting.load();
         case 10: return s.rows_assigned.load();
         case 11: return s.blit_skipped.load();
+        case 12: return (uint64_t)s.by_callback.load();
         default: return 0;
     }
 }
@@ -842,10 +962,14 @@ int nvrx_ktrace_feed_kernel_name(uint64_t kernel_id, const char *name, int own) 
 }
 
 int nvrx_ktrace_feed(const nvrx_ktrace_dispatch *recs, int n, int counted) {
-    if (n < 0 || (n > 0 && !recs && !counted)) return fail(NVRX_KTRACE_ERR_INVALID, "bad records");
+    if (n < 0 || (n > 0 && !recs && !(counted & 1))) return fail(NVRX_KTRACE_ERR_INVALID, "bad records");
     State &s = st();
-    if (counted) s.enqueued.fetch_add((uint64_t)n, std::memory_order_relaxed);
-    if (recs) consume(recs, (size_t)n);
+    if (counted & 1) s.enqueued.fetch_add((uint64_t)n, std::memory_order_relaxed);
+    if (recs && (counted & 2)) {
+        for (int i = 0; i < n; i++) inbox_append(s, recs[i]);  // as the completion callback leaves them: somebody has to drain
+    } else if (recs) {
+        consume(recs, (size_t)n);
+    }
     return NVRX_KTRACE_OK;
 }
 

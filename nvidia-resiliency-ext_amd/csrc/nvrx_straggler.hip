@@ -1962,6 +1962,8 @@ struct nvrx_ctx {
     float *d_hist_min = nullptr;
 
     std::vector<uint64_t> total;  // samples ever pushed per row since the last reset
+    std::vector<uint8_t> occupied_seen;  // nvrx_ring_occupancy_changed: which rows held samples at the previous call
+    int occupied_rows = -1;              // ... over how many rows (-1: never asked)
     int rows_used = 0;            // rows of a logical rank handed out so far (nvrx_row_alloc)
     uint8_t *h_kinds = nullptr;   // pinned
     int32_t *h_gid = nullptr;     // pinned
@@ -2902,6 +2904,25 @@ int nvrx_ring_counts(const nvrx_ctx *ctx, int32_t *out, int n) {
     std::lock_guard<std::mutex> lk(const_cast<nvrx_ctx *>(ctx)->mu);  // (the kernel tracer's thread appends concurrently)
     for (int r = 0; r < n; r++) out[r] = (int32_t)std::min<uint64_t>(ctx->total[(size_t)r], (uint64_t)ctx->ring_cap);
     return NVRX_OK;
+}
+
+int nvrx_ring_occupancy_changed(nvrx_ctx *ctx, int n) {
+    if (!ctx) return fail(NVRX_ERR_INVALID, "ctx is null");
+    if (n < 0 || n > ctx->rows) return fail(NVRX_ERR_INVALID, "n %d outside [0,%d]", n, ctx->rows);
+    std::lock_guard<std::mutex> lk(ctx->mu);  // (the kernel tracer's thread appends concurrently)
+    int changed = ctx->occupied_rows != n;
+    if (changed) {
+        ctx->occupied_seen.assign((size_t)n, 0);
+        ctx->occupied_rows = n;
+    }
+    for (int r = 0; r < n; r++) {
+        const uint8_t now = ctx->total[(size_t)r] != 0;
+        if (ctx->occupied_seen[(size_t)r] != now) {
+            ctx->occupied_seen[(size_t)r] = now;
+            changed = 1;
+        }
+    }
+    return changed;
 }
 
 int nvrx_ring_reset(nvrx_ctx *ctx) {

@@ -69,6 +69,7 @@ SYMBOLS = [
     ("nvrx_ring_set_count_all", c_int, [c_void_p, c_int]),
     ("nvrx_ring_count", c_int, [c_void_p, c_int]),
     ("nvrx_ring_counts", c_int, [c_void_p, c_void_p, c_int]),
+    ("nvrx_ring_occupancy_changed", c_int, [c_void_p, c_int]),
     ("nvrx_ring_reset", c_int, [c_void_p]),
     ("nvrx_history_reset", c_int, [c_void_p, c_void_p]),
     ("nvrx_ring_flush", c_int, [c_void_p, c_void_p]),

@@ -555,6 +555,14 @@ class HipRings:
         _native.check(self.lib.nvrx_ring_counts(self.ctx, self._counts_buf.ctypes.data, n))
         return self._counts_buf[:n]
 
+    def occupancy_changed(self) -> bool:
+        """Whether the SET of used rows that hold samples differs from what the previous call saw (one C call, nothing
+        copied): the report's name tables are rebuilt only then."""
+        rc = self.lib.nvrx_ring_occupancy_changed(self.ctx, self._rows_used)
+        if rc < 0:
+            _native.check(rc)
+        return rc != 0
+
     def reset(self) -> None:
         _native.check(self.lib.nvrx_ring_reset(self.ctx))
 

@@ -99,7 +99,7 @@ SYMBOLS = [
     ("nvrx_ktrace_feed", c_int, [c_void_p, c_int, c_int]),
 ]
 COUNTERS = ("enqueued", "arrived", "delivered", "lost_no_row", "sink_errors", "own_skipped", "keys_without_row", "forgiven",
-            "pump_flushes", "counting", "rows_assigned", "blit_skipped")
+            "pump_flushes", "counting", "rows_assigned", "blit_skipped", "by_callback")
 
 _lib = None
 _lock = threading.Lock()
@@ -364,11 +364,12 @@ def key_name(key: int) -> str:
     return name.decode() if name else f"unknown_key_{key}"
 
 
-def feed(dispatches: np.ndarray, counted: bool = True) -> None:
-    """Hand ``DISPATCH_DTYPE`` records to the tracer's data path on the calling thread (``nvrx_ktrace_feed``): what the SDK's
-    callback thread does with a batch of dispatch records.  Tests and the benchmark's feeder thread."""
+def feed(dispatches: np.ndarray, counted: bool = True, through_inbox: bool = False) -> None:
+    """Hand ``DISPATCH_DTYPE`` records to the tracer's data path (``nvrx_ktrace_feed``): consumed on the calling thread, as
+    the tracer's own threads do with a batch -- or, ``through_inbox``, left in the inbox as the SDK's completion callback
+    leaves them, for the pump thread / the next ``harvest`` to bring in.  Tests and the benchmark's feeder thread."""
     a = np.ascontiguousarray(dispatches, dtype=DISPATCH_DTYPE)
-    _check(load().nvrx_ktrace_feed(a.ctypes.data, int(a.size), int(counted)))
+    _check(load().nvrx_ktrace_feed(a.ctypes.data, int(a.size), int(bool(counted)) | (2 if through_inbox else 0)))
 
 
 def feed_kernel_name(kernel_id: int, name: str, own: bool = False) -> None:
@@ -416,6 +417,8 @@ def _register_exit_hook() -> None:
 
 
 def _sync_patience_s() -> float:
+    """How long a report waits for the records of its window's kernels before it synchronises the device the reference's
+    way (``NVRX_KTRACE_SYNC_PATIENCE_S``, read when the profiler is built: a report does not look at the environment)."""
     try:
         return float(os.environ.get("NVRX_KTRACE_SYNC_PATIENCE_S", "2.0"))
     except ValueError:
@@ -450,6 +453,7 @@ class KernelTraceProfiler:
         self.keys_without_row = 0
         self._warned_leak = False
         self._counting = True  # dispatches are counted at enqueue (read back in initialize)
+        self.sync_patience_s = _sync_patience_s()
         # memsets / memcpys are not kernels to CUPTI; NVRX_KTRACE_BLITS=1 records ROCm's blit kernels all the same
         self._lib.nvrx_ktrace_include_blits(1 if os.environ.get("NVRX_KTRACE_BLITS", "0") == "1" else 0)
         # from now on the tracer's thread appends every kernel duration to these rings
@@ -534,7 +538,7 @@ class KernelTraceProfiler:
             import torch
 
             torch.cuda.synchronize()
-        missing = lib.nvrx_ktrace_sync(_sync_patience_s() if wait else 0.0)
+        missing = lib.nvrx_ktrace_sync(self.sync_patience_s if wait else 0.0)
         if missing < 0:
             _check(missing)
         if missing > 0 and wait:
@@ -544,7 +548,7 @@ class KernelTraceProfiler:
         return missing
 
     def _wait_the_long_way(self, missing: int) -> int:
-        """The kernels of the window are still running after ``NVRX_KTRACE_SYNC_PATIENCE_S`` (a long step, a collective
+        """The kernels of the window are still running after ``sync_patience_s`` (a long step, a collective
         waiting for a straggler) -- or a dispatch was counted and its record never came.  Wait for the device as the
         reference does, look again, and if records are STILL missing stop expecting them."""
         import torch

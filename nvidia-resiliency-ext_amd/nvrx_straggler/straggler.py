@@ -172,8 +172,8 @@ class Detector(metaclass=_DeviceSideOnDemand):
     # collaborators
     reporter: ReportGenerator
     report_interval_tracker: ReportIntervalTracker
-    # which rows held samples at the last report, and the name -> row tables derived from that
-    _occupied_key: Optional[bytes] = None
+    # the name -> row tables of the rows that held samples at the last report (and the rings they were derived from)
+    _occupied_key: Any = None
     _active_sections: Dict[str, int] = {}
     _active_kernels: Dict[str, int] = {}
     # the GPU-timing mode has been compared across the ranks of this process group (a token of the group, or None)
@@ -384,12 +384,11 @@ class Detector(metaclass=_DeviceSideOnDemand):
     def _report_and_reset(cls, rings, reporter):
         # which rows hold samples this window (one C call); the name tables are rebuilt only when
         # that set changes, so a steady-state report does no per-section Python work
-        occupied = (rings.counts() > 0).tobytes()
-        if occupied != cls._occupied_key:
+        if rings.occupancy_changed() or cls._occupied_key is not rings:
             counts = rings.counts()
             cls._active_sections = {n: sec.row for n, sec in cls.custom_sections.items() if counts[sec.row] > 0}
             cls._active_kernels = {k: row for k, row in rings.kernel_row_names.items() if counts[row] > 0}
-            cls._occupied_key = occupied
+            cls._occupied_key = rings  # (the tables belong to these rings: a re-initialised Detector starts over)
         order_after = _backend_mod.get_backend().current_stream_handle() if reporter.world_size > 1 else None
         report = reporter.generate_report_from_rings(rings, cls._active_sections, cls._active_kernels,
                                                      order_after=order_after)

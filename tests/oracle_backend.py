@@ -241,6 +241,12 @@ class OracleRings:
     def count(self, row, lr=0):
         return int(min(self.total[lr * self.rows_per_rank + row], self.ring_cap))
 
+    def occupancy_changed(self):
+        now = (self.total[: self.rows_used] > 0).tobytes()
+        changed = now != getattr(self, "_occupied_seen", None)
+        self._occupied_seen = now
+        return changed
+
     def reset(self):
         self.total[:] = 0
 

@@ -40,10 +40,11 @@ KHOST = os.path.join(REPO, "tests", "c_abi", "_build", "ktrace_host")
 
 
 def _need_ktrace_host(target="all", path=KHOST):
+    """``make`` every time (a no-op when up to date): a sanitizer build left over from an older source would check nothing."""
+    p = subprocess.run(["make", "-C", os.path.join(REPO, "tests", "c_abi"), target], capture_output=True, text=True)
     if not os.path.exists(path):
-        p = subprocess.run(["make", "-C", os.path.join(REPO, "tests", "c_abi"), target], capture_output=True, text=True)
-        if p.returncode != 0 or not os.path.exists(path):
-            pytest.skip(f"{path} is not built and could not be built here: " + (p.stderr or p.stdout)[-300:])
+        pytest.skip(f"{path} is not built and could not be built here: " + (p.stderr or p.stdout)[-300:])
+    assert p.returncode == 0, (p.stderr or p.stdout)[-1500:]
 
 
 def test_a_plain_c_host_with_threads_drives_the_kernel_tracer_abi():

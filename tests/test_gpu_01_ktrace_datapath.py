@@ -306,5 +306,5 @@ def test_tracer_soak_threads_streams_small_rings(asynchronous):
     assert out["entries"] > 200 and out["reports"] >= 5 and out["keys"] >= 8
     assert c["enqueued"] == c["arrived"] + c["forgiven"] and c["forgiven"] == 0, c
     assert c["sink_errors"] == 0 and c["lost_no_row"] == 0 and c["keys_without_row"] == 0, c
-    assert c["delivered"] + c["own_skipped"] == c["arrived"], c        # (no record with a zero timestamp on this path)
+    assert c["delivered"] + c["own_skipped"] + c["blit_skipped"] == c["arrived"], c        # (no record with a zero timestamp on this path; fills / copies the soak issues are ROCclr blit kernels: counted, not keys)
     assert 0 < out["kernel_samples_reported"] <= c["delivered"]         # (rings are 64 deep: windows with more launches keep the newest)

@@ -268,7 +268,7 @@ def test_harvest_waits_for_dispatches_that_are_still_running(profiler, monkeypat
     assert prof.get_stats.__self__ is prof and rings.count(0) == 0
     timer = threading.Timer(0.15, lambda: ktrace.feed(d, counted=False))
     timer.start()
-    monkeypatch.setenv("NVRX_KTRACE_SYNC_PATIENCE_S", "5")
+    prof.sync_patience_s = 5.0
     assert prof.harvest(wait=True) == 0               # blocks ~0.15 s in C, GIL released
     timer.join()
     assert prof.get_stats()["late_blk_1_1_1_grid_1_1_1"].num_calls == 2
@@ -278,11 +278,41 @@ def test_harvest_waits_for_dispatches_that_are_still_running(profiler, monkeypat
 
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     monkeypatch.setattr(ktrace.load(), "nvrx_ktrace_flush", lambda: 0, raising=False)
-    monkeypatch.setenv("NVRX_KTRACE_SYNC_PATIENCE_S", "0.05")
+    prof.sync_patience_s = 0.05
     assert lib.nvrx_ktrace_feed(None, 1, 1) == 0
     assert prof.harvest(wait=True) == 1
     assert ktrace.counters()["forgiven"] >= 1
     assert prof.harvest(wait=True) == 0
+
+
+def test_records_left_in_the_inbox_by_the_completion_callback_reach_the_rings_at_the_next_wait(profiler):
+    """Callback delivery (the default on a GPU): the SDK's completion handler only appends a finished dispatch to the
+    tracer's inbox; a look (``harvest(wait=False)``) leaves it there and reports the dispatches as missing, a wait
+    (``harvest(wait=True)`` -> ``nvrx_ktrace_sync``) drains it on the calling thread -- in arrival order, per key the newest
+    ``cap`` survive -- and so does ``nvrx_ktrace_flush``."""
+    cap = 8
+    prof, rings = profiler(4, cap)
+    ids = _fresh_kernel_ids(2).tolist()
+    for i, n in zip(ids, ("inbox_a", "inbox_b")):
+        ktrace.feed_kernel_name(i, n)
+    d = np.zeros(30, dtype=ktrace.DISPATCH_DTYPE)
+    d["kernel_id"] = [ids[i % 2] for i in range(30)]
+    d["workgroup"], d["grid"], d["start_ns"] = (64, 1, 1), (128, 1, 1), 1000
+    d["end_ns"] = 1000 + 1000 * np.arange(1, 31, dtype=np.uint64)
+    before = ktrace.counters()
+    ktrace.feed(d[:20], counted=True, through_inbox=True)
+    assert prof.harvest(wait=False) == 20                       # enqueued, completed, nobody has brought them in
+    assert ktrace.counters()["arrived"] == before["arrived"]
+    assert prof.harvest(wait=True) == 0
+    got = prof.get_stats()
+    assert got["inbox_a_blk_64_1_1_grid_2_1_1"].num_calls == cap and got["inbox_b_blk_64_1_1_grid_2_1_1"].num_calls == cap
+    row = rings.kernel_row_names["inbox_b_blk_64_1_1_grid_2_1_1"]
+    assert sorted(rings.samples[row].tolist()) == [float(v) for v in range(6, 21, 2)]     # the NEWEST eight of b's ten: 6 .. 20 us
+    # the flush entry (the reference's cuptiActivityFlushAll) drains as well
+    ktrace.feed(d[20:], counted=True, through_inbox=True)
+    assert ktrace.load().nvrx_ktrace_flush() == 0
+    assert prof.harvest(wait=False) == 0
+    assert ktrace.counters()["arrived"] - before["arrived"] == 30
 
 
 def test_without_a_sink_the_pending_queue_keeps_the_newest(monkeypatch):
