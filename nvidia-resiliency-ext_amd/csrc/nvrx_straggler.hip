@@ -1962,6 +1962,7 @@ struct nvrx_ctx {
     float *d_hist_min = nullptr;
 
     std::vector<uint64_t> total;  // samples ever pushed per row since the last reset
+    int rows_hi = 0;  // rows [rows_hi, rows) have never held a sample or been configured: a flush uploads counts / metadata below it only
     std::vector<uint8_t> occupied_seen;  // nvrx_ring_occupancy_changed: which rows held samples at the previous call
     int occupied_rows = -1;              // ... over how many rows (-1: never asked)
     int rows_used = 0;            // rows of a logical rank handed out so far (nvrx_row_alloc)
@@ -2186,6 +2187,13 @@ int wait_stage_buffer(StageBuf &b) {
     return NVRX_OK;
 }
 
+// Every writer of total[] / h_kinds[] / h_gid[] says which row it touched: the per-kernel rings are 4096 rows of which a
+// job uses tens, and a flush that fills and uploads 4096 counts per report was a third of the report's C call at cadence
+// (profiles/r06a_kernels_mode_breakdown.txt: 14-21 us "staged samples flushed").
+inline void touch_row(nvrx_ctx *ctx, int row) {
+    if (row >= ctx->rows_hi) ctx->rows_hi = row + 1;
+}
+
 int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, int rows_active = 0) {
     if (uniform_n) *uniform_n = -1;
     if (!ctx->stamp_streams.empty()) {
@@ -2216,14 +2224,15 @@ int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, in
         if (grc) return grc;
     }
     StageBuf &b = ctx->buf[ctx->cur];
-    for (int r = 0; r < ctx->rows; r++)
+    const int hi = ctx->rows_hi;  // (d_counts / d_kinds / d_gid above it still hold their initial values)
+    for (int r = 0; r < hi; r++)
         b.h_counts[r] = (uint32_t)std::min<uint64_t>(ctx->total[r], (uint64_t)ctx->ring_cap);
-    const int work = std::max(ctx->n_staged, ctx->rows);
+    const int work = std::max(ctx->n_staged, hi);
     const int threads = 256;
     const int blocks = (work + threads - 1) / threads;
     b.ticket = (b.ticket % 0x7FFFFFFFu) + 1u;
     hipLaunchKernelGGL(k_scatter, dim3(blocks), dim3(threads), 0, stream, b.h_counts, b.h_entries, ctx->n_staged,
-                       ctx->d_samples, ctx->row_stride, ctx->d_counts, ctx->rows,
+                       ctx->d_samples, ctx->row_stride, ctx->d_counts, hi,
                        ctx->meta_dirty ? ctx->h_kinds : nullptr, ctx->d_kinds,
                        ctx->meta_dirty ? ctx->h_gid : nullptr, ctx->d_gid, b.d_cnt, b.d_done, b.ticket);
     HIP_TRY(hipGetLastError());
@@ -2255,6 +2264,7 @@ inline int push_locked(nvrx_ctx *ctx, int row, float value) {
         ctx->stage_cnt[(size_t)row] = 0;
     }
     ctx->stage_cnt[(size_t)row]++;
+    touch_row(ctx, row);
     const uint32_t slot = (uint32_t)(ctx->total[row] % (uint64_t)ctx->ring_cap);
     StagedSample &e = ctx->buf[ctx->cur].h_entries[ctx->n_staged++];
     e.row_slot = ((uint32_t)row << 16) | slot;
@@ -2626,6 +2636,7 @@ int nvrx_row_configure(nvrx_ctx *ctx, int row, int kind, int gid) {
     if (ctx->h_kinds[row] != (uint8_t)kind || ctx->h_gid[row] != gid) {
         ctx->h_kinds[row] = (uint8_t)kind;
         ctx->h_gid[row] = gid;
+        touch_row(ctx, row);
         ctx->meta_dirty = true;
     }
     return NVRX_OK;
@@ -2644,6 +2655,7 @@ int nvrx_row_alloc(nvrx_ctx *ctx, int kind) {
             ctx->h_kinds[g] = (uint8_t)kind;
             ctx->h_gid[g] = -1;
             ctx->meta_dirty = true;
+            touch_row(ctx, (int)g);
         }
     }
     return row;
@@ -2723,6 +2735,7 @@ int nvrx_ring_push_pairs(nvrx_ctx *ctx, const int32_t *rows, const float *values
         if (r < 0) continue;
         if (r >= ctx->rows) return fail(NVRX_ERR_RANGE, "row %d out of range (%d rows)", (int)r, ctx->rows);
         ctx->bulk_cnt[(size_t)r]++;
+        touch_row(ctx, (int)r);
     }
     if (ctx->bulk_in_flight) {  // the previous call's scatter still reads the entry buffer
         int wrc = nvrx_poll_u32(const_cast<const uint32_t *>(ctx->bulk_word), ctx->bulk_ticket, stage_wait_s());
@@ -2809,6 +2822,7 @@ int nvrx_ring_push_device(nvrx_ctx *ctx, int row, const float *d_values, int n, 
         left -= chunk;
     }
     ctx->total[row] += (uint64_t)n;
+    touch_row(ctx, row);
     ctx->counts_dirty = true;
     return NVRX_OK;
 }
@@ -2858,6 +2872,7 @@ int nvrx_ring_push_device_rows(nvrx_ctx *ctx, int first_row, int n_rows, const f
         }
     }
     for (int r = 0; r < n_rows; r++) ctx->total[(size_t)(first_row + r)] += (uint64_t)n;
+    touch_row(ctx, first_row + n_rows - 1);
     ctx->counts_dirty = true;
     return NVRX_OK;
 }
@@ -2876,6 +2891,7 @@ int nvrx_ring_set_count(nvrx_ctx *ctx, int row, int n) {
     ctx->n_staged = kept;
     ctx->stage_cnt[(size_t)row] = 0;
     ctx->total[row] = (uint64_t)n;
+    touch_row(ctx, row);
     ctx->counts_dirty = true;
     return NVRX_OK;
 }
@@ -2887,6 +2903,7 @@ int nvrx_ring_set_count_all(nvrx_ctx *ctx, int n) {
     ctx->n_staged = 0;
     ctx->flush_gen++;
     std::fill(ctx->total.begin(), ctx->total.end(), (uint64_t)n);
+    ctx->rows_hi = ctx->rows;
     ctx->counts_dirty = true;
     return NVRX_OK;
 }
@@ -3159,10 +3176,12 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
         const uint64_t cap = (uint64_t)ctx->ring_cap;
         float *dst_gpu = ctx->d_samples + (size_t)row * (size_t)ctx->row_stride + (size_t)(ctx->total[(size_t)row] % cap);
         ctx->total[(size_t)row]++;
+        touch_row(ctx, row);
         float *dst_cpu = nullptr;
         if (cpu_row >= 0) {
             dst_cpu = ctx->d_samples + (size_t)cpu_row * (size_t)ctx->row_stride + (size_t)(ctx->total[(size_t)cpu_row] % cap);
             ctx->total[(size_t)cpu_row]++;
+            touch_row(ctx, cpu_row);
         }
         ctx->counts_dirty = true;
         hipStream_t st = as_stream(stream);
