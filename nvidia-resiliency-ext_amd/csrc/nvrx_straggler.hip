@@ -2227,7 +2227,7 @@ int flush_locked(nvrx_ctx *ctx, hipStream_t stream, int *uniform_n = nullptr, in
     const int hi = ctx->rows_hi;  // (d_counts / d_kinds / d_gid above it still hold their initial values)
     for (int r = 0; r < hi; r++)
         b.h_counts[r] = (uint32_t)std::min<uint64_t>(ctx->total[r], (uint64_t)ctx->ring_cap);
-    const int work = std::max(ctx->n_staged, hi);
+    const int work = std::max(std::max(ctx->n_staged, hi), 1);  // (nothing touched yet, e.g. a reset of fresh rings: the ticket is still stored)
     const int threads = 256;
     const int blocks = (work + threads - 1) / threads;
     b.ticket = (b.ticket % 0x7FFFFFFFu) + 1u;
