@@ -10,8 +10,10 @@ data is its own flag) and polls its own window until all rows of this epoch are 
 by all ranks so that either every rank gets a :class:`PeerAllGather` or none does.  It presents the interface of
 ``rccl_direct.DirectAllGather`` (``fn_address`` / ``comm_address`` for ``nvrx_report``, ``exchange``, ``close``).
 Only ranks of ONE node can share windows; multi-node groups stay on RCCL.  ``choose()`` picks between the two routes:
-``NVRX_EXCHANGE=rccl|peer|auto``.  The default is ``rccl``: the window route is OPT-IN until it has a committed run across
-real GPUs behind it (so far it has only run between processes sharing one device).  ``peer`` = the windows if their
+``NVRX_EXCHANGE=rccl|peer|auto``.  The default is neither (``c10d``: the job's own process group, see ``exchange_mode``):
+both in-stream routes are OPT-IN until they have a committed run across real GPUs behind them (so far the windows have only
+run between processes sharing one device, and ``ncclAllGather`` on our communicator with one rank).  ``rccl`` = the second
+communicator if its checked trial passes on every rank; ``peer`` = the windows if their
 checked trial passes on every rank, else RCCL; ``auto`` = both are built, each is timed and checked on a dummy row, the
 faster one that delivered the right table on every rank wins (a calm-state timing, so not reproducible run to run).
 The chosen route is logged once on rank 0.
@@ -162,15 +164,18 @@ def create(group=None, device_index: Optional[int] = None, timeout_s: float = 18
 
 
 def exchange_mode() -> str:
-    """``NVRX_EXCHANGE``: ``rccl`` (default) | ``peer`` | ``auto`` | ``c10d``.
+    """``NVRX_EXCHANGE``: ``c10d`` (default) | ``rccl`` | ``peer`` | ``auto``.
 
-    ``c10d`` is the conservative choice: no communicator of our own, the report's all-gather is a plain
+    ``c10d`` is the conservative choice and the default: no communicator of our own, the report's all-gather is a plain
     ``torch.distributed.all_gather_into_tensor`` on the JOB's process group, i.e. on the communicator and in the launch order
     of the job's own collectives (c10d serialises a group's collectives on its one RCCL stream).  It costs a c10d dispatch
     and two event hops per report; what it buys is that nothing of ours can be launched out of order against the job's
-    collectives ("two communicators")."""
-    mode = os.environ.get("NVRX_EXCHANGE", "") or "rccl"
-    return mode if mode in ("rccl", "peer", "auto", "c10d") else "rccl"
+    collectives ("two communicators").  The in-stream routes -- ``rccl`` (``ncclAllGather`` on a second
+    communicator, on the detector's stream, inside the report's one C call), ``peer`` (xGMI peer stores into IPC windows) and
+    ``auto`` (times and checks both, keeps the faster) -- are faster and OPT-IN: none of them has a committed run across
+    more than one real GPU yet (this pool's boxes have one), and a default must not be the route nobody has seen work."""
+    mode = os.environ.get("NVRX_EXCHANGE", "") or "c10d"
+    return mode if mode in ("rccl", "peer", "auto", "c10d") else "c10d"
 
 
 def trial_timeout_s() -> float:

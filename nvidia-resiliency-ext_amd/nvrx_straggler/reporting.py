@@ -893,11 +893,12 @@ class ReportGenerator:
         from . import peer_exchange, rccl_direct
 
         mode = peer_exchange.exchange_mode()
-        # NVRX_EXCHANGE=c10d on ANY rank keeps every rank on torch.distributed (the decision has to be the same everywhere:
+        # c10d (the default) on ANY rank keeps every rank on torch.distributed (the decision has to be the same everywhere:
         # building a communicator is collective)
         if not dist_utils.is_all_true(mode != "c10d", self.group):
             self._direct = None
-            self.exchange_info = {"route": "torch.distributed all-gather on the job's own process group (NVRX_EXCHANGE=c10d)"}
+            self.exchange_info = {"route": "torch.distributed all-gather on the job's own process group (NVRX_EXCHANGE=c10d, the "
+                                           "default; rccl | peer | auto select an in-stream route)", "mode": "c10d"}
             if self.rank == 0:
                 _LOG.info("straggler report exchange route: %s", self.exchange_info["route"])
             return

@@ -178,6 +178,9 @@ class Detector(metaclass=_DeviceSideOnDemand):
     _active_kernels: Dict[str, int] = {}
     # the GPU-timing mode has been compared across the ranks of this process group (a token of the group, or None)
     _mode_agreed: Any = None
+    # the job's common mode is region timing but this rank could not switch yet (a region was open): the reason, else None
+    _pending_region_switch: Optional[str] = None
+    _pending_switch_said: bool = False
 
     def __new__(cls):
         raise RuntimeError(f"class {cls.__name__} should not be instantiated")
@@ -224,6 +227,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
         cls._rings = cls._cupti_manager = None
         cls._device_side_args = (int(max_rows), capacity)
         cls._mode_agreed = None
+        cls._pending_region_switch, cls._pending_switch_said = None, False
         _log.info("nvrx straggler: GPU time of profile_cuda sections is measured per %s (mode '%s': %s)",
                   "kernel, by kernel name" if per_kernel else "profiled region", _ktrace.timing_mode(), _ktrace.mode_note())
 
@@ -274,13 +278,29 @@ class Detector(metaclass=_DeviceSideOnDemand):
             return
         why = ("another rank of this job cannot trace kernels (its HIP runtime was up before nvrx_straggler was imported, or "
                "the tracer could not register): all ranks time GPU work per profiled region")
+        # The agreement is ONE collective per group and is never repeated by a single rank (its peers hold the token and would
+        # pair a lone all-reduce with whatever collective they issue next).  What may have to wait is only this rank's own
+        # switch: a profiled region is open right now (a report called inside a section) -- it is applied, without any
+        # collective, as soon as a report finds no region open (_apply_pending_mode_switch).
+        cls._pending_region_switch = why
+        cls._apply_pending_mode_switch()
+
+    @classmethod
+    def _apply_pending_mode_switch(cls) -> None:
+        why = cls._pending_region_switch
+        if why is None:
+            return
         if cls.cupti_manager.switch_to_regions():
+            cls._pending_region_switch = None
             _ktrace.fall_back_to_regions(why)
             _log.warning("nvrx straggler: %s. GPU scores of THIS report window mix kernel keys and region keys and may be NaN; "
                          "later windows are consistent. Collectives inside profile_cuda sections now count into the region's "
                          "time: keep them outside, or fix the slow-starting rank (NVRX_GPU_TIMING=kernels makes it an error).", why)
-        else:
-            cls._mode_agreed = None  # a region is open on this rank: compare again at the next report
+        elif not cls._pending_switch_said:
+            cls._pending_switch_said = True
+            _log.warning("nvrx straggler: %s -- but a profiled region is open on this rank right now (generate_report was called "
+                         "inside a detection_section): this rank switches at the first report that finds none open; until then its "
+                         "GPU scores are NaN on the other ranks' reports.", why)
 
     @classmethod
     def shutdown(cls):
@@ -356,6 +376,8 @@ class Detector(metaclass=_DeviceSideOnDemand):
         rings = cls.rings
         reporter = cls.reporter
         manager = cls.cupti_manager
+        if cls._pending_region_switch is not None:
+            cls._apply_pending_mode_switch()
         if reporter.world_size > 1 or cls._mode_agreed is None:
             from . import dist_utils
 

@@ -635,6 +635,15 @@ def test_ranks_agree_on_one_gpu_timing_mode_at_their_first_collective_report():
     assert not any("all ranks time GPU work" in m for m in res[1]["log"])
 
 
+def test_a_rank_that_cannot_switch_yet_defers_its_switch_and_never_repeats_the_agreement_alone():
+    """``switch_to_regions()`` refused on rank 0 at the first report (a region open).  Exactly ONE
+    agreement all-reduce per rank over four reports; rank 0 switches at the third report, with no collective of its own."""
+    res = run_ranks(workers.detector_mode_agreement_deferred, 2)
+    assert res[0]["agreements"] == 1 and res[1]["agreements"] == 1, res
+    assert res[0]["refused"] == 2 and res[0]["switched"] == 1 and res[0]["mode"] == "stamp", res[0]
+    assert res[0]["pending_after"] == [True, True, False, False] and res[1]["pending_after"] == [False] * 4
+
+
 def test_c10d_exchange_route_is_taken_by_every_rank_when_one_asks_for_it():
     """``NVRX_EXCHANGE=c10d`` (the report's all-gather on the JOB's own process group, no communicator of ours) is a
     collective decision: one rank's environment is enough to keep every rank on it."""

@@ -675,10 +675,65 @@ def detector_mode_agreement(rank, world):
         Detector.shutdown()
 
 
+def detector_mode_agreement_deferred(rank, world):
+    """The same, but rank 0's switch cannot happen at the first report (a profiled region is open there): the comparison
+    must NOT be repeated by rank 0 alone (its lone all-reduce would pair with the peers' next collective) -- the
+    switch is applied, without any collective, at the first report that finds no region open.  ``dist.all_reduce`` calls with
+    an int32 tensor of two elements (the mode code and its negative) are counted on every rank."""
+    import torch.distributed as dist
+
+    from nvrx_straggler import Detector, ktrace
+
+    agreements = []
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        if t.dtype == torch.int32 and t.numel() == 2:
+            agreements.append(1)
+        return real_all_reduce(t, *a, **k)
+
+    import torch
+
+    dist.all_reduce = counting_all_reduce
+    Detector.initialize(scores_to_compute=["relative_perf_scores"], gather_on_rank0=True, node_name=f"host{rank}")
+    try:
+        switched, refused = [], []
+        region_open = [True]
+        if rank == 0:
+            ktrace._mode, ktrace._mode_note = "kernels", "forced by the test"
+            mgr = Detector.cupti_manager
+            mgr.per_kernel = True
+
+            def switch():
+                if region_open[0]:
+                    refused.append(1)
+                    return False
+                switched.append(1)
+                mgr.per_kernel = False
+                return True
+
+            mgr.switch_to_regions = switch
+        pending_after = []
+        for i in range(4):
+            for _ in range(4):
+                with Detector.detection_section("s", profile_cuda=False):
+                    time.sleep(0.001)
+            if i == 2:
+                region_open[0] = False     # from the third report on, no region is open at report time
+            Detector.generate_report()
+            pending_after.append(Detector._pending_region_switch is not None)
+        return {"agreements": len(agreements), "switched": len(switched), "refused": len(refused), "pending_after": pending_after,
+                "mode": ktrace.timing_mode()}
+    finally:
+        dist.all_reduce = real_all_reduce
+        ktrace._reset_mode_for_tests()
+        Detector.shutdown()
+
+
 def detector_c10d_route(rank, world):
-    """``NVRX_EXCHANGE=c10d`` in ONE rank's environment: every rank keeps the report's exchange on torch.distributed."""
-    if rank == 1:
-        os.environ["NVRX_EXCHANGE"] = "c10d"
+    """``NVRX_EXCHANGE=c10d`` in ONE rank's environment (the other one asks for the in-stream RCCL route by name): every rank
+    keeps the report's exchange on torch.distributed."""
+    os.environ["NVRX_EXCHANGE"] = "c10d" if rank == 1 else "rccl"
     from nvrx_straggler import Detector
 
     Detector.initialize(scores_to_compute=["relative_perf_scores"], gather_on_rank0=False, node_name=f"host{rank}")
