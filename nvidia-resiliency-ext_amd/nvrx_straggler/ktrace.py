@@ -18,9 +18,11 @@ every kernel enqueued in a section so far has finished and is in the rings -- th
 nobody has seen before turned up, their names (cold).  The statistics (mean-of-middles median, population stddev;
 CuptiProfiler.cpp:44-74) are computed by the same HIP kernel as every other row.
 
-The SDK only accepts tools before the HIP runtime initialises.  Importing ``nvrx_straggler`` registers the tool
-right away (``setup``) when the mode is ``kernels``; if HIP was initialised earlier the profiler raises with the
-advice to import the package first.  ``NVRX_KTRACE_AT_IMPORT=0`` defers the decision to ``Detector.initialize``.
+The SDK only accepts tools before the HIP runtime initialises.  In a job launched the ``torchrun`` way (``WORLD_SIZE`` in
+the environment, more than one rank) -- or with ``NVRX_GPU_TIMING=kernels`` -- importing ``nvrx_straggler`` registers the
+tool right away (``setup``); everywhere else the import touches nothing and the mode is settled at
+``Detector.initialize`` (``setup_from_env``).  If HIP was initialised earlier, ``auto`` falls back to region stamps and an
+explicit ``kernels`` raises with the advice to import the package first.
 """
 from __future__ import annotations
 
@@ -154,6 +156,26 @@ def release_env() -> None:
             os.environ.pop("ROCP_TOOL_LIBRARIES", None)
 
 
+def _release_env_when_hip_is_up() -> None:
+    """What registering leaves in the environment is taken back the moment this process' HIP runtime has come up (PyTorch runs
+    the queued call at the end of its lazy CUDA initialisation): before the job has built a communicator or started worker
+    threads, and also when no profiler is ever initialised (a rank that imports the package and never uses the detector used to
+    hand ``ROCPROFILER_REGISTER_FORCE_LOAD=1`` to every child it started).  The profiler's ``initialize`` does the same again,
+    which is then a no-op."""
+    def _quietly():
+        try:
+            release_env()
+        except Exception as e:  # noqa: BLE001  (never fail somebody's first CUDA call over housekeeping)
+            _log.debug("nvrx straggler: release_env failed: %s", e)
+
+    try:
+        import torch
+
+        torch.cuda._lazy_call(_quietly)
+    except Exception:  # noqa: BLE001  (a PyTorch without the hook: the profiler's initialize() releases)
+        pass
+
+
 def _check(rc: int) -> int:
     if rc < 0:
         msg = load().nvrx_ktrace_last_error()
@@ -201,6 +223,7 @@ def setup(max_pending: int = 0) -> None:
             if rc != ERR_UNSAFE:
                 _check(rc)
                 _setup_error, _setup_route = None, "force_configure"
+                _release_env_when_hip_is_up()
                 return
             msg = load().nvrx_ktrace_last_error()
             if _hip_is_up():  # (naming the library for the HIP runtime's start-up is pointless once it has started)
@@ -210,6 +233,7 @@ def setup(max_pending: int = 0) -> None:
                       "library for tools when HIP starts: seconds to minutes)", msg.decode() if msg else "tool-search guard refused")
         _name_in_tool_libraries()
         _setup_error, _setup_route = None, "ROCP_TOOL_LIBRARIES"
+        _release_env_when_hip_is_up()
     except RuntimeError as e:
         _setup_error = str(e)
         raise
@@ -261,7 +285,7 @@ def timing_mode() -> str:
     """How ``profile_cuda=True`` sections measure GPU time in this process: ``stamp`` | ``event`` | ``kernels``.
 
     ``NVRX_GPU_TIMING`` names it outright.  Unset (or ``auto``) it is decided ONCE, the first time anybody asks -- at
-    ``import nvrx_straggler`` (``NVRX_KTRACE_AT_IMPORT=0``: at ``Detector.initialize``):
+    ``import nvrx_straggler`` when ``WORLD_SIZE`` is in the environment, else at ``Detector.initialize`` (``setup_from_env``):
 
     * a process of a multi-rank job (``WORLD_SIZE`` > 1 in the environment, what ``torchrun`` and every launcher that
       follows its convention exports; without it srun's, mpirun's or a PMI launcher's job size) gets ``kernels`` -- the reference's data model (CuptiProfiler.cpp:168-207): the GPU
@@ -333,11 +357,24 @@ def _reset_mode_for_tests() -> None:
 
 
 def setup_from_env() -> None:
-    """Import-time hook: settle the timing mode, which registers the tracer when the mode is ``kernels`` (it has to
-    happen before anything touches HIP; errors of an explicitly requested mode surface at first use).
-    ``NVRX_KTRACE_AT_IMPORT=0`` leaves it to ``Detector.initialize`` -- nothing of the SDK is touched by the import then
-    (and the mode becomes ``stamp`` if HIP is up by that time)."""
-    if os.environ.get("NVRX_KTRACE_AT_IMPORT", "1") != "0":
+    """Import-time hook.  rocprofiler-sdk accepts tools only BEFORE the process' HIP runtime starts, so a multi-rank job that
+    is to trace kernels by name has to register early; but an import should not reconfigure a process that never uses the
+    detector.  The rule:
+
+    * ``WORLD_SIZE`` is in the environment (``torchrun`` and every launcher that follows its convention), or
+      ``NVRX_GPU_TIMING=kernels`` asks for the mode by name: the mode is settled NOW -- for a job of more than one rank that
+      registers the tracer (``timing_mode``); scripts typically select their GPU right after the imports, and by
+      ``Detector.initialize`` it would be too late;
+    * otherwise (single process; ``srun`` / ``mpirun`` / PMI launchers without ``WORLD_SIZE``) NOTHING is touched by the
+      import: the mode is settled at ``Detector.initialize``.  Such a job gets per-kernel tracing if the detector is
+      initialised before the first HIP call (as the reference's own example does, examples/straggler/example.py:60-66), region
+      stamps otherwise -- or set ``NVRX_KTRACE_AT_IMPORT=1``.
+
+    ``NVRX_KTRACE_AT_IMPORT=0`` defers in every case, ``=1`` settles at import in every case."""
+    when = os.environ.get("NVRX_KTRACE_AT_IMPORT", "")
+    if when == "0":
+        return
+    if when == "1" or "WORLD_SIZE" in os.environ or os.environ.get("NVRX_GPU_TIMING", "").strip().lower() == "kernels":
         timing_mode()
 
 

@@ -901,6 +901,12 @@ class ReportGenerator:
                                            "default; rccl | peer | auto select an in-stream route)", "mode": "c10d"}
             if self.rank == 0:
                 _LOG.info("straggler report exchange route: %s", self.exchange_info["route"])
+                if self.asynchronous:
+                    # torch.distributed's collective is issued by the host, between the statistics and the score kernel: a
+                    # report on this route is complete when generate_report returns, whatever `asynchronous` says
+                    _LOG.warning("nvrx straggler: asynchronous=True has no effect on the default exchange route (c10d: the report's "
+                                 "all-gather is a torch.distributed call on the job's process group, and generate_report() waits for "
+                                 "the scores); NVRX_EXCHANGE=rccl | peer | auto selects an in-stream route whose reports are only enqueued")
             return
         maker = getattr(be, "create_direct_exchange", None)  # a test backend may bring its own in-call exchange
         if maker is not None:
@@ -934,6 +940,14 @@ class ReportGenerator:
             return self._direct.exchange(ws, be)
         with be.stream_context():  # the collective must queue behind the statistics kernel
             return dist_utils.all_gather_rows(ws.send, ws.table, self.group)
+
+    def enqueue_only(self) -> bool:
+        """Whether a steady-state ring report of this generator is only ENQUEUED (``asynchronous=True`` and nothing on the way
+        needs the host: a single process, no exchange, or an in-stream exchange route).  On torch.distributed's route the
+        collective is issued by the host between the two kernels and the report waits, whatever ``asynchronous`` says."""
+        if not self.asynchronous:
+            return False
+        return self.world_size == 1 or not self._exchanged() or self._direct is not None or not self._direct_tried
 
     def take_unreported_rows(self) -> list:
         """Ring rows that held samples at the last ``generate_report_from_rings`` but were in no report (an asynchronous
@@ -1255,7 +1269,7 @@ class ReportGenerator:
                 return out
             self._ring_plan = None
             resync_first = True  # some OTHER rank met a new name during this report's exchange
-        elif (plan is not None and self.asynchronous and plan.fused and plan.key[6:8] == key[6:8] and plan.key[9:] == key[9:]
+        elif (plan is not None and self.enqueue_only() and plan.fused and plan.key[6:8] == key[6:8] and plan.key[9:] == key[9:]
               and not plan.mapper.has_all_names(list(kernel_rows.keys()), list(section_rows.keys()))):
             # asynchronous + a name this rank has no id for: the other ranks will not wait inside this report, so the
             # name exchange cannot happen now.  Run the OLD plan (the new rows are not exchanged yet) with the

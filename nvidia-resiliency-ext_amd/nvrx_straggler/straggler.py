@@ -391,7 +391,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
         # every kernel enqueued inside a section so far has finished and its duration is in its ring (one C call; the
         # tracer's thread has been appending them all along) -- an ASYNCHRONOUS report does not wait even for that:
         # durations that arrive later count in the next window
-        if manager.per_kernel and reporter.asynchronous:
+        if manager.per_kernel and reporter.enqueue_only():
             # ... and what arrives from here to the ring reset below stays with the tracer's thread until then
             manager.cupti_ext.hold(True)
             try:
@@ -414,7 +414,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
         order_after = _backend_mod.get_backend().current_stream_handle() if reporter.world_size > 1 else None
         report = reporter.generate_report_from_rings(rings, cls._active_sections, cls._active_kernels,
                                                      order_after=order_after)
-        keep = reporter.take_unreported_rows() if reporter.asynchronous else None
+        keep = reporter.take_unreported_rows() if reporter.asynchronous else None  # (empty unless the report was enqueued on old tables)
         if keep:
             # an asynchronous report that met names it has no ids for ran on the old tables (the ranks sync names at the next
             # report): the samples of those rows were in nobody's report and stay for the next window

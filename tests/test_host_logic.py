@@ -702,12 +702,31 @@ def test_config2_loop_ten_reports_match_reference():
     assert all(not f for f in flagged[:5]) and all(set(f) == {f"section_{s:03d}" for s in range(4)} for f in flagged[5:])
 
 
+def test_asynchronous_detector_on_the_default_c10d_route_reports_like_a_synchronous_one():
+    """The default exchange route is torch.distributed on the job's own group: a host-issued collective, so a multi-rank
+    report is complete when ``generate_report`` returns even with ``asynchronous=True`` (said once in the log).  Same reports,
+    same name ids, as the synchronous run -- the new name enters AT report 3, not one report later."""
+    kw = dict(backend_kwargs={"emulate_fused": True})
+    sync = run_ranks(workers.detector_async_sequence, 2, asynchronous=False, **kw)
+    asyn = run_ranks(workers.detector_async_sequence, 2, asynchronous=True, **kw)
+    assert asyn[0]["ids"] == sync[0]["ids"] and asyn[1]["ids"] == sync[1]["ids"]
+    for t in range(6):
+        a, s = asyn[0]["reports"][t], sync[0]["reports"][t]
+        assert set(a["section_relative_perf_scores"]) == set(s["section_relative_perf_scores"]), t
+        for n, per_rank in s["section_relative_perf_scores"].items():
+            for r, v in per_rank.items():
+                w = a["section_relative_perf_scores"][n][r]
+                assert (np.isnan(v) and np.isnan(w)) or abs(v - w) < 1e-6, (t, n, r, v, w)
+
+
 @pytest.mark.parametrize("world", [1, 2, 4])
 def test_asynchronous_reports_match_synchronous_ones_and_defer_new_names(world):
     """Asynchronous reports (enqueue now, wait on first read): same scores as the synchronous run for every report;
     a section that ONE rank meets at report 3 enters at report 4, after the name sync every rank runs at the start of
     that report (the synchronous run has it at report 3 already)."""
-    kw = dict(backend_kwargs={"emulate_fused": True})
+    # (an in-stream exchange route, which asynchronous multi-rank reports need: on the default route -- c10d, a host-driven
+    #  collective on the job's group -- a report waits, see the next test)
+    kw = dict(backend_kwargs={"emulate_fused": True}, env={"NVRX_EXCHANGE": "rccl"})
     sync = run_ranks(workers.detector_async_sequence, world, asynchronous=False, **kw)
     asyn = run_ranks(workers.detector_async_sequence, world, asynchronous=True, **kw)
     late = "late_rank1_only"
