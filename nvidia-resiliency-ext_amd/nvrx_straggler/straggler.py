@@ -181,6 +181,15 @@ class Detector(metaclass=_DeviceSideOnDemand):
     # the job's common mode is region timing but this rank could not switch yet (a region was open): the reason, else None
     _pending_region_switch: Optional[str] = None
     _pending_switch_said: bool = False
+    # per-kernel tracing budget (kernel_trace_budget_pct, see initialize and _calibration_mark): kernels are traced on every
+    # (profiling_interval x _trace_every)-th entry of a profile_cuda section; while the cost is being measured _trace_gate
+    # switches tracing on and off iteration by iteration
+    kernel_trace_budget_pct: float = 0.0
+    kernel_trace_cost_pct: Optional[float] = None   # what the calibration measured (None: not measured)
+    _trace_every: int = 1
+    _trace_gate: bool = True
+    _trace_sparse: bool = False                      # fast check in detection_section: gate closed or _trace_every > 1
+    _calib: Any = None                               # (marks, flags) while measuring, else None
 
     def __new__(cls):
         raise RuntimeError(f"class {cls.__name__} should not be instantiated")
@@ -196,6 +205,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
         node_name: Optional[str] = None,
         max_rows: int = 256,
         asynchronous: Optional[bool] = None,
+        kernel_trace_budget_pct: Optional[float] = None,
     ):
         """
         Args:
@@ -209,6 +219,17 @@ class Detector(metaclass=_DeviceSideOnDemand):
                 ``Report`` that waits for the device when it is first read, so the training loop never stalls on a
                 report (see ``ReportGenerator``).  Default: the ``NVRX_ASYNC_REPORT`` environment variable, else
                 False = the reference's synchronous behaviour.
+            kernel_trace_budget_pct: per-kernel tracing only (``ktrace.timing_mode() == "kernels"``).  The share of a training
+                iteration that tracing every kernel of the profiled sections may cost.  rocprofiler-sdk adds about a
+                microsecond to every traced dispatch, which on a step of hundreds of small kernels is more than the
+                reference's "< 1 %" (docs/source/straggler_det/usage_guide.rst:169).  With a budget, the first 16 iterations
+                seen by ``generate_report_if_interval_elapsed`` -- the ones the interval tracker times anyway
+                (interval_tracker.py:35,58-72) -- alternate between tracing and not tracing; if the traced ones are slower
+                by more than the budget, kernels are traced on every (profiling_interval x N)-th entry only, N the smallest
+                multiple that fits, the LARGEST N over the ranks (one all-reduce), logged once.  Section wall times are
+                still recorded at ``profiling_interval``.  Default: ``NVRX_KTRACE_BUDGET_PCT``, else 1.0; 0 = trace at
+                ``profiling_interval`` whatever it costs (the reference's behaviour).  Jobs that call ``generate_report``
+                themselves never calibrate.
         """
         assert not cls.initialized
         _backend_mod.require_engine()  # no silent CPU path: a box that cannot run the engine says so here
@@ -228,6 +249,15 @@ class Detector(metaclass=_DeviceSideOnDemand):
         cls._device_side_args = (int(max_rows), capacity)
         cls._mode_agreed = None
         cls._pending_region_switch, cls._pending_switch_said = None, False
+        if kernel_trace_budget_pct is None:
+            try:
+                kernel_trace_budget_pct = float(os.environ.get("NVRX_KTRACE_BUDGET_PCT", "1.0"))
+            except ValueError:
+                kernel_trace_budget_pct = 1.0
+        cls.kernel_trace_budget_pct = max(0.0, float(kernel_trace_budget_pct))
+        cls.kernel_trace_cost_pct = None
+        cls._trace_every, cls._trace_gate, cls._trace_sparse = 1, True, False
+        cls._calib = ([], []) if (per_kernel and cls.kernel_trace_budget_pct > 0.0) else None
         _log.info("nvrx straggler: GPU time of profile_cuda sections is measured per %s (mode '%s': %s)",
                   "kernel, by kernel name" if per_kernel else "profiled region", _ktrace.timing_mode(), _ktrace.mode_note())
 
@@ -238,6 +268,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
                                        node_name=node_name or socket.gethostname(), asynchronous=asynchronous)
         cls.report_interval_tracker = ReportIntervalTracker(time_interval=report_time_interval,
                                                             profiling_interval=profiling_interval)
+        cls.report_interval_tracker.also_max = cls._trace_every_needed  # (the tracing budget's number rides on the tracker's all-reduce)
         cls.initialized = True
 
     @classmethod
@@ -292,6 +323,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
             return
         if cls.cupti_manager.switch_to_regions():
             cls._pending_region_switch = None
+            cls._calib, cls._trace_every, cls._trace_gate, cls._trace_sparse = None, 1, True, False  # (region stamps cost next to nothing)
             _ktrace.fall_back_to_regions(why)
             _log.warning("nvrx straggler: %s. GPU scores of THIS report window mix kernel keys and region keys and may be NaN; "
                          "later windows are consistent. Collectives inside profile_cuda sections now count into the region's "
@@ -432,8 +464,72 @@ class Detector(metaclass=_DeviceSideOnDemand):
         iteration interval has elapsed, otherwise returns None."""
         assert cls.initialized
         tracker = cls.report_interval_tracker
+        if cls._calib is not None:
+            cls._calibration_mark()
         tracker.iter_increase()
+        if cls._calib is not None and tracker.iter_interval is not None:
+            cls._calibration_done(tracker.agreed_also)
         return cls.generate_report() if tracker.is_interval_elapsed() else None
+
+    # ---- per-kernel tracing budget -----------------------------------------------------------------
+    _MAX_TRACE_EVERY = 64
+
+    @classmethod
+    def _calibration_mark(cls) -> None:
+        """One call per training iteration while the cost of tracing is being measured -- the interval tracker's 16 timed
+        iterations: iterations alternate between tracing the kernels of their profiled sections and not tracing, each one's
+        wall time is the distance between two of these calls."""
+        marks, flags = cls._calib
+        marks.append(time.monotonic())
+        on = len(marks) % 2 == 1  # the iteration that starts now: traced after marks 1, 3, 5 ...
+        flags.append(on)
+        cls._trace_gate = on
+        cls._trace_sparse = (not on) or cls._trace_every > 1
+
+    @classmethod
+    def _trace_every_needed(cls) -> float:
+        """What the interval tracker's all-reduce carries for this rank (``ReportIntervalTracker.also_max``): the multiple of
+        ``profiling_interval`` at which tracing fits the budget, from the medians of the traced and the untraced iterations."""
+        if cls._calib is None:
+            return 1.0
+        marks, flags = cls._calib
+        steps = [b - a for a, b in zip(marks, marks[1:])]
+        t_on = sorted(t for t, f in zip(steps, flags) if f)
+        t_off = sorted(t for t, f in zip(steps, flags) if not f)
+        cls.kernel_trace_cost_pct = None
+        if not t_on or not t_off:
+            return 1.0
+        if cls.profiling_interval == 1:
+            m_on, m_off = t_on[(len(t_on) - 1) // 2], t_off[(len(t_off) - 1) // 2]  # lower medians, as the tracker's
+        else:
+            # only every profiling_interval-th entry is traced at all, so only some of the "traced" iterations carry the cost:
+            # the average is what a step pays (less robust than a median; the default interval is 1)
+            m_on, m_off = sum(t_on) / len(t_on), sum(t_off) / len(t_off)
+        if m_off <= 0.0:
+            return 1.0
+        cost = cls.kernel_trace_cost_pct = (m_on - m_off) / m_off * 100.0
+        if cost <= cls.kernel_trace_budget_pct:
+            return 1.0
+        return float(min(cls._MAX_TRACE_EVERY, int(-(-cost // cls.kernel_trace_budget_pct))))
+
+    @classmethod
+    def _calibration_done(cls, agreed: Optional[float]) -> None:
+        """The ranks take the LARGEST multiple any of them needs (kernel summaries are compared across ranks: they should
+        cover the same share of the entries); it came back with the interval tracker's own all-reduce."""
+        mine = int(cls._trace_every_needed())
+        cost, n = cls.kernel_trace_cost_pct, len(cls._calib[0]) - 1
+        cls._calib = None
+        every = max(1, min(cls._MAX_TRACE_EVERY, int(agreed))) if agreed else mine
+        cls._trace_every, cls._trace_gate = every, True
+        cls._trace_sparse = every > 1
+        total = cls.profiling_interval * every
+        _log.info("nvrx straggler: tracing the kernels of the profiled sections costs this rank %s of an iteration at "
+                  "profiling_interval=%d (%s of %d iterations with and %d without); budget %.2f %%: kernels are traced on every "
+                  "%d%s entry of a profile_cuda section%s", "%.2f %%" % cost if cost is not None else "an unmeasured share",
+                  cls.profiling_interval, "medians" if cls.profiling_interval == 1 else "means", (n + 1) // 2, n // 2,
+                  cls.kernel_trace_budget_pct, total,
+                  {1: "st", 2: "nd", 3: "rd"}.get(total if total < 20 else total % 10, "th"),
+                  "" if every == mine else " (another rank needed the larger interval)")
 
     @classmethod
     def is_interval_elapsed(cls) -> bool:
@@ -481,6 +577,10 @@ class Detector(metaclass=_DeviceSideOnDemand):
             yield
             return
 
+        if profile_cuda and cls._trace_sparse:
+            # the tracing budget (initialize: kernel_trace_budget_pct): this entry's wall time is recorded, its kernels are traced
+            # only on every (profiling_interval x _trace_every)-th entry -- and not at all in the untraced calibration iterations
+            profile_cuda = cls._trace_gate and ((section.total_entry_cnt - 1) // cls.profiling_interval) % cls._trace_every == 0
         if profile_cuda:
             cls.cupti_manager.start_profiling(GPU_KEY_PREFIX + name)
         t0 = time.perf_counter_ns()

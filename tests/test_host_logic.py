@@ -644,6 +644,40 @@ def test_a_rank_that_cannot_switch_yet_defers_its_switch_and_never_repeats_the_a
     assert res[0]["pending_after"] == [True, True, False, False] and res[1]["pending_after"] == [False] * 4
 
 
+def test_kernel_trace_budget_thins_tracing_until_it_fits_and_the_ranks_agree():
+    """``Detector.initialize(kernel_trace_budget_pct=...)``: the interval tracker's 16 timed iterations alternate between
+    tracing and not tracing; rank 0's tracing costs 3 ms on a 12 ms step (25 %), rank 1's nothing.  Budget 5 %: rank 0 needs
+    every 5th-6th entry, rank 1 every entry -- both adopt the LARGER interval, carried by the tracker's own all-reduce (no
+    collective of the detector's).  Section wall times are still recorded for every entry."""
+    res = run_ranks(workers.detector_trace_budget, 2, cost_ms_by_rank=[3.0, 0.0], budget_pct=5.0, timeout=240)
+    r0, r1 = res
+    assert r0["every"] == r1["every"] and 4 <= r0["every"] <= 7, (r0["every"], r1["every"], r0["cost_pct"], r1["cost_pct"])
+    assert 15.0 < r0["cost_pct"] < 40.0 and abs(r1["cost_pct"]) < 5.0, (r0["cost_pct"], r1["cost_pct"])
+    assert r0["iter_interval"] == r1["iter_interval"] and r0["iter_interval"] > 1000     # (3600 s / ~13 ms)
+    for r in (r0, r1):
+        every = r["every"]
+        cal = [e for e in r["traced"] if e <= 16]
+        after = [e for e in r["traced"] if e > 17]
+        assert cal == [0, 1, 3, 5, 7, 9, 11, 13, 15], r["traced"]                         # iteration 0, then every other one
+        assert after and all(e % every == 0 for e in after) and len(after) == len([e for e in range(18, 40) if e % every == 0]), r["traced"]
+        assert r["cpu_samples"] == 40
+        assert len(r["log"]) == 1 and "budget 5.00 %" in r["log"][0]
+    assert "another rank needed" in r1["log"][0] and "another rank" not in r0["log"][0]
+
+
+def test_kernel_trace_budget_zero_or_cheap_tracing_changes_nothing():
+    """Budget 0 (the reference's behaviour: trace at ``profiling_interval`` whatever it costs) never calibrates; a budget that
+    the measured cost fits leaves every profiled entry traced."""
+    (off,) = run_ranks(workers.detector_trace_budget, 1, cost_ms_by_rank=[2.0], budget_pct=0.0, iters=24)
+    assert off["every"] == 1 and off["cost_pct"] is None and off["traced"] == list(range(24)) and not off["log"]
+    (fits,) = run_ranks(workers.detector_trace_budget, 1, cost_ms_by_rank=[0.0], budget_pct=10.0, iters=24)
+    assert fits["every"] == 1 and fits["traced"][-6:] == list(range(18, 24)) and len(fits["log"]) == 1
+    # with profiling_interval=3 the multiple applies to the PROFILED entries: every (3 x N)-th entry is traced
+    (thin,) = run_ranks(workers.detector_trace_budget, 1, cost_ms_by_rank=[9.0], budget_pct=10.0, iters=60, profiling_interval=3)
+    n = thin["every"]
+    assert n >= 2 and all(e % (3 * n) == 0 for e in thin["traced"] if e > 17) and thin["cpu_samples"] == 20, thin
+
+
 def test_c10d_exchange_route_is_taken_by_every_rank_when_one_asks_for_it():
     """``NVRX_EXCHANGE=c10d`` (the report's all-gather on the JOB's own process group, no communicator of ours) is a
     collective decision: one rank's environment is enough to keep every rank on it."""

@@ -730,6 +730,58 @@ def detector_mode_agreement_deferred(rank, world):
         Detector.shutdown()
 
 
+def detector_trace_budget(rank, world, cost_ms_by_rank, budget_pct, step_ms=12.0, iters=40, profiling_interval=1):
+    """Per-kernel mode emulated at the profiler's surface (the tracer itself needs a GPU): ``start()`` of the profiler costs
+    this rank ``cost_ms_by_rank[rank]`` -- what tracing the section's kernels costs -- and a step sleeps ``step_ms``.  The loop
+    is the reference's (one section per iteration, ``generate_report_if_interval_elapsed`` after it).  Returns what the
+    calibration decided and which entries were traced."""
+    import logging
+
+    from nvrx_straggler import Detector, ktrace
+
+    traced = []
+    records = []
+
+    class _Grab(logging.Handler):
+        def emit(self, record):
+            records.append(record.getMessage())
+
+    log = logging.getLogger("nvrx_straggler.straggler")
+    log.addHandler(_Grab())
+    log.setLevel(logging.INFO)
+    cost = cost_ms_by_rank[rank] / 1e3
+    KP = ktrace.KernelTraceProfiler
+    saved = (ktrace._mode, ktrace._mode_note, ktrace._setup_error, ktrace.setup, KP._ensure_ready, KP.start, KP.stop)
+    ktrace._mode, ktrace._mode_note, ktrace._setup_error = "kernels", "forced by the test", None
+    ktrace.setup = lambda *a, **k: None
+    KP._live = None
+    KP._ensure_ready = lambda self: None
+
+    def start(self, key=""):
+        self._started = True
+        traced.append(Detector.custom_sections["train_step"].total_entry_cnt - 1)
+        time.sleep(cost)
+
+    KP.start = start
+    KP.stop = lambda self, *a: (setattr(self, "_started", False), False)[1]
+    Detector.initialize(scores_to_compute=["relative_perf_scores"], gather_on_rank0=True, node_name=f"host{rank}",
+                        report_time_interval=3600.0, kernel_trace_budget_pct=budget_pct, profiling_interval=profiling_interval)
+    try:
+        for _ in range(iters):
+            with Detector.detection_section("train_step", profile_cuda=True):
+                time.sleep(step_ms / 1e3)
+            assert Detector.generate_report_if_interval_elapsed() is None
+        return {"every": Detector._trace_every, "cost_pct": Detector.kernel_trace_cost_pct, "traced": traced,
+                "cpu_samples": len(Detector.custom_sections["train_step"].cpu_elapsed_times),
+                "iter_interval": Detector.report_interval_tracker.iter_interval,
+                "log": [m for m in records if "budget" in m]}
+    finally:
+        Detector.shutdown()
+        (ktrace._mode, ktrace._mode_note, ktrace._setup_error, ktrace.setup, KP._ensure_ready, KP.start, KP.stop) = saved
+        KP._live = None
+        ktrace._reset_mode_for_tests()
+
+
 def detector_c10d_route(rank, world):
     """``NVRX_EXCHANGE=c10d`` in ONE rank's environment (the other one asks for the in-stream RCCL route by name): every rank
     keeps the report's exchange on torch.distributed."""
