@@ -427,12 +427,22 @@ def _kernels_mode_child(mode: str = "kernels"):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps
 
-    def overhead_legs(interval, steps, rounds):
-        Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="node0", profiling_interval=interval)
+    def overhead_legs(interval, steps, rounds, budget=0.0):
+        """``budget`` 0: kernels traced on every ``interval``-th entry whatever it costs (the reference's behaviour); None: the
+        package's default (``kernel_trace_budget_pct`` 1.0) -- the loop then calls ``generate_report_if_interval_elapsed()``
+        after every step, as the reference's example and the PTL callback do, so that the first 17 iterations calibrate."""
+        Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="node0", profiling_interval=interval,
+                            **({} if budget is None else {"kernel_trace_budget_pct": budget}))
         try:
             def with_section():
                 with Detector.detection_section("train_step", profile_cuda=True):
                     train_step()
+                if budget is None:
+                    Detector.generate_report_if_interval_elapsed()   # (one report per 60 s: none inside the timed blocks)
+
+            if budget is None:
+                for _ in range(20):
+                    with_section()                                   # the interval tracker's 16 timed iterations: tracing on / off
 
             def with_report():
                 with_section()
@@ -440,10 +450,12 @@ def _kernels_mode_child(mode: str = "kernels"):
 
             for _ in range(3):
                 with_report()
-            c0 = ktrace.counters()
-            with_section()
-            Detector.cupti_manager.harvest(wait=True)
-            dispatches = ktrace.counters()["enqueued"] - c0["enqueued"]
+            dispatches = 0
+            for _ in range(interval * Detector._trace_every):        # (one of these entries is a traced one)
+                c0 = ktrace.counters()
+                with_section()
+                Detector.cupti_manager.harvest(wait=True)
+                dispatches = max(dispatches, ktrace.counters()["enqueued"] - c0["enqueued"])
             Detector.generate_report()
             legs = [("without", train_step), ("section", with_section)] + ([("report_every_step", with_report)] if interval == 1 else [])
             acc = {k: [] for k, _ in legs}
@@ -463,7 +475,10 @@ def _kernels_mode_child(mode: str = "kernels"):
                         "added_us_per_step_median": round(float(np.median(np.asarray(acc[name]) - base)) * 1e6, 1)}
 
             sec = paired("section")
-            res = {"profiling_interval": interval, "dispatches_traced_per_profiled_step": int(dispatches),
+            res = {"profiling_interval": interval, "kernel_trace_budget_pct": Detector.kernel_trace_budget_pct,
+                   "kernel_trace_cost_pct_measured_by_the_calibration": None if Detector.kernel_trace_cost_pct is None else round(Detector.kernel_trace_cost_pct, 3),
+                   "kernels_traced_on_every_nth_entry": interval * Detector._trace_every,
+                   "dispatches_traced_per_profiled_step": int(dispatches),
                    "step_ms_without": round(float(np.median(base)) * 1e3, 4),
                    "section_every_step_no_report_pct": sec["pct_median"], "section_every_step_no_report": sec}
             if "report_every_step" in acc:
@@ -478,16 +493,24 @@ def _kernels_mode_child(mode: str = "kernels"):
     try:
         o1 = overhead_legs(1, steps, rounds)
         o10 = overhead_legs(10, steps, 8) if mode == "kernels" else o1
-        # one report per 100 steps on top of the section: what a job at the reference's default cadence pays per step
+        odef = overhead_legs(1, steps, rounds, budget=None) if mode == "kernels" else o1
         out["per_step_overhead_kernels"] = {
+            # what a job gets WITHOUT touching a setting: Detector.initialize() defaults (profiling_interval 1, kernel_trace_budget_pct
+            # 1.0), the reference's loop (a section around the step, generate_report_if_interval_elapsed() after it)
+            "default_settings": odef,
+            "pct": odef["section_every_step_no_report_pct"],
+            "kernels_traced_on_every_nth_entry": odef["kernels_traced_on_every_nth_entry"],
+            "dispatches_traced_per_profiled_step": odef["dispatches_traced_per_profiled_step"],
+            # the same with the budget off (kernel_trace_budget_pct=0: every entry traced, the reference's behaviour)
             "profiling_interval_1": o1, "profiling_interval_10": o10,
-            "pct": o1["section_every_step_no_report_pct"],
+            "pct_budget_off_profiling_interval_1": o1["section_every_step_no_report_pct"],
             "pct_at_profiling_interval_10": o10["section_every_step_no_report_pct"],
             "steps_per_block": steps, "blocks": rounds, "counters": ktrace.counters(),
             "workload": f"{layers} x TransformerEncoderLayer(d_model {d_model}, 16 heads, ffn {4 * d_model}, pre-norm, bf16), batch {batch} x "
                         f"{seq} tokens, forward + backward + SGD inside ONE detection_section(profile_cuda=True), NVRX_GPU_TIMING={mode} "
-                        "(kernels: every dispatch of the section traced by name); pct = section every step, no report (what a step pays between "
-                        "two reports); report_every_step_pct = a synchronous generate_report() + identify_stragglers() after every step"}
+                        "(kernels: every dispatch of a traced entry recorded by name); pct = section every step, no report (what a step pays "
+                        "between two reports) at the DEFAULT settings, where the tracing budget thins tracing to every n-th entry; "
+                        "report_every_step_pct = a synchronous generate_report() + identify_stragglers() after every step"}
     except Exception as e:  # noqa: BLE001
         out["per_step_overhead_kernels"] = {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
 

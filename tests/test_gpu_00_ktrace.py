@@ -334,7 +334,7 @@ print("RESULT " + json.dumps(out))
 '''
 
 
-def _run_two_ranks(env_extra, cycles):
+def _run_two_ranks(env_extra, cycles, script=None):
     import socket
     import tempfile
 
@@ -348,7 +348,7 @@ def _run_two_ranks(env_extra, cycles):
         env.update({"RANK": str(rank), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "NVRX_TEST_INIT": f"tcp://127.0.0.1:{port}",
                     "NVRX_TEST_CYCLES": str(cycles), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         env.update(env_extra)
-        procs.append(subprocess.Popen([sys.executable, "-c", f"REPO = {REPO!r}\n" + COLLECTIVE_SCRIPT], stdout=subprocess.PIPE,
+        procs.append(subprocess.Popen([sys.executable, "-c", f"REPO = {REPO!r}\n" + (script or COLLECTIVE_SCRIPT)], stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True, env=env))
     outs = []
     for p in procs:
@@ -481,3 +481,80 @@ def test_ranks_that_time_gpu_work_differently_agree_on_one_mode_at_their_first_r
     assert last["keys"] == ["hipevent::train_step"]
     assert all(math.isfinite(v) for v in last["gpu_rel"].values()), last
     assert abs(last["gpu_rel"]["0"] - 1.0) < 0.03 and abs(last["gpu_rel"]["1"] - 0.8) < 0.04, last
+
+
+BUDGET_SCRIPT = r'''
+import faulthandler, json, logging, os, sys
+faulthandler.enable()
+faulthandler.dump_traceback_later(170, exit=True)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+import nvrx_straggler                      # WORLD_SIZE=2 and HIP is not up: per-kernel tracing is registered now
+from nvrx_straggler import Detector, ktrace
+import torch
+import torch.distributed as dist
+
+records = []
+class _Grab(logging.Handler):
+    def emit(self, record):
+        records.append(record.getMessage())
+log = logging.getLogger("nvrx_straggler.straggler")
+log.addHandler(_Grab()); log.setLevel(logging.INFO)
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)                    # both ranks share the one MI355X of the box (gloo group)
+dist.init_process_group("gloo", init_method=os.environ["NVRX_TEST_INIT"], rank=rank, world_size=2)
+# a tiny budget so that the per-dispatch cost of tracing (about a microsecond each) certainly exceeds it on the rank whose step
+# is nothing BUT tiny kernels; the other rank's step is one long kernel plus a few tiny ones
+Detector.initialize(scores_to_compute=["relative_perf_scores"], gather_on_rank0=True, node_name=f"node{rank}",
+                    report_time_interval=3600.0, kernel_trace_budget_pct=float(os.environ["NVRX_TEST_BUDGET"]))
+x = torch.ones(256, device="cuda")
+traced_entries = []
+c_prev = ktrace.counters()["enqueued"]
+for i in range(40):
+    with Detector.detection_section("train_step", profile_cuda=True):
+        if rank == 0:
+            for _ in range(400):
+                x.add_(1.0)                 # 400 tiny dispatches
+            torch.cuda.synchronize()
+        else:
+            torch.cuda._sleep(int(os.environ["NVRX_TEST_CYCLES"]))
+            for _ in range(5):
+                x.add_(1.0)
+            torch.cuda.synchronize()
+    c_now = ktrace.counters()["enqueued"]
+    if c_now != c_prev:
+        traced_entries.append(i)
+    c_prev = c_now
+    assert Detector.generate_report_if_interval_elapsed() is None
+out = {"mode": ktrace.timing_mode(), "every": Detector._trace_every, "cost_pct": Detector.kernel_trace_cost_pct,
+       "traced_entries": traced_entries, "iter_interval": Detector.report_interval_tracker.iter_interval,
+       "log": [m for m in records if "budget" in m]}
+rep = Detector.generate_report()
+if rank == 0:
+    out["gpu_rel_ranks"] = sorted(rep.gpu_relative_perf_scores)
+dist.barrier()
+Detector.shutdown()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.gpu
+def test_both_ranks_trace_at_the_same_thinned_interval_when_one_of_them_exceeds_the_tracing_budget():
+    '''``Detector.initialize(kernel_trace_budget_pct=...)`` on real kernels, two processes: rank 0's step is 400 tiny kernels
+    (tracing costs it a visible share of the step), rank 1's is one long kernel.  The calibration rides on the interval
+    tracker's all-reduce: both ranks end on the SAME multiple, the larger one; afterwards kernels are traced on exactly
+    every N-th entry on both, and the report still covers both ranks.'''
+    outs = _run_two_ranks({"NVRX_TEST_BUDGET": "0.2"}, cycles=2_000_000, script=BUDGET_SCRIPT)
+    r0, r1 = outs
+    print("[ktrace budget]", {k: (r0[k], r1[k]) for k in ("every", "cost_pct")}, r0["log"], r1["log"])
+    assert r0["mode"] == r1["mode"] == "kernels"
+    assert r0["every"] == r1["every"] >= 1 and r0["iter_interval"] == r1["iter_interval"]
+    assert r0["cost_pct"] is not None and r1["cost_pct"] is not None
+    every = r0["every"]
+    for r in (r0, r1):
+        after = [e for e in r["traced_entries"] if e > 17]
+        assert after == [e for e in range(18, 40) if e % every == 0], (every, r["traced_entries"])
+        cal = [e for e in r["traced_entries"] if e <= 16]
+        assert cal == [0, 1, 3, 5, 7, 9, 11, 13, 15], r["traced_entries"]
+        assert len(r["log"]) == 1
+    assert r0["gpu_rel_ranks"] == [0, 1]
