@@ -517,8 +517,9 @@ def _kernels_mode_child(mode: str = "kernels"):
     def cadence(asynchronous, reports):
         Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="node0", asynchronous=asynchronous)
         try:
-            t, t_late, t_harvest, stages = [], [], [], []
+            t, t_late, t_harvest, stages, lanes = [], [], [], [], 0
             clk = (ctypes.c_double * 8)()
+            wclk = (ctypes.c_double * 2)()
             held = None
             mgr = Detector.cupti_manager
             plain_harvest = mgr.harvest
@@ -535,6 +536,8 @@ def _kernels_mode_child(mode: str = "kernels"):
                     with Detector.detection_section("train_step", profile_cuda=True):
                         train_step()
                 torch.cuda.synchronize()
+                lane = Detector._lane
+                n_h = len(t_harvest)
                 t0 = time.perf_counter_ns()
                 rep = Detector.generate_report()
                 tg = time.perf_counter_ns()
@@ -546,6 +549,11 @@ def _kernels_mode_child(mode: str = "kernels"):
                 t2 = time.perf_counter_ns()
                 held = rep
                 Detector.rings.lib.nvrx_report_clocks(clk)
+                if lane is not None and Detector._lane is lane and len(t_harvest) == n_h:
+                    # served by the steady-state lane (one C call): the wait for the window's kernel records is its first stage
+                    Detector.rings.lib.nvrx_window_clocks(wclk)
+                    t_harvest.append((wclk[1] - wclk[0]) * 1e3)
+                    lanes += i >= 2
                 if i >= 2:
                     t.append(t1 - t0)
                     t_late.append(t2 - t1)
@@ -556,7 +564,7 @@ def _kernels_mode_child(mode: str = "kernels"):
             res = {"us_median": round(float(np.median(a)), 2), "us_p95": round(float(np.percentile(a, 95)), 2),
                    "us_max": round(float(a.max()), 2), "reports": len(t),
                    "of_which_harvest_us_median": round(float(np.median(t_harvest[2:])) / 1e3, 2),
-                   "kernel_keys": len(Detector.rings.kernel_row_names)}
+                   "kernel_keys": len(Detector.rings.kernel_row_names), "reports_served_by_the_lane": int(lanes)}
             st_ = np.median(np.asarray(stages, dtype=np.float64), axis=0) / 1e3
             res["stages_us_median"] = dict(zip(("generate_report", "identify_stragglers", "c_stream_ordering", "c_flush_scatter",
                                                 "c_row_stats_launch", "c_score_launch", "c_wait_completion", "c_call_total"),

@@ -274,7 +274,34 @@ typedef struct nvrx_report_desc {
                                  report's statistics kernel */
 } nvrx_report_desc;
 int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *desc, void *stream);
-/* Diagnostics: host clocks of this thread's last nvrx_report, microseconds on the monotonic clock -- [0] entry, [1] stream
+/* One report WINDOW in one call: what straggler.py:228-244 does around the report in the steady state -- wait for the
+ * window's GPU measurements (torch.cuda.synchronize() + the profiler's get_stats there; here the kernel tracer's sync, or a
+ * harvest of the region events), check that the set of rows holding samples is the one the caller's name tables were built
+ * for, run nvrx_report, empty the rings (straggler.py:241-242).  The kernel tracer lives in another library
+ * (include/nvrx_ktrace.h): its three entry points are handed over as plain function pointers.
+ * Returns NVRX_OK (the report ran -- for asynchronous ones: was enqueued -- and the rings are empty), NVRX_WINDOW_MISS
+ * (NOTHING ran: dispatches still missing after the patience, kernel keys the host has not learnt yet, or the occupied rows
+ * changed -- the caller takes its general path), NVRX_WINDOW_NAMES (synchronous only: the report ran and its table says some
+ * rank has names without ids; the rings were NOT emptied -- the caller syncs names and reports again), or a negative error. */
+#define NVRX_WINDOW_MISS 1
+#define NVRX_WINDOW_NAMES 2
+typedef struct nvrx_window_desc {
+    int (*kt_sync)(double timeout_s);  /* nvrx_ktrace_sync, or NULL: GPU time is measured per region */
+    int (*kt_hold)(int on);            /* nvrx_ktrace_hold: brackets "statistics launch + ring reset" of an asynchronous report */
+    uint64_t (*kt_counter)(int what);  /* nvrx_ktrace_counter */
+    double kt_patience_s;              /* how long a synchronous report waits for the window's kernel records */
+    uint64_t kt_rows_known;            /* the host's copies of tracer counters 10 and 6: a difference = kernel keys to learn */
+    uint64_t kt_keys_without_row;
+    int32_t rows_used;                 /* rows the caller's name tables cover (as for nvrx_ring_occupancy_changed) */
+    int32_t asynchronous;              /* nonzero: desc->h_seq_word is NULL, the report is only enqueued, nothing is waited for */
+    int32_t harvest_regions;           /* region timing: nvrx_event_harvest before the report */
+    int32_t out_names_ok;              /* out: 0 when NVRX_WINDOW_NAMES was returned */
+} nvrx_window_desc;
+int nvrx_window_report(nvrx_ctx *ctx, nvrx_report_desc *desc, void *stream, nvrx_window_desc *window);
+/* Diagnostics: host clocks of this thread's last nvrx_window_report, microseconds on the monotonic clock -- [0] entry, [1]
+ * the wait for the window's measurements and the occupancy look are done, nvrx_report begins (its own clocks follow). */
+int nvrx_window_clocks(double *out2);
+/* Diagnostics: host clocks of this thread's last nvrx_report/* Diagnostics: host clocks of this thread's last nvrx_report, microseconds on the monotonic clock -- [0] entry, [1] stream
  * ordering done, [2] staged samples flushed, [3] statistics kernel launched, [4] exchange enqueued, [5] score kernel
  * launched, [6] completion word seen (synchronous reports), [7] spare.  No counterpart in the reference. */
 int nvrx_report_clocks(double *out8);

@@ -44,6 +44,18 @@ class ReportDesc(ctypes.Structure):
     ]
 
 
+class WindowDesc(ctypes.Structure):
+    """``nvrx_window_desc`` (include/nvrx_straggler.h): what ``nvrx_window_report`` does around the report itself."""
+
+    _fields_ = [
+        ("kt_sync", c_void_p), ("kt_hold", c_void_p), ("kt_counter", c_void_p), ("kt_patience_s", c_double),
+        ("kt_rows_known", ctypes.c_uint64), ("kt_keys_without_row", ctypes.c_uint64),
+        ("rows_used", c_int32), ("asynchronous", c_int32), ("harvest_regions", c_int32), ("out_names_ok", c_int32),
+    ]
+
+
+WINDOW_MISS, WINDOW_NAMES = 1, 2
+
 # every symbol include/nvrx_straggler.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("nvrx_abi_version", c_int, []),
@@ -70,6 +82,8 @@ SYMBOLS = [
     ("nvrx_ring_count", c_int, [c_void_p, c_int]),
     ("nvrx_ring_counts", c_int, [c_void_p, c_void_p, c_int]),
     ("nvrx_ring_occupancy_changed", c_int, [c_void_p, c_int]),
+    ("nvrx_window_report", c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("nvrx_window_clocks", c_int, [POINTER(c_double)]),
     ("nvrx_ring_reset", c_int, [c_void_p]),
     ("nvrx_history_reset", c_int, [c_void_p, c_void_p]),
     ("nvrx_ring_flush", c_int, [c_void_p, c_void_p]),

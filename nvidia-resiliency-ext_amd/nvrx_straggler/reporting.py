@@ -843,6 +843,7 @@ class ReportGenerator:
         self.exchange_info: Dict[str, Any] = {}
         self._unreported_rows: list = []  # see take_unreported_rows
         self._prev_async_settled = True  # no asynchronous report of this generator is unaccounted for (see _settle_inflight)
+        self._resync_pending = False  # the next ring report starts with the name sync (see Detector's lane)
         self._wr_cache: list = [None]  # this generator's remembered (default group, group, (world, rank)): dist_utils.world_and_rank
 
     # ---- pieces kept from the reference's host logic ----------------------------------------------
@@ -1254,7 +1255,7 @@ class ReportGenerator:
         key = (id(section_rows), len(section_rows), id(kernel_rows), len(kernel_rows), self.name_mapper.version,
                self._private_mapper.version, self.world_size, self.rank, rings.rows_used, local_ranks, id(rings))
         plan = self._ring_plan
-        resync_first = False
+        resync_first, self._resync_pending = self._resync_pending, False  # (left by a lane that saw an "ids missing" table)
         if self._inflight is not None and self._settle_inflight():
             # the previous (asynchronous) report's exchange carried an "ids missing" flag: every rank is here now
             self._ring_plan = plan = None

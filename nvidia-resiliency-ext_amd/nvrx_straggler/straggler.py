@@ -22,6 +22,7 @@ What changed underneath:
 """
 from __future__ import annotations
 
+import ctypes
 import dataclasses
 import functools
 import inspect
@@ -36,10 +37,11 @@ from typing import Any, Dict, Iterable, List, Optional, Sequence, Union
 
 from . import _native
 from . import backend as _backend_mod
+from . import dist_utils as _dist_utils
 from . import ktrace as _ktrace
 from .cupti import CuptiManager
 from .interval_tracker import ReportIntervalTracker
-from .reporting import ReportGenerator
+from .reporting import Report, ReportGenerator, _LiveBlock, _PendingBlock, _ScoreSource
 from .statistics import Statistic  # noqa: F401  (re-exported for callers that poke summaries)
 
 GPU_KEY_PREFIX = "hipevent::"  # kernel-summary key of a section's GPU-time row
@@ -119,6 +121,137 @@ class CustomSection:
         self.cpu_elapsed_times = _ElapsedRing(rings, self.row)
 
 
+_MISS = object()  # a lane that cannot serve this report says so; the general path runs
+
+
+class _Lane:
+    """The steady-state report as ONE Python function around ONE C call (``nvrx_window_report``).
+
+    ``Detector.generate_report`` is a dozen small methods of four objects -- profiler harvest, occupancy check, the
+    generator's plan lookup, the one-call report, ring reset -- each cheap while the interpreter is warm.  At production
+    cadence (a report per minute, a report per hundreds of steps) every one of them runs COLD after a second of training
+    code: ~100 interpreter-level calls cost 150-190 us around a C call of 45 (profiles/r06a/r06c_kernels_mode_breakdown.txt).
+    A lane is built after a report that took the cached plan; it holds everything that report looked up, checks with a few
+    attribute reads that nothing it depends on has changed, and otherwise says ``_MISS`` BEFORE anything has happened, so the
+    general path -- which stays the specification -- runs as if the lane did not exist."""
+
+    __slots__ = ("rings", "reporter", "manager", "ext", "plan", "ws", "be", "view", "versions", "wr", "group", "wr_cache",
+                 "rows_used", "desc_key", "window", "window_ref", "call", "ctx", "stream", "multi", "enqueue_only",
+                 "returns_none", "stats_needed", "gather_on_rank0", "rank", "token", "asynchronous")
+
+    @classmethod
+    def build(cls, det) -> Optional["_Lane"]:
+        rings, reporter, manager = det._rings, det.reporter, det._cupti_manager
+        plan = reporter._ring_plan
+        call = getattr(getattr(rings, "lib", None), "nvrx_window_report", None)
+        if plan is None or not plan.fused or call is None or manager is None or not manager.is_initialized:
+            return None
+        multi = reporter.world_size > 1 and reporter._exchanged()
+        if (multi and reporter._direct is None) or det._pending_region_switch is not None or reporter._inflight is not None:
+            return None  # (a host-driven exchange: the report is three calls with a collective between them)
+        if reporter.asynchronous and not reporter.enqueue_only():
+            return None
+        ext = manager.cupti_ext
+        ws = plan.ws
+        if ws.block.desc_key is None or not ws.send_initialised:
+            return None
+        self = cls()
+        self.rings, self.reporter, self.manager, self.ext, self.plan, self.ws = rings, reporter, manager, ext, plan, ws
+        self.be = _backend_mod.get_backend()
+        self.view = plan.view
+        self.versions = (reporter.name_mapper.version, reporter._private_mapper.version)
+        self.group, self.wr_cache = reporter.group, reporter._wr_cache
+        self.wr = _dist_utils.world_and_rank(self.group, self.wr_cache)
+        self.token = det._mode_agreed
+        self.rows_used = rings.rows_used
+        self.desc_key = ws.block.desc_key
+        self.asynchronous = reporter.asynchronous
+        self.enqueue_only = bool(reporter.asynchronous)
+        self.multi = multi
+        self.stats_needed = plan.stats_needed
+        self.gather_on_rank0, self.rank = reporter.gather_on_rank0, reporter.rank
+        self.returns_none = reporter.gather_on_rank0 and reporter.rank != 0
+        w = self.window = _native.WindowDesc()
+        if manager.per_kernel:
+            if not getattr(ext, "_counting", False):
+                return None  # (dispatches are not counted: a report has to synchronise the device first -- the general path does)
+            cast, klib = ctypes.cast, ext._lib
+            w.kt_sync = cast(klib.nvrx_ktrace_sync, ctypes.c_void_p).value
+            w.kt_hold = cast(klib.nvrx_ktrace_hold, ctypes.c_void_p).value
+            w.kt_counter = cast(klib.nvrx_ktrace_counter, ctypes.c_void_p).value
+            w.kt_patience_s = float(ext.sync_patience_s)
+            w.kt_rows_known, w.kt_keys_without_row = int(ext._rows_known), int(ext.keys_without_row)
+        else:
+            w.harvest_regions = 1
+        w.rows_used = self.rows_used
+        w.asynchronous = 1 if self.enqueue_only else 0
+        self.window_ref = ctypes.byref(w)
+        self.call, self.ctx, self.stream = call, rings.ctx, self.be._stream_handle
+        return self
+
+    def run(self, det):
+        """The report, or ``_MISS`` (nothing has happened), or -- names incomplete on some rank -- the general path's report."""
+        t0 = time.perf_counter_ns()
+        reporter, ws, rings = self.reporter, self.ws, self.rings
+        if (reporter._ring_plan is not self.plan or det._rings is not rings or det._cupti_manager is not self.manager
+                or self.manager.cupti_ext is not self.ext or rings._rows_used != self.rows_used
+                or reporter.asynchronous is not self.asynchronous or det._pending_region_switch is not None
+                or det._mode_agreed != self.token
+                or (reporter.name_mapper.version, reporter._private_mapper.version) != self.versions
+                or _dist_utils.world_and_rank(self.group, self.wr_cache) != self.wr):
+            return _MISS
+        if self.enqueue_only and reporter._inflight is not None and reporter._settle_inflight():
+            reporter._ring_plan = None       # the previous report's table carried an "ids missing" flag: every rank is
+            reporter._resync_pending = True  # heading for the name sync now, at the start of its general path
+            return _MISS
+        cur = ws._cur
+        nxt = ws.blocks[1 - cur]
+        if nxt.desc_key != self.desc_key:
+            return _MISS
+        if nxt._live is not None:
+            nxt.settle()  # (its report of two reports ago: copied out if somebody still holds it)
+        ws._cur, ws.block = 1 - cur, nxt
+        d = nxt.desc
+        if self.enqueue_only:
+            d.prev_settled = 1 if reporter._prev_async_settled else 0
+        if self.multi:
+            d.order_after_stream, d.order_after_enabled = self.be.current_stream_handle(), 1
+        elif d.order_after_enabled:
+            d.order_after_enabled = 0
+        d.seq = ws.seq
+        rc = self.call(self.ctx, nxt.desc_ref, self.stream, self.window_ref)
+        seq = ws.seq = d.seq
+        if rc == _native.WINDOW_MISS:
+            ws._cur, ws.block = cur, ws.blocks[cur]  # nothing ran on the block: it is not the current one
+            return _MISS
+        if rc < 0:
+            reporter._ring_plan = None
+            if rc == _native.ERR_TIMEOUT:
+                self.be.retire_workspace(ws)
+            _native.check(rc)
+        if self.enqueue_only:
+            reporter._prev_async_settled = False  # until somebody has seen THIS report complete
+            pend = reporter._inflight = _PendingBlock(self.be, ws, seq)
+            if self.returns_none:
+                return None
+            return Report._from_device(_ScoreSource(self.view, pend), reporter._shared_rank_to_node(),
+                                       (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank)
+        nxt.mark_live(seq)  # (the statistics rows land under a completion word of their own: the block's next user waits for it)
+        if self.multi:
+            reporter._check_exchange()
+        if rc == _native.WINDOW_NAMES:
+            # some rank met a new name during this report's exchange: the rings still hold the window -- sync names, report again
+            reporter._ring_plan = None
+            reporter._resync_pending = True
+            return det._report_and_reset(rings, reporter)
+        if self.returns_none:
+            return None
+        live = _LiveBlock(self.be, ws, seq, self.stats_needed)
+        nxt.attach(live)
+        return Report._from_device(_ScoreSource(self.view, live), reporter._shared_rank_to_node(),
+                                   (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank)
+
+
 class _DeviceSideOnDemand(type):
     """``Detector.rings`` and ``Detector.cupti_manager`` -- everything that lives on a GPU -- come into being the first
     time they are touched, on the device that is current THEN.  The reference's own example initialises the detector
@@ -190,6 +323,9 @@ class Detector(metaclass=_DeviceSideOnDemand):
     _trace_gate: bool = True
     _trace_sparse: bool = False                      # fast check in detection_section: gate closed or _trace_every > 1
     _calib: Any = None                               # (marks, flags) while measuring, else None
+    # the steady-state report as one function around one C call (_Lane), built after a report that took the cached plan
+    _lane: Optional[_Lane] = None
+    _lanes_enabled: bool = True
 
     def __new__(cls):
         raise RuntimeError(f"class {cls.__name__} should not be instantiated")
@@ -245,7 +381,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
         per_kernel = _ktrace.timing_mode() == "kernels"
         if per_kernel and int(max_rows) == 256:
             max_rows = 4096  # one row per distinct kernel key; 4096 x 8192 f32 = 128 MB of 288 GB
-        cls._rings = cls._cupti_manager = None
+        cls._rings = cls._cupti_manager = cls._lane = None
         cls._device_side_args = (int(max_rows), capacity)
         cls._mode_agreed = None
         cls._pending_region_switch, cls._pending_switch_said = None, False
@@ -337,6 +473,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
     @classmethod
     def shutdown(cls):
         """Undo ``initialize``: wrapped callables get their originals back, profiler, rings and exchange route close."""
+        cls._lane = None
         manager, cls._cupti_manager = cls._cupti_manager, None
         if manager is not None:
             manager.shutdown()
@@ -405,6 +542,19 @@ class Detector(metaclass=_DeviceSideOnDemand):
     def generate_report(cls):
         """Score everything recorded since the last report, then empty the rings.  Collective."""
         assert cls.initialized
+        lane = cls._lane
+        if lane is not None:
+            out = lane.run(cls)
+            if out is not _MISS:
+                return out
+            cls._lane = None  # something it was built on has changed: the general path, and a new lane after it
+        report = cls._generate_report_general()
+        if cls._lane is None and cls._lanes_enabled:
+            cls._lane = _Lane.build(cls)
+        return report
+
+    @classmethod
+    def _generate_report_general(cls):
         rings = cls.rings
         reporter = cls.reporter
         manager = cls.cupti_manager
@@ -480,6 +630,19 @@ class Detector(metaclass=_DeviceSideOnDemand):
         iterations: iterations alternate between tracing the kernels of their profiled sections and not tracing, each one's
         wall time is the distance between two of these calls."""
         marks, flags = cls._calib
+        # The iteration's DEVICE work has to be inside its wall time: a GPU-bound loop enqueues a step in a fraction of the time the
+        # GPU takes for it, and tracing doubles what a launch costs the HOST -- without the wait the host-side times say "tracing
+        # costs 266 %" of a loop it slows down by 1.2 % (profiles/r06d_budget_calibration.txt).  Seventeen device
+        # synchronisations at the start of a job; the reference synchronises at every report (straggler.py:234).
+        try:
+            import torch
+
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+        except RuntimeError:  # (e.g. a stream is being captured into a graph right now: no calibration then)
+            cls._calib = None
+            cls._trace_gate, cls._trace_sparse = True, cls._trace_every > 1
+            return
         marks.append(time.monotonic())
         on = len(marks) % 2 == 1  # the iteration that starts now: traced after marks 1, 3, 5 ...
         flags.append(on)

@@ -59,7 +59,8 @@ def test_gpus_2_without_a_launcher_spawns_its_own_ranks():
     # which route the reports took and what the checked trial said: a gloo group has no RCCL communicator, so the rows
     # travel through torch.distributed and the selection says so
     assert "route" in ex and isinstance(ex["selection"], dict)
-    assert ex["route"] == "torch.distributed" or "ncclCommCount" in str(ex["selection"]) or "rccl_comm_ranks" in ex["selection"]
+    assert ex["route"].startswith("torch.distributed") or "ncclCommCount" in str(ex["selection"]) or "rccl_comm_ranks" in ex["selection"]
+    assert ex["selection"].get("mode") == "c10d"      # the default route: the job's own process group, no second communicator
     assert d["gpu_timing_mode"] in ("stamp", "kernels")
 
 

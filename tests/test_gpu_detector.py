@@ -322,6 +322,73 @@ def test_asynchronous_and_synchronous_detector_reports_agree():
     assert results[False] == results[True]
 
 
+@pytest.mark.parametrize("asynchronous", [False, True])
+def test_the_steady_state_lane_reports_exactly_what_the_general_path_reports(asynchronous):
+    """``Detector._lane`` (one Python function around ``nvrx_window_report``) serves a report only when nothing it was built on
+    has changed; everything else -- a section that holds no samples in one window, a section that appears later, GPU-timed
+    regions coming and going -- must fall back to the general path and come out the same.  The same 24 windows run twice,
+    lanes on and lanes off: every report equal (summaries bit for bit, scores, flagged sets), and with lanes on most
+    reports were served by a lane."""
+    from nvrx_straggler import Detector, straggler
+
+    rng = np.random.default_rng(17)
+    windows = []
+    for t in range(24):
+        w = {f"sec{i}": rng.normal(4.0 * (i + 1), 0.3, 40).astype(np.float32) * (1.6 if (i == 2 and t >= 12) else 1.0) for i in range(4)}
+        if t in (7, 8):
+            del w["sec1"]                      # holds no samples in these windows: the occupied set changes twice
+        if t >= 15:
+            w["late_section"] = rng.normal(9.0, 0.1, 40).astype(np.float32)
+        windows.append((w, t % 5 != 3))        # (and a GPU-timed region in most windows)
+    x = torch.randn(256, 256, device="cuda")
+
+    def run(lanes):
+        served = []
+        real_run = straggler._Lane.run
+
+        def counting_run(self, det):
+            out = real_run(self, det)
+            served.append(out is not straggler._MISS)
+            return out
+
+        straggler._Lane.run = counting_run
+        Detector._lanes_enabled = lanes
+        Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n", asynchronous=asynchronous)
+        try:
+            reps = []
+            for w, gpu in windows:
+                for name, vals in w.items():
+                    with Detector.detection_section(name, profile_cuda=False):
+                        pass
+                    Detector.custom_sections[name].cpu_elapsed_times.clear()
+                    Detector.custom_sections[name].cpu_elapsed_times.extend(vals)
+                if gpu:
+                    for _ in range(3):
+                        with Detector.detection_section("gpu_region", profile_cuda=True):
+                            (x @ x).sum()
+                    torch.cuda.synchronize()
+                reps.append(Detector.generate_report())
+            out = []
+            for r in reps:
+                ks = {k: {s: v for s, v in d.items() if s.name in ("NUM",)} for k, d in r.local_kernel_summaries.items()}
+                out.append((dict(r.section_individual_perf_scores), dict(r.section_relative_perf_scores), dict(r.local_section_summaries),
+                            ks, r.identify_stragglers(section_indiv_threshold=0.7), r.identify_stragglers()))
+            return out, served
+        finally:
+            Detector.shutdown()
+            Detector._lanes_enabled = True
+            straggler._Lane.run = real_run
+
+    with_lanes, served = run(True)
+    without, never = run(False)
+    assert never == []
+    assert with_lanes == without
+    assert served.count(True) >= 12, served     # the steady stretches; the changing windows missed and rebuilt
+    assert served.count(False) >= 3, served
+    flagged = [bool(r[4]["straggler_sections_individual"]) for r in with_lanes]
+    assert not any(flagged[:12]) and all(flagged[12:]), flagged      # sec2 slows down by 1.6 from window 12 on
+
+
 def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
     """The wait for the completion word is bounded by NVRX_REPORT_TIMEOUT_S (default: 30 minutes, c10d's): when it
     expires the report raises, the workspace whose kernels may still be queued is parked (never reused, never freed

@@ -4,7 +4,7 @@ with > 500 traced dispatches inside one GPU-timed section, 40 steps between repo
 which part of the C call costs what.  Stages are timed by wrapping the callables the method goes through; a second pass runs
 a few reports under cProfile and prints the functions by own time.
 
-    python tools/cadence_kernels_breakdown.py [--async] [--reports N] [--profile]
+    python tools/cadence_kernels_breakdown.py [--async] [--reports N] [--profile] [--no-lane]
 """
 import os
 import sys
@@ -21,7 +21,10 @@ import ctypes  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from nvrx_straggler import Detector, ktrace, reporting  # noqa: E402
+from nvrx_straggler import Detector, ktrace, reporting, straggler  # noqa: E402
+
+if "--no-lane" in sys.argv:
+    Detector._lanes_enabled = False  # the general path at every report (what rounds 1-5 ran)
 
 ASYNC = "--async" in sys.argv
 REPORTS = int(sys.argv[sys.argv.index("--reports") + 1]) if "--reports" in sys.argv else 8
@@ -88,8 +91,13 @@ for obj, name, label in (
         wrap(obj, name, label)
         LABELS.append(label)
 
+wrap(straggler._Lane, "run", "lane.run (steady state: one function around nvrx_window_report)")
+LABELS.insert(0, "lane.run (steady state: one function around nvrx_window_report)")
+wrap(rings.lib, "nvrx_window_report", "  nvrx_window_report (C: wait for the window + occupancy look + nvrx_report + reset)")
+LABELS.insert(1, "  nvrx_window_report (C: wait for the window + occupancy look + nvrx_report + reset)")
 clk = (ctypes.c_double * 8)()
-C_LABELS = ["C: entry -> stream ordering done", "C: -> staged samples flushed (k_scatter launch)", "C: -> k_row_stats launched",
+wclk = (ctypes.c_double * 2)()
+C_LABELS = ["C: window entry -> nvrx_report entry (wait for the window's records, occupancy look)", "C: entry -> stream ordering done", "C: -> staged samples flushed (k_scatter launch)", "C: -> k_row_stats launched",
             "C: -> score kernel launched", "C: -> completion word seen (poll)"]
 
 
@@ -107,15 +115,17 @@ def one_report(record):
         rep.identify_stragglers()
     t2 = time.perf_counter_ns()
     rings.lib.nvrx_report_clocks(clk)
+    rings.lib.nvrx_window_clocks(wclk)
     if record is not None:
         d = dict(marks)
+        d["C: window entry -> nvrx_report entry (wait for the window's records, occupancy look)"] = int((wclk[1] - wclk[0]) * 1e3) if wclk[1] <= clk[0] + 1 and clk[0] - wclk[1] < 50 else 0
         d["TOTAL generate_report"] = t1 - t0
         d["identify_stragglers"] = t2 - t1
-        d[C_LABELS[0]] = int((clk[1] - clk[0]) * 1e3)
-        d[C_LABELS[1]] = int((clk[2] - clk[1]) * 1e3)
-        d[C_LABELS[2]] = int((clk[3] - clk[2]) * 1e3)
-        d[C_LABELS[3]] = int((clk[5] - clk[3]) * 1e3)
-        d[C_LABELS[4]] = 0 if ASYNC else int((clk[6] - clk[5]) * 1e3)
+        d[C_LABELS[1]] = int((clk[1] - clk[0]) * 1e3)
+        d[C_LABELS[2]] = int((clk[2] - clk[1]) * 1e3)
+        d[C_LABELS[3]] = int((clk[3] - clk[2]) * 1e3)
+        d[C_LABELS[4]] = int((clk[5] - clk[3]) * 1e3)
+        d[C_LABELS[5]] = 0 if ASYNC else int((clk[6] - clk[5]) * 1e3)
         d["_calls"] = dict(calls)
         record.append(d)
     return rep
