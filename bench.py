@@ -825,6 +825,132 @@ def _side_leg(fn, *a, **k):
         return {"error": f"{type(e).__name__}: {str(e)[-300:]}"}
 
 
+def _route_leg(route: str, world: int, rank: int, steps: int, warmup: int):
+    """The headline loop once more on ONE named exchange route (N > 1): a fresh job (its own rings, generator and -- for the
+    in-stream routes -- communicator / windows), ``warmup`` + ``steps`` reports, each step's time; then the route's floor.
+    Collective: every rank runs it.  What the route's checked trial said is in ``selection``; a route the trial dropped is
+    reported as dropped (the reports then ran on torch.distributed, and the figure says so)."""
+    import synth
+    from nvrx_straggler.folded import FoldedJob
+
+    saved = os.environ.get("NVRX_EXCHANGE")
+    os.environ["NVRX_EXCHANGE"] = route
+    job = None
+    try:
+        job = FoldedJob(total_ranks=TOTAL_RANKS, section_names=[synth.section_name(s) for s in range(SECTIONS)],
+                        ring_cap=SAMPLES, node_name=f"node{rank}")
+        for lr, r in enumerate(job.logical_ranks()):
+            job.load(lr, synth.stress_samples(r, SECTIONS, SAMPLES, slow_rank=3, slow_factor=1.5))
+        torch.cuda.synchronize()
+        found = None
+        for _ in range(warmup + 3):
+            job.rearm(SAMPLES)
+            rep = job.report()
+            found = rep.identify_stragglers() if rep is not None else None
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = []
+        for _ in range(steps):
+            t0 = time.perf_counter_ns()
+            job.rearm(SAMPLES)
+            rep = job.report()
+            found = rep.identify_stragglers() if rep is not None else None
+            t.append(time.perf_counter_ns() - t0)
+        torch.cuda.synchronize()
+        ok = True
+        if rank == 0:
+            flagged = found["straggler_sections_relative"]
+            ok = len(flagged) == SECTIONS and all({s.rank for s in v} == {3} for v in flagged.values())
+        info = dict(job.reporter.exchange_info)
+        direct = job.reporter._direct
+        took = "in-stream" if direct is not None else "torch.distributed"
+        dropped = [k for k in ("rccl_rejected", "peer_rejected") if info.get(k)]
+        med = torch.tensor([float(np.median(t)) / 1e3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(med, op=dist.ReduceOp.MAX)
+        out = {"us_median": round(float(med.item()), 2), "steps": steps, "flagged_set_right": bool(ok),
+               "ran_on": getattr(direct, "route", None) or info.get("route", took),
+               "status": "ok" if (route == "c10d" or direct is not None) else "dropped: " + (", ".join(dropped) or "the route could not be built on this group")
+               + " -- the reports ran on torch.distributed", "selection": info}
+        ranks_fn = getattr(direct, "comm_ranks", None)
+        if ranks_fn is not None:
+            out["ncclCommCount"] = ranks_fn()
+        # the route's floor on this machine: ONE rank's production row (129 f32) all-gathered on the same communicator / stream
+        from nvrx_straggler import dist_utils as _du
+
+        L1 = 2 * SECTIONS + 1
+        f_send = torch.zeros(L1, dtype=torch.float32, device="cuda")
+        f_recv = torch.zeros(world * L1, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        be_ = job.backend
+
+        def floor_once():
+            if direct is not None and hasattr(direct, "all_gather"):
+                direct.all_gather(f_send.data_ptr(), f_recv.data_ptr(), L1, be_.stream_handle)
+            else:
+                with be_.stream_context():
+                    _du.all_gather_rows(f_send.view(1, L1), f_recv.view(world, L1), job.reporter.group)
+            be_.synchronize()
+
+        for _ in range(5):
+            floor_once()
+        t_fl = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            floor_once()
+            t_fl.append(time.perf_counter() - t0)
+        fl = torch.tensor([float(np.median(t_fl)) * 1e6], dtype=torch.float64, device="cuda")
+        dist.all_reduce(fl, op=dist.ReduceOp.MAX)
+        out["floor_us"] = round(float(fl.item()), 2)
+        return out
+    finally:
+        if job is not None:
+            try:
+                job.close()
+            except Exception:  # noqa: BLE001
+                pass
+        if saved is None:
+            os.environ.pop("NVRX_EXCHANGE", None)
+        else:
+            os.environ["NVRX_EXCHANGE"] = saved
+
+
+def _routes_table(world: int, rank: int, steps: int, warmup: int, headline_route: str, per_route_timeout_s: float, device_index: int):
+    """N > 1: the same reports on every OTHER exchange route, so that one run of the driver's scaling bench yields the whole
+    table (c10d = the default, rccl = ncclAllGather on a second communicator in the detector's stream, peer = xGMI peer
+    stores into IPC windows).  Each route runs on a helper thread with a deadline: none of the in-stream routes has ever
+    run across two real devices, and a route that hangs must cost its own entry, not the line.  After a timeout nothing
+    collective is attempted any more (the ranks may disagree about where they are) and main() leaves through os._exit."""
+    import threading
+
+    table, hung = {}, False
+    for route in ("c10d", "rccl", "peer"):
+        if route == headline_route:
+            continue
+        if hung:
+            table[route] = {"status": "not run: an earlier route did not come back"}
+            continue
+        box = {}
+
+        def body(route=route, box=box):
+            try:
+                torch.cuda.set_device(device_index)  # (HIP's current device is per thread)
+                box["out"] = _route_leg(route, world, rank, steps, warmup)
+            except BaseException as e:  # noqa: BLE001
+                box["out"] = {"status": f"error: {type(e).__name__}: {str(e)[-300:]}"}
+
+        th = threading.Thread(target=body, daemon=True)
+        th.start()
+        th.join(per_route_timeout_s)
+        if th.is_alive():
+            table[route] = {"status": f"timed out after {per_route_timeout_s:.0f} s"}
+            hung = True
+        else:
+            table[route] = box.get("out", {"status": "no result"})
+            if str(table[route].get("status", "")).startswith("error"):
+                hung = True  # (a rank that raised has left the others inside a collective: treat like a hang)
+    return table, hung
+
+
 def _self_launch(n: int) -> int:
     """``python bench.py --gpus N`` without a launcher: start N copies of this command, one rank each, with the
     environment torch.distributed.run would give them (rendezvous on 127.0.0.1, a free port).  Rank 0 prints the JSON
@@ -879,6 +1005,8 @@ def main():
     ap.add_argument("--cadence-reports", type=int, default=30)
     ap.add_argument("--dump-steps", action="store_true", help="add the per-step latencies of the timed region to the JSON line")
     ap.add_argument("--no-kernels-mode", action="store_true", help="skip the per-kernel-tracing legs (they run in a child interpreter)")
+    ap.add_argument("--no-routes", action="store_true", help="N > 1: skip the legs that repeat the timed loop on the other exchange routes")
+    ap.add_argument("--route-timeout", type=float, default=90.0, help="N > 1: seconds one exchange route's leg may take")
     ap.add_argument("--child", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.child in ("kernels_mode", "stamp_mode"):
@@ -1099,6 +1227,19 @@ def main():
         except Exception as e:  # noqa: BLE001  (deterministic on every rank: same state everywhere)
             exchange = {"error": str(e)[-200:]}
 
+    # the max over ranks of the timed regions is taken NOW, while every rank is certainly still in step
+    if world > 1:
+        _t = torch.tensor([elapsed, elapsed_instr, exchange.get("us_median", 0.0) if exchange and "us_median" in exchange else 0.0],
+                          dtype=torch.float64, device="cuda")
+        dist.all_reduce(_t, op=dist.ReduceOp.MAX)
+        times_max = _t.tolist()
+
+    # the other exchange routes (N > 1): the same timed loop on each, inside a deadline
+    routes, routes_hung = None, False
+    if world > 1 and not args.no_routes:
+        headline_mode = job.reporter.exchange_info.get("mode", "c10d") if job.reporter._direct is None else job.reporter.exchange_info.get("mode", "rccl")
+        routes, routes_hung = _routes_table(world, rank, min(args.steps, 100), min(args.warmup, 10), headline_mode, args.route_timeout, device_index)
+
     # the same kernel with its rows coming from HBM: a 1 GiB sweep between reports evicts L2 and the Infinity Cache
     cold = None
     n8 = None
@@ -1157,7 +1298,7 @@ def main():
                                                               ("per_step_overhead_kernels", "report_at_cadence_kernels", "error") if k in stamp_twin}
 
     overhead = overhead_async = None
-    if not args.no_overhead:
+    if not args.no_overhead and not routes_hung:
         job.backend.synchronize()
         # (collective at N > 1: every rank runs it and a failure is a failure of the job; at N = 1 it is a side leg)
         if world == 1:
@@ -1167,10 +1308,8 @@ def main():
             overhead = _per_step_overhead(world, rank, args.overhead_steps, args.overhead_blocks)
 
     ex_us = exchange.get("us_median", 0.0) if exchange else 0.0
-    times = torch.tensor([elapsed, elapsed_instr, ex_us], dtype=torch.float64, device="cuda")
     if world > 1:
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    elapsed, elapsed_instr, ex_us = times.tolist()
+        elapsed, elapsed_instr, ex_us = times_max
 
     if rank == 0:
         us_per_report = elapsed / args.steps * 1e6
@@ -1283,10 +1422,22 @@ def main():
             exchange["us_median"] = round(ex_us, 2) if "us_median" in exchange else None
             exchange["note"] = "enqueue + stream wait of one all-gather of the exchange rows, max over ranks; latency-bound"
             out["exchange"] = exchange
-        if world == 1 and not args.no_cpu_baseline:
+        if routes is not None:
+            head = {"us_median": out["us_per_report_median"], "status": "ok (the headline of this line)",
+                    "ran_on": getattr(job.reporter._direct, "route", None) or job.reporter.exchange_info.get("route", "torch.distributed")}
+            if exchange and "floor_us" in exchange:
+                head["floor_us"] = exchange["floor_us"]
+            out["routes"] = {job.reporter.exchange_info.get("mode", "c10d"): head, **routes}
+        if not args.no_cpu_baseline:
+            # (at N > 1 the other ranks wait at the closing barrier meanwhile: the baseline runs on rank 0's host cores)
             out["cpu_baseline"] = _side_leg(_cpu_baseline, args.cpu_reps)
         print(json.dumps(out), flush=True)
 
+    if routes_hung:
+        # a route leg is still stuck in a collective on its helper thread: nothing can be torn down in order any more
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     job.close()
     if world > 1:
         dist.barrier()

@@ -45,7 +45,8 @@ def test_single_gpu_line_has_the_contract_fields_and_the_round3_legs():
 
 @pytest.mark.gpu
 def test_gpus_2_without_a_launcher_spawns_its_own_ranks():
-    r, lines = _run(["--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2"] + FAST)
+    r, lines = _run(["--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--cpu-reps", "6", "--route-timeout", "60"]
+                    + [f for f in FAST if f != "--no-cpu-baseline"], timeout=500)
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
     d = json.loads(lines[0])
     import torch
@@ -62,6 +63,17 @@ def test_gpus_2_without_a_launcher_spawns_its_own_ranks():
     assert ex["route"].startswith("torch.distributed") or "ncclCommCount" in str(ex["selection"]) or "rccl_comm_ranks" in ex["selection"]
     assert ex["selection"].get("mode") == "c10d"      # the default route: the job's own process group, no second communicator
     assert d["gpu_timing_mode"] in ("stamp", "kernels")
+    # one run yields the whole route table: the headline's route plus the same timed loop on each other route, each with its
+    # floor and what became of it.  On this box the ranks are gloo processes sharing one GPU: there is no RCCL communicator
+    # to build (dropped, the reports ran on torch.distributed) and the peer windows work between processes on one device
+    routes = d["routes"]
+    assert set(routes) == {"c10d", "rccl", "peer"}, routes
+    assert routes["c10d"]["status"].startswith("ok") and routes["c10d"]["us_median"] > 0
+    assert routes["rccl"]["status"].startswith("dropped") and routes["rccl"]["flagged_set_right"] and routes["rccl"]["floor_us"] > 0
+    assert routes["peer"]["status"] == "ok" and routes["peer"]["flagged_set_right"], routes["peer"]
+    assert routes["peer"]["us_median"] > 0 and routes["peer"]["floor_us"] > 0
+    # rule (d): roofline and cpu_baseline next to the value at every N
+    assert d["roofline"]["kernel"] == "k_row_stats" and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
 
 
 @pytest.mark.gpu
