@@ -60,11 +60,16 @@ TOTAL_RANKS = 8
 SECTIONS = 64
 SAMPLES = 10_000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-# tools/port_vs_reference_timing.py, build container (the only place that has /root/reference), round 4: one rank x 64 sections
-# x 10 000 samples -- reference 37.12 ms (summaries 35.99 + generate_report 1.13), port 37.49 ms (37.22 + 0.27)
-PORT_VS_REFERENCE = {"ratio": 1.01, "reference_ms": 37.12, "port_ms": 37.49, "host": "build container, 8 cpus, 1 torch thread",
-                     "source": "tools/port_vs_reference_timing.py (round 4; 0.99 in round 3)",
-                     "note": "NOT measured by this run: port (oracle/port_mp.py) vs the real reference, timed where both exist"}
+
+def _port_vs_reference():
+    """How the port's timing relates to the REAL reference's: measured where both exist (the build container -- a Python
+    reference cannot travel to the GPU box), both 8-process gloo jobs in the same run, by tools/port_vs_reference_timing.py;
+    the committed fixture is read here, nothing is typed in."""
+    try:
+        with open(os.path.join(REPO, "tests", "golden", "port_vs_reference.json")) as f:
+            return json.load(f)
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def _cpu_baseline(reps: int):
@@ -123,6 +128,8 @@ def _cpu_baseline(reps: int):
     except Exception as e:  # noqa: BLE001  (the single-rank figure still stands)
         single["gloo_job_error"] = str(e)[-300:]
         return single
+    pvr = _port_vs_reference()
+    ratio = (pvr.get("job_8_gloo_ranks") or {}).get("ratio_port_over_reference")
     return {
         "value": round(r["report_us"], 1),
         "unit": "us",
@@ -136,9 +143,11 @@ def _cpu_baseline(reps: int):
         "all_gather_object_of_summaries_us": round(r["all_gather_object_us"], 1),
         "single_rank_no_collectives": single,
         "host_cpus": os.cpu_count(),
-        # the reference tree does not exist on the GPU box, so what is timed is the port; how far the port's timing is
-        # from the real reference's was measured where both exist (build container, same process, same inputs)
-        "quoted_from_profiles": {"port_vs_reference": PORT_VS_REFERENCE},
+        # the reference is Python and cannot travel to the GPU box, so what is timed HERE is the port; the port against the real
+        # reference -- both as 8-process gloo jobs, same run, same inputs -- was measured where both exist (fixture)
+        "port_vs_reference_measured_in_the_build_container": pvr,
+        "reference_equivalent_us": None if not ratio else round(r["report_us"] / ratio, 1),
+        "reference_equivalent_note": "this host's port figure / (port / reference measured in the build container): an estimate, not a measurement",
     }
 
 
