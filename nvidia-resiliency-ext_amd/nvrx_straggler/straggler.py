@@ -135,6 +135,8 @@ class _Lane:
     attribute reads that nothing it depends on has changed, and otherwise says ``_MISS`` BEFORE anything has happened, so the
     general path -- which stays the specification -- runs as if the lane did not exist."""
 
+    trace = None
+
     __slots__ = ("rings", "reporter", "manager", "ext", "plan", "ws", "be", "view", "versions", "wr", "group", "wr_cache",
                  "rows_used", "desc_key", "window", "window_ref", "call", "ctx", "stream", "multi", "enqueue_only",
                  "returns_none", "stats_needed", "gather_on_rank0", "rank", "token", "asynchronous")
@@ -147,7 +149,7 @@ class _Lane:
         if plan is None or not plan.fused or call is None or manager is None or not manager.is_initialized:
             return None
         multi = reporter.world_size > 1 and reporter._exchanged()
-        if (multi and reporter._direct is None) or det._pending_region_switch is not None or reporter._inflight is not None:
+        if (multi and reporter._direct is None) or det._pending_region_switch is not None:
             return None  # (a host-driven exchange: the report is three calls with a collective between them)
         if reporter.asynchronous and not reporter.enqueue_only():
             return None
@@ -192,6 +194,7 @@ class _Lane:
     def run(self, det):
         """The report, or ``_MISS`` (nothing has happened), or -- names incomplete on some rank -- the general path's report."""
         t0 = time.perf_counter_ns()
+        tr = _Lane.trace  # (diagnostics, tools/cadence_kernels_breakdown.py: a list that collects clock marks, normally None)
         reporter, ws, rings = self.reporter, self.ws, self.rings
         if (reporter._ring_plan is not self.plan or det._rings is not rings or det._cupti_manager is not self.manager
                 or self.manager.cupti_ext is not self.ext or rings._rows_used != self.rows_used
@@ -204,6 +207,8 @@ class _Lane:
             reporter._ring_plan = None       # the previous report's table carried an "ids missing" flag: every rank is
             reporter._resync_pending = True  # heading for the name sync now, at the start of its general path
             return _MISS
+        if tr is not None:
+            tr.append(("checks", time.perf_counter_ns() - t0))
         cur = ws._cur
         nxt = ws.blocks[1 - cur]
         if nxt.desc_key != self.desc_key:
@@ -219,7 +224,11 @@ class _Lane:
         elif d.order_after_enabled:
             d.order_after_enabled = 0
         d.seq = ws.seq
+        if tr is not None:
+            tr.append(("settle_flip_desc", time.perf_counter_ns() - t0))
         rc = self.call(self.ctx, nxt.desc_ref, self.stream, self.window_ref)
+        if tr is not None:
+            tr.append(("c_call", time.perf_counter_ns() - t0))
         seq = ws.seq = d.seq
         if rc == _native.WINDOW_MISS:
             ws._cur, ws.block = cur, ws.blocks[cur]  # nothing ran on the block: it is not the current one
@@ -248,8 +257,13 @@ class _Lane:
             return None
         live = _LiveBlock(self.be, ws, seq, self.stats_needed)
         nxt.attach(live)
-        return Report._from_device(_ScoreSource(self.view, live), reporter._shared_rank_to_node(),
-                                   (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank)
+        if tr is not None:
+            tr.append(("live_block", time.perf_counter_ns() - t0))
+        rep = Report._from_device(_ScoreSource(self.view, live), reporter._shared_rank_to_node(),
+                                  (time.perf_counter_ns() - t0) * 1e-6, self.gather_on_rank0, self.rank)
+        if tr is not None:
+            tr.append(("report_object", time.perf_counter_ns() - t0))
+        return rep
 
 
 class _DeviceSideOnDemand(type):

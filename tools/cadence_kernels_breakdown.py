@@ -132,14 +132,23 @@ def one_report(record):
 
 
 acc = []
+lane_marks = []
 for i in range(REPORTS + 3):
+    straggler._Lane.trace = [] if i >= 3 else None
     one_report(acc if i >= 3 else None)
+    if straggler._Lane.trace:
+        lane_marks.append(dict(straggler._Lane.trace))
+straggler._Lane.trace = None
 print(("=== ASYNCHRONOUS, " if ASYNC else "=== synchronous, ") + f"per-kernel mode ({ktrace.timing_mode()}), one report per 40 transformer steps, "
       f"{len(rings.kernel_row_names)} kernel keys, rows_used {rings.rows_used}, {len(acc)} reports")
 for k in ["TOTAL generate_report"] + LABELS + C_LABELS + ["identify_stragglers"]:
     v = [a.get(k, 0) for a in acc]
     n = [a["_calls"].get(k, 0) for a in acc]
     print(f"  {k:62s} median {np.median(v) / 1e3:8.1f} us   p95 {np.percentile(v, 95) / 1e3:8.1f}   calls/report {np.median(n):.0f}")
+if lane_marks:
+    keys = [k for k in ("checks", "settle_flip_desc", "c_call", "live_block", "report_object") if k in lane_marks[0]]
+    print("  inside lane.run, time from its first line (cumulative, median): " +
+          ", ".join(f"{k} {np.median([m.get(k, 0) for m in lane_marks]) / 1e3:.1f} us" for k in keys))
 print("tracer counters:", ktrace.counters())
 
 if "--profile" in sys.argv:
