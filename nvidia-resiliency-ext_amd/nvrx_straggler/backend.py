@@ -40,10 +40,23 @@ def report_timeout_s() -> float:
     a checkpoint or evaluation on one rank, an actual straggler).  The reference simply blocks in its collective
     until the process group's timeout; the default here is c10d's 30 minutes.  ``NVRX_REPORT_TIMEOUT_S`` overrides
     it, ``0`` waits for ever."""
+    t = _timeout_cache[0]
+    if t is None:
+        t = refresh_report_timeout()
+    return t
+
+
+_timeout_cache = [None]  # read once: a report (and the wait for the previous asynchronous one) does not look at the environment
+
+
+def refresh_report_timeout() -> float:
+    """Re-read ``NVRX_REPORT_TIMEOUT_S`` (a process that changes it after its first report calls this)."""
     try:
-        return float(os.environ.get("NVRX_REPORT_TIMEOUT_S", "1800"))
+        t = float(os.environ.get("NVRX_REPORT_TIMEOUT_S", "1800"))
     except ValueError:
-        return 1800.0
+        t = 1800.0
+    _timeout_cache[0] = t
+    return t
 
 
 _backend = None
@@ -125,6 +138,8 @@ class ResultBlock:
         self._host = host
         self.stats = host[self._off_stats : self._off_stats + stats_rows * 32].view(np.float32).reshape(stats_rows, _native.STATS_STRIDE)
         self.meta = host[self._off_meta : self._off_meta + _native.META_WORDS * 4].view(np.uint32)
+        # the same words without numpy (a scalar read of the pinned block through numpy costs a report microseconds when cold)
+        self.meta_words = (ctypes.c_uint32 * _native.META_WORDS).from_address(self.h_ptr + self._off_meta)
         self.scores = host[self._off_scores : self._off_scores + R * W * 4].view(np.float32).reshape(R, W)
         self.flags = host[self._off_flags : self._off_flags + R * W].reshape(R, W)
         self.h_stats_dst = self.d_ptr + self._off_stats
@@ -178,7 +193,7 @@ class ResultBlock:
             live = ref()
             if live is not None:
                 live.detach()
-            elif self.meta[5] != self._live_seq:
+            elif self.meta_words[5] != self._live_seq:
                 self._backend.wait_seq(None, self._live_seq, stats=True, block=self)
 
     def host_block(self) -> np.ndarray:

@@ -156,9 +156,15 @@ class _PendingBlock:
     def complete(self) -> int:
         """Wait until the report has published its results; returns its ``names complete`` word (meta[0])."""
         with self.lock:
-            if self.blob is None and self.blk is not None:
-                self.backend.wait_seq(self.ws, self.seq, block=self.blk)
-                return int(self.blk.meta[0])
+            blk = self.blk
+            if self.blob is None and blk is not None:
+                words = getattr(blk, "meta_words", None)
+                if words is None:  # (the CPU checker backend's block)
+                    self.backend.wait_seq(self.ws, self.seq, block=blk)
+                    return int(blk.meta[0])
+                if words[4] != self.seq:  # (usually published long ago: one look at the word, no call)
+                    self.backend.wait_seq(self.ws, self.seq, block=blk)
+                return words[0]
         return int(self.wait()[0:4].view(np.uint32)[0])
 
     def wait(self) -> np.ndarray:

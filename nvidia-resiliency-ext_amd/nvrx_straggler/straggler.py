@@ -196,10 +196,10 @@ class _Lane:
         t0 = time.perf_counter_ns()
         tr = _Lane.trace  # (diagnostics, tools/cadence_kernels_breakdown.py: a list that collects clock marks, normally None)
         reporter, ws, rings = self.reporter, self.ws, self.rings
-        if (reporter._ring_plan is not self.plan or det._rings is not rings or det._cupti_manager is not self.manager
-                or self.manager.cupti_ext is not self.ext or rings._rows_used != self.rows_used
-                or reporter.asynchronous is not self.asynchronous or det._pending_region_switch is not None
-                or det._mode_agreed != self.token
+        # (what else a lane is built on -- the rings, the profiler, the agreed timing mode -- only changes through Detector
+        #  methods that drop the lane: initialize, shutdown, _apply_pending_mode_switch)
+        if (reporter._ring_plan is not self.plan or rings._rows_used != self.rows_used
+                or reporter.asynchronous is not self.asynchronous
                 or (reporter.name_mapper.version, reporter._private_mapper.version) != self.versions
                 or _dist_utils.world_and_rank(self.group, self.wr_cache) != self.wr):
             return _MISS
@@ -471,6 +471,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
         why = cls._pending_region_switch
         if why is None:
             return
+        cls._lane = None  # (the profiler underneath is about to change)
         if cls.cupti_manager.switch_to_regions():
             cls._pending_region_switch = None
             cls._calib, cls._trace_every, cls._trace_gate, cls._trace_sparse = None, 1, True, False  # (region stamps cost next to nothing)

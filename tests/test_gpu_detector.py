@@ -382,10 +382,18 @@ def test_the_steady_state_lane_reports_exactly_what_the_general_path_reports(asy
             Detector._lanes_enabled = True
             straggler._Lane.run = real_run
 
+    def plain(v):   # NaN scores (a section that holds no samples in a window) must compare equal to themselves
+        if isinstance(v, dict):
+            return {k: plain(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple, set, frozenset)):
+            return type(v)(plain(x) for x in v)
+        return "nan" if isinstance(v, float) and v != v else v
+
     with_lanes, served = run(True)
     without, never = run(False)
     assert never == []
-    assert with_lanes == without
+    for t, (a, b) in enumerate(zip(with_lanes, without)):
+        assert plain(a) == plain(b), (t, a, b)
     assert served.count(True) >= 12, served     # the steady stretches; the changing windows missed and rebuilt
     assert served.count(False) >= 3, served
     flagged = [bool(r[5]) for r in with_lanes]
@@ -397,6 +405,7 @@ def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
     expires the report raises, the workspace whose kernels may still be queued is parked (never reused, never freed
     under them), and the next report runs on a fresh one."""
     from nvrx_straggler import _native
+    from nvrx_straggler import backend as backend_mod
     from nvrx_straggler.backend import get_backend
     from nvrx_straggler.folded import FoldedJob
 
@@ -411,6 +420,7 @@ def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
         ws_before = job.reporter._ring_plan.ws
         big = torch.randn(8192, 8192, device="cuda")
         monkeypatch.setenv("NVRX_REPORT_TIMEOUT_S", "0.02")
+        backend_mod.refresh_report_timeout()
         for blk in ws_before.blocks:  # every result block caches a descriptor (and the timeout in it): make both pick the new one up
             blk.desc_key = None
         with torch.cuda.stream(be.stream):
@@ -420,6 +430,7 @@ def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
             job.report(reset=False)
         assert ws_before in be._retired and ws_before not in be._workspaces.values()
         monkeypatch.setenv("NVRX_REPORT_TIMEOUT_S", "60")
+        backend_mod.refresh_report_timeout()
         be.synchronize()
         assert job.reporter._ring_plan is None  # the generator dropped the plan that pointed at the parked workspace
         again = job.report(reset=False)
@@ -427,6 +438,8 @@ def test_report_timeout_raises_and_the_next_report_recovers(monkeypatch):
         assert again.section_relative_perf_scores == first.section_relative_perf_scores
     finally:
         job.close()
+        monkeypatch.undo()
+        backend_mod.refresh_report_timeout()
 
 
 def test_resident_scorer_never_reads_a_stale_row(monkeypatch):
