@@ -635,6 +635,29 @@ class HipRings:
         if rc < 0:
             _native.check(rc)
 
+    @staticmethod
+    def configure_desc(ws: Workspace, blk: ResultBlock, key: tuple) -> None:
+        """Fill a result block's report descriptor for the switches in ``key`` -- ``(rows_active, stats_rows, do_indiv, do_rel,
+        thresholds, direct, names_ok, wait, resident)`` -- and remember the key (cold: once per block and shape)."""
+        rows_active, stats_rows, do_indiv, do_rel, thresholds, direct, names_ok, wait, resident = key
+        d = blk.desc
+        d.rows_active, d.stats_rows = rows_active, min(stats_rows, ws.stats_rows)
+        d.do_indiv, d.do_rel = int(do_indiv), int(do_rel)
+        d.names_ok = int(names_ok)
+        for i in range(4):
+            d.thresholds[i] = float(thresholds[i])
+        if direct is not None:
+            d.allgather_fn, d.comm = direct.fn_address, direct.comm_address
+        else:
+            d.allgather_fn, d.comm = None, None
+        d.timeout_s = report_timeout_s()
+        d.h_seq_word = blk.h_seq if wait else None
+        d.guard_rings = 0 if wait else 1
+        # resident score kernel on a stream of its own: the library decides among the eligible shapes (no exchange or
+        # peer windows, table fits one workgroup); off when ranks share a device
+        d.resident = 1 if (wait and resident) else 0
+        blk.desc_key = key
+
     def report_fused(self, ws: Workspace, rows_active: int, stats_rows: int, do_indiv: bool, do_rel: bool,
                      thresholds: Sequence[float], direct=None, names_ok: bool = True, wait: bool = True,
                      order_after: Optional[int] = None, resident: bool = True, prev_settled: bool = False) -> int:
@@ -647,22 +670,7 @@ class HipRings:
         d = blk.desc
         key = (rows_active, stats_rows, do_indiv, do_rel, thresholds, direct, names_ok, wait, resident)
         if blk.desc_key != key:  # cold: the switches of this shape changed
-            d.rows_active, d.stats_rows = rows_active, min(stats_rows, ws.stats_rows)
-            d.do_indiv, d.do_rel = int(do_indiv), int(do_rel)
-            d.names_ok = int(names_ok)
-            for i in range(4):
-                d.thresholds[i] = float(thresholds[i])
-            if direct is not None:
-                d.allgather_fn, d.comm = direct.fn_address, direct.comm_address
-            else:
-                d.allgather_fn, d.comm = None, None
-            d.timeout_s = report_timeout_s()
-            d.h_seq_word = blk.h_seq if wait else None
-            d.guard_rings = 0 if wait else 1
-            # resident score kernel on a stream of its own: the library decides among the eligible shapes (no exchange or
-            # peer windows, table fits one workgroup); off when ranks share a device
-            d.resident = 1 if (wait and resident) else 0
-            blk.desc_key = key
+            self.configure_desc(ws, blk, key)
         # prev_settled: the caller has SEEN this context's previous asynchronous report complete (ReportGenerator polls its
         # completion word in _settle_inflight and says so only when that poll returned): the library may then stop guarding
         # the rings against that report and, when reports are rare, enqueue this one on the stream it has to follow.  A wait

@@ -212,7 +212,7 @@ class _Lane:
         cur = ws._cur
         nxt = ws.blocks[1 - cur]
         if nxt.desc_key != self.desc_key:
-            return _MISS
+            rings.configure_desc(ws, nxt, self.desc_key)  # (cold: this block has not run this shape yet)
         if nxt._live is not None:
             nxt.settle()  # (its report of two reports ago: copied out if somebody still holds it)
         ws._cur, ws.block = 1 - cur, nxt
