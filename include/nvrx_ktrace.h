@@ -9,7 +9,7 @@
  * (CuptiProfiler.cpp:168-207, CircularBuffer.h:53-61).  Here a rocprofiler-sdk context with the buffered
  * KERNEL_DISPATCH tracing service does the same job: start/stop map to rocprofiler_start_context /
  * rocprofiler_stop_context (cuptiActivityEnable / Disable, CuptiProfiler.cpp:116-133), finished dispatches arrive
- * from the SDK (completion callbacks by default, buffered records with NVRX_KTRACE_DELIVERY=buffer), and a thread
+ * from the SDK (completion callbacks by default, buffered records with NVRX_DEBUG_KTRACE_DELIVERY=buffer), and a thread
  * of the tracer -- never the one that trains -- appends every duration to its key's ring: the rings are the device
  * rings of libnvrx_straggler_hip.so, reached through a SINK of two plain function pointers
  * (nvrx_ktrace_set_sink), so the two libraries do not link against each other.  Overflow keeps the NEWEST
@@ -105,7 +105,7 @@ int nvrx_ktrace_stop(void);
  * cuptiActivityFlushAll in the reference (straggler.py:234, CuptiProfiler.cpp:138) without waiting for anything
  * else on the device.  Returns 0 when complete, the number of dispatches still missing (> 0) after timeout_s
  * seconds (<= 0: do not wait, just look), or a negative error.  Dispatches are counted by an ENQUEUE callback
- * on the launching thread (one atomic increment); NVRX_KTRACE_COUNT=0 turns the counting off and this call into
+ * on the launching thread (one atomic increment); NVRX_DEBUG_KTRACE_COUNT=0 turns the counting off and this call into
  * "flush until two flushes bring nothing new" (the caller then has to synchronise the device first). */
 int nvrx_ktrace_sync(double timeout_s);
 /* Give up on the dispatches nvrx_ktrace_sync is still missing (call after the device has been synchronised and
@@ -125,7 +125,7 @@ uint64_t nvrx_ktrace_dropped(void);
  * of this library's own engine kernels left out, 7 forgiven dispatches, 8 SDK buffer flushes issued by the pump
  * thread (callback delivery: drains of the inbox), 9 = 1 if dispatches are counted, 11 records of the runtime's memset /
  * memcpy (blit) kernels left out, 12 = 1 if finished dispatches are delivered by completion callbacks (0: buffered
- * records, NVRX_KTRACE_DELIVERY=buffer); under the
+ * records, NVRX_DEBUG_KTRACE_DELIVERY=buffer); under the
  * CURRENT sink: 6 keys that found no row left, 10 keys that were given a row (a host polls this one to learn when new
  * names have turned up). */
 uint64_t nvrx_ktrace_counter(int what);

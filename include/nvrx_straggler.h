@@ -232,7 +232,7 @@ int nvrx_report_local(nvrx_ctx *ctx, float *d_stats, float *d_send, int K, int S
  * `stream` is where the report runs unless it is RE-HOMED: a synchronous report (h_seq_word given, guard_rings 0) that
  * must follow the work of exactly one other stream -- the stream the window's region stamps (nvrx_stamp_end) were
  * launched on and / or order_after_stream -- is enqueued on THAT stream instead, so that the stream order is the
- * dependency and no event is recorded or waited for (NVRX_REPORT_REHOME=0 keeps it on `stream` behind event waits).
+ * dependency and no event is recorded or waited for (NVRX_DEBUG_REPORT_REHOME=0 keeps it on `stream` behind event waits).
  * Replaces Detector.generate_report's body (straggler.py:236-239) + ReportGenerator.generate_report
  * (reporting.py:421-554) for the case where the summaries never leave the device. */
 typedef struct nvrx_report_desc {
@@ -264,7 +264,7 @@ typedef struct nvrx_report_desc {
     int32_t resident;         /* nonzero: the library may run the score kernel RESIDENT on a stream of its own next to the
                                  statistics kernel (rows handed over as 8-byte tagged granules instead of through the
                                  stream order); used for synchronous reports without an exchange or with the peer-window
-                                 exchange that have no other stream's work to wait for (NVRX_RESIDENT_SCORER=0|1|2: never /
+                                 exchange that have no other stream's work to wait for (NVRX_DEBUG_RESIDENT_SCORER=0|1|2: never /
                                  that rule / always).  The statistics rows then land under their own completion word d_meta[5]. */
     int32_t prev_settled;     /* nonzero: the caller has seen this context's previous asynchronous report complete (it polled
                                  that report's completion word): ring writers need not wait for it any more, and an
@@ -301,7 +301,7 @@ int nvrx_window_report(nvrx_ctx *ctx, nvrx_report_desc *desc, void *stream, nvrx
 /* Diagnostics: host clocks of this thread's last nvrx_window_report, microseconds on the monotonic clock -- [0] entry, [1]
  * the wait for the window's measurements and the occupancy look are done, nvrx_report begins (its own clocks follow). */
 int nvrx_window_clocks(double *out2);
-/* Diagnostics: host clocks of this thread's last nvrx_report/* Diagnostics: host clocks of this thread's last nvrx_report, microseconds on the monotonic clock -- [0] entry, [1] stream
+/* Diagnostics: host clocks of this thread's last nvrx_report, microseconds on the monotonic clock -- [0] entry, [1] stream
  * ordering done, [2] staged samples flushed, [3] statistics kernel launched, [4] exchange enqueued, [5] score kernel
  * launched, [6] completion word seen (synchronous reports), [7] spare.  No counterpart in the reference. */
 int nvrx_report_clocks(double *out8);

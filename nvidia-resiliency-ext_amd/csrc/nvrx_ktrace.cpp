@@ -9,7 +9,7 @@
 // appends the batch to the rings through the installed sink with ONE call.  The rings and their statistics live
 // on the device (libnvrx_straggler_hip.so).  What the training thread does at report time is nvrx_ktrace_sync().
 //
-// How the records get here (NVRX_KTRACE_DELIVERY, default `callback`):
+// How the records get here (NVRX_DEBUG_KTRACE_DELIVERY, default `callback`):
 //   * callback: the SDK's KERNEL_DISPATCH callback service with the COMPLETE operation -- the runtime's completion
 //     handler hands every finished dispatch (with its timestamps) to on_dispatch(), which does nothing but append 48
 //     bytes to an INBOX under a mutex nobody holds for longer than a memcpy (the handler also forwards the job's own
@@ -206,7 +206,7 @@ inline uint64_t outstanding(State &s) {
 // situation at import time, where the only other threads are BLAS pool workers parked on a futex.  Otherwise
 // nvrx_ktrace_setup refuses (NVRX_KTRACE_ERR_UNSAFE) and the caller takes the SDK's own route (ROCP_TOOL_LIBRARIES,
 // full search).  NVRX_KTRACE_SCAN_GUARD=0 turns the guard off, =force skips the check;
-// NVRX_KTRACE_SCAN_GUARD_MIN_MB (default 4) is the size from which a library is hidden.  A tool library (one exporting
+// NVRX_DEBUG_KTRACE_SCAN_GUARD_MIN_MB (default 4) is the size from which a library is hidden.  A tool library (one exporting
 // rocprofiler_configure) larger than that would not be discovered by the search while hidden; tools named in
 // ROCP_TOOL_LIBRARIES are loaded by name and unaffected.
 struct HiddenNames {
@@ -523,7 +523,7 @@ void on_dispatch(rocprofiler_callback_tracing_record_t record, rocprofiler_user_
 
 #define KT_DBG(msg)                                                        \
     do {                                                                   \
-        if (getenv("NVRX_KTRACE_DEBUG")) {                                 \
+        if (getenv("NVRX_DEBUG_KTRACE_LOG")) {                                 \
             fprintf(stderr, "[nvrx_ktrace] %s\n", msg);                    \
             fflush(stderr);                                                \
         }                                                                  \
@@ -543,8 +543,8 @@ int tool_init(rocprofiler_client_finalize_t, void *) {
         return -1;
     KT_DBG("tool_init: names context configured");
     if (rocprofiler_create_context(&s.ctx) != ROCPROFILER_STATUS_SUCCESS) return -1;
-    const bool want_callback = !env_is("NVRX_KTRACE_DELIVERY", "buffer");
-    const bool count = !env_is("NVRX_KTRACE_COUNT", "0");
+    const bool want_callback = !env_is("NVRX_DEBUG_KTRACE_DELIVERY", "buffer");
+    const bool count = !env_is("NVRX_DEBUG_KTRACE_COUNT", "0");
     if (want_callback) {
         // ENQUEUE counts the dispatches a window expects, COMPLETE brings each one's timestamps: no buffer, no flush
         rocprofiler_tracing_operation_t dops[] = {ROCPROFILER_KERNEL_DISPATCH_ENQUEUE, ROCPROFILER_KERNEL_DISPATCH_COMPLETE};
@@ -585,7 +585,7 @@ int tool_init(rocprofiler_client_finalize_t, void *) {
     if (rocprofiler_context_is_valid(s.ctx, &valid) != ROCPROFILER_STATUS_SUCCESS || !valid) return -1;
     KT_DBG("tool_init: starting names context");
     if (rocprofiler_start_context(s.names_ctx) != ROCPROFILER_STATUS_SUCCESS) return -1;
-    s.pump_enabled = !env_is("NVRX_KTRACE_PUMP", "0");
+    s.pump_enabled = !env_is("NVRX_DEBUG_KTRACE_PUMP", "0");
     s.ready.store(1, std::memory_order_release);
     KT_DBG("tool_init: done");
     return 0;
@@ -710,7 +710,7 @@ int nvrx_ktrace_setup(int max_pending) {
                                 "while they are all asleep (NVRX_KTRACE_SCAN_GUARD=force overrides, =0 registers without the guard)",
                                 awake);
             }
-            const char *mb = getenv("NVRX_KTRACE_SCAN_GUARD_MIN_MB");
+            const char *mb = getenv("NVRX_DEBUG_KTRACE_SCAN_GUARD_MIN_MB");
             const long min_mb = mb && atol(mb) > 0 ? atol(mb) : 4;
             hidden.hide((size_t)min_mb << 20);
         }

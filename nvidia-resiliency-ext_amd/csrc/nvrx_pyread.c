@@ -44,7 +44,7 @@
  * Objects/dictobject.c: struct _dictkeysobject / PyDictKeyEntry), which is private, so it is fenced three ways:
  *   - compiled only for 3.10 (the layout changed in 3.11);
  *   - a self-test at import builds, clones, fills and reads back a dict through the public API -- any disagreement
- *     turns the path off for the process (NVRX_PYREAD_INPLACE=0 does the same by hand);
+ *     turns the path off for the process (NVRX_DEBUG_PYREAD_INPLACE=0 does the same by hand);
  *   - before EVERY fill the clone is checked: combined table, n entries used, and the key pointer found in each of the
  *     first n entry slots is the very key object expected there.  A layout that differs cannot pass that by accident;
  *     a clone that fails it is filled through PyDict_SetItem instead.
@@ -694,7 +694,7 @@ static struct PyModuleDef pyread_module = {PyModuleDef_HEAD_INIT, "_nvrx_pyread"
 PyMODINIT_FUNC PyInit__nvrx_pyread(void) {
     PyObject *m = PyModule_Create(&pyread_module);
     if (!m) return NULL;
-    const char *e = getenv("NVRX_PYREAD_INPLACE");
+    const char *e = getenv("NVRX_DEBUG_PYREAD_INPLACE");
     g_inplace = (e && e[0] == '0') ? 0 : inplace_self_test();
     return m;
 }

@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(PEER_THREADS) void k_peer_allgather(PeerArgs a) { p
 //     the fabric, so instead of a system-scope release fence (an L2 write-back sweep per wave, ~1.7 us each
 //     on gfx950) every wave drains its own stores with s_waitcnt vmcnt(0), the workgroup meets at a barrier
 //     and lane 0 then stores the sequence word -- PCIe keeps posted writes of one requester in order.
-//     NVRX_SCORE_FENCE=1 (read by the host library) adds the release fence back in front of that store.
+//     NVRX_DEBUG_SCORE_FENCE=1 (read by the host library) adds the release fence back in front of that store.
 // ------------------------------------------------------------------------------------------------
 constexpr int SCORE1_THREADS = 1024;
 constexpr int SCORE1_RESIDENT_THREADS = 256;
@@ -1810,19 +1810,9 @@ const StatsVariant kVariants[] = {
 
 // Smallest variant of the preferred width that holds a whole row in registers.
 const StatsVariant *pick_variant(int row_stride) {
-    static int forced_threads = -1;
-    if (forced_threads < 0) {
-        const char *e = getenv("NVRX_STATS_THREADS");
-        forced_threads = e ? atoi(e) : 0;
-    }
-    const int prefs_default[3] = {512, 1024, 256};
-    int prefs[3] = {prefs_default[0], prefs_default[1], prefs_default[2]};
-    if (forced_threads == 256 || forced_threads == 512 || forced_threads == 1024) {
-        prefs[0] = forced_threads;
-        int j = 1;
-        for (int t : prefs_default)
-            if (t != forced_threads) prefs[j++] = t;
-    } else if (row_stride <= 256 * 4 * 2) {
+    // (the width A/B of rounds 2-3 is answered -- 512 threads, 256 for rows of at most 2048 samples -- and its switch is gone)
+    int prefs[3] = {512, 1024, 256};
+    if (row_stride <= 256 * 4 * 2) {
         prefs[0] = 256;
         prefs[1] = 512;
         prefs[2] = 1024;
@@ -1859,24 +1849,16 @@ int launch_row_stats(const float *d_samples, const uint32_t *d_counts, const uin
     return NVRX_OK;
 }
 
-// NVRX_SCORE_SINGLE_WG=0 keeps the one-workgroup-per-rank score kernel for every shape (A/B measurements);
-// NVRX_SCORE_FENCE=1 puts a system-scope release fence in front of the completion word of k_score1.
-int score_single_wg_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("NVRX_SCORE_SINGLE_WG");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v;
-}
+// The single-workgroup score kernel serves every shape that fits it (the A/B switch of round 2 is gone: answered).
+constexpr int score_single_wg_enabled() { return 1; }
 // The fence-free publication of k_score1 (write-through stores drained per wave, a barrier, then the sequence word)
 // leans on how gfx942 / gfx950 map pinned host memory (uncached, posted PCIe writes of one requester kept in order),
 // not on the HIP memory model: it is used on exactly those two architectures, every other device gets the
-// system-scope release fence in front of the completion word.  NVRX_SCORE_FENCE=0|1 overrides the detection.
+// system-scope release fence in front of the completion word.  NVRX_DEBUG_SCORE_FENCE=0|1 overrides the detection.
 int score_fence_enabled() {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("NVRX_SCORE_FENCE");
+        const char *e = getenv("NVRX_DEBUG_SCORE_FENCE");
         if (e && *e) {
             v = atoi(e) != 0 ? 1 : 0;
         } else {
@@ -1891,28 +1873,20 @@ int score_fence_enabled() {
     return v;
 }
 
-// NVRX_RESIDENT_SCORER: 0 = the score kernel always behind the statistics kernel on the report's stream, 2 = resident
+// NVRX_DEBUG_RESIDENT_SCORER: 0 = the score kernel always behind the statistics kernel on the report's stream, 2 = resident
 // whenever the shape allows it (A/B measurements), 1 / unset = the library decides (see nvrx_report).  Read once per
-// context (nvrx_ctx_create), like NVRX_POLL_NAPS: a report does not call getenv.
+// context (nvrx_ctx_create): a report does not call getenv.
 int resident_scorer_mode_from_env() {
-    const char *e = getenv("NVRX_RESIDENT_SCORER");
+    const char *e = getenv("NVRX_DEBUG_RESIDENT_SCORER");
     const int v = e ? atoi(e) : 1;
     return (v < 0 || v > 2) ? 1 : v;
 }
-int poll_naps_from_env() {
-    const char *e = getenv("NVRX_POLL_NAPS");
-    return e ? std::max(1, atoi(e)) : 4;  // 4 x 64 clk between passes: same latency as 1, less issue pressure on the CU's rows
+constexpr int poll_naps_from_env() {
+    return 4;  // 4 x 64 clk between passes: same latency as 1, less issue pressure on the CU's rows (round-3 A/B, switch gone)
 }
 
-// NVRX_PEER_PROLOGUE=0 keeps the peer-window exchange in its own kernel (A/B measurements).
-int peer_prologue_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("NVRX_PEER_PROLOGUE");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    return v;
-}
+// The peer-window exchange runs as the score kernel's prologue (its own kernel was the slower side of round 3's A/B).
+constexpr int peer_prologue_enabled() { return 1; }
 
 // scratch for the multi-kernel scoring path (large R or K+S): column minima and their per-chunk partials.  One buffer
 // per launch stream -- launches on one stream are ordered, so a buffer is reused safely there, while two contexts
@@ -2019,7 +1993,7 @@ struct nvrx_ctx {
     static constexpr int NSTAMP = NVRX_NSTAMP;
     unsigned long long *d_stamps = nullptr;  // [NSTAMP] begin timestamps, handed out round-robin: the device's g_stamp_slots
                                              // (argument-free begin kernels, the default) or an allocation of this context
-    bool stamps_argfree = true;              // NVRX_STAMP_ARGFREE=0: the one-argument begin kernel
+    bool stamps_argfree = true;              // (false: the one-argument begin kernel -- kept for a context that cannot take the device's slots)
     int stamp_next = 0;
     float us_per_tick = 0.01f;
     struct OpenStamp {
@@ -2044,9 +2018,9 @@ struct nvrx_ctx {
     uint32_t *h_gather_err = nullptr, *d_gather_err = nullptr;  // pinned: epoch of a granule wait that gave up
     uint32_t gran_epoch = 0;
     int wall_khz = 100000;
-    int resident_mode = 1;  // NVRX_RESIDENT_SCORER / NVRX_POLL_NAPS as they stood when the context was created
+    int resident_mode = 1;  // NVRX_DEBUG_RESIDENT_SCORER as it stood when the context was created
     int poll_naps = 4;
-    int rehome_mode = 1;    // NVRX_REPORT_REHOME: synchronous reports may run ON the one stream they must follow
+    int rehome_mode = 1;    // NVRX_DEBUG_REPORT_REHOME: synchronous reports may run ON the one stream they must follow
     // work of ours that may still be running on a stream a re-homed report would not be ordered after (a staging flush
     // forced by a full buffer, device-side appends, bulk appends, history resets, asynchronous reports); cleared when
     // a synchronous report on the context's own stream has completed
@@ -2059,7 +2033,7 @@ struct nvrx_ctx {
     uint64_t side_gen = 1, async_gen = 0;
     bool async_on_ctx = false;            // an asynchronous report may still be running on the context's own stream
     double last_report_us = 0.0;          // monotonic clock of the previous nvrx_report's entry
-    double async_rehome_gap_us = 5000.0;  // NVRX_ASYNC_REHOME_GAP_US: asynchronous reports at least this far apart are re-homed (0 = never)
+    double async_rehome_gap_us = 5000.0;  // NVRX_DEBUG_ASYNC_REHOME_GAP_US: asynchronous reports at least this far apart are re-homed (0 = never)
     hipEvent_t report_ev = nullptr;
     uint64_t report_epoch = 0;  // bumped by every guarded report
     // the stream the last guarded (asynchronous) report's statistics kernel runs on; whether report_ev has been recorded
@@ -2149,12 +2123,12 @@ int order_after_stamps(nvrx_ctx *ctx, hipStream_t stream, hipStream_t also = nul
 // reading d_counts (which stays marked dirty until a later flush uploads it).
 // A staging buffer is free again when the scatter that read it has stored its ticket (k_scatter): usually long ago; else
 // the host spins on the pinned word (cold paths only: new row metadata, or a pusher a whole rotation ahead of the GPU).
-// The wait is bounded (NVRX_STAGE_WAIT_S, default 30 s: the scatter is a microsecond kernel on a stream of our own) and
+// The wait is bounded (NVRX_DEBUG_STAGE_WAIT_S, default 30 s: the scatter is a microsecond kernel on a stream of our own) and
 // looks at the device between slices: a scatter that never runs (device fault, a destroyed stream) becomes a HIP error or
 // a timeout after seconds, not a host thread spinning for half an hour with the context locked.
 double stage_wait_s() {
     static const double v = [] {
-        const char *e = getenv("NVRX_STAGE_WAIT_S");
+        const char *e = getenv("NVRX_DEBUG_STAGE_WAIT_S");
         const double d = e ? atof(e) : 0.0;
         return d > 0.0 ? d : 30.0;
     }();
@@ -2463,9 +2437,9 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
     ctx->resident_mode = resident_scorer_mode_from_env();
     ctx->poll_naps = poll_naps_from_env();
     {
-        const char *e = getenv("NVRX_REPORT_REHOME");
+        const char *e = getenv("NVRX_DEBUG_REPORT_REHOME");
         ctx->rehome_mode = (e && atoi(e) == 0) ? 0 : 1;
-        const char *g = getenv("NVRX_ASYNC_REHOME_GAP_US");
+        const char *g = getenv("NVRX_DEBUG_ASYNC_REHOME_GAP_US");
         if (g && *g) ctx->async_rehome_gap_us = atof(g);
     }
 
@@ -2526,10 +2500,7 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
         ctx->h_gather_err[0] = 0;
         CTX_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->d_gather_err), ctx->h_gather_err, 0));
     }
-    {
-        const char *e = getenv("NVRX_STAMP_ARGFREE");
-        ctx->stamps_argfree = !(e && e[0] == '0');
-    }
+    ctx->stamps_argfree = true;  // (the one-argument begin kernel was the slower side of round 4's A/B; its switch is gone)
     if (ctx->stamps_argfree) {
         CTX_TRY(hipGetSymbolAddress(reinterpret_cast<void **>(&ctx->d_stamps), HIP_SYMBOL(g_stamp_slots)));
     } else {
@@ -3316,12 +3287,12 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     // (tools/cadence_detector_breakdown.py), against 3 us for each of the launches, whose code the training loop keeps
     // warm.  Not for asynchronous reports (they are meant to run BESIDE the next step; re-homed they measured 2.7 % per
     // step instead of 2.0-2.4 % and no gain at cadence), not while work of ours may still be running on the context's
-    // own stream (side_work), NVRX_REPORT_REHOME=0 turns it off.
+    // own stream (side_work), NVRX_DEBUG_REPORT_REHOME=0 turns it off.
     // Asynchronous reports are re-homed too when they are rare (round 4): one that stays on the detector's own stream needs
     // an event record + stream-wait pair to follow the training stream's stamps, and at production cadence those two
     // cold calls were 45-52 us of the 51-116 us an enqueue cost (profiles/r04o).  Re-homed, the report's kernels (~20 us of
     // GPU time) sit in the training stream once per interval instead of beside it -- which is why reports closer together
-    // than NVRX_ASYNC_REHOME_GAP_US (default 5000) stay where they were: a report EVERY step is cheaper beside the step.
+    // than NVRX_DEBUG_ASYNC_REHOME_GAP_US (default 5000) stay where they were: a report EVERY step is cheaper beside the step.
     const bool is_async = d->h_seq_word == nullptr;
     bool async_gap_ok = false;
     {

@@ -13,9 +13,9 @@ import threading
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint32, c_void_p
 
 _LIB_NAME = "libnvrx_straggler_hip.so"
-# NVRX_LIB_DIR: load the native libraries from another directory (the sanitizer build of `make -C csrc asan` lives in
+# NVRX_DEBUG_LIB_DIR: load the native libraries from another directory (the sanitizer build of `make -C csrc asan` lives in
 # lib_asan/; tools/run_sanitized.sh points here)
-_LIB_PATH = os.path.join(os.environ.get("NVRX_LIB_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib"), _LIB_NAME)
+_LIB_PATH = os.path.join(os.environ.get("NVRX_DEBUG_LIB_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib"), _LIB_NAME)
 
 NVRX_ABI_VERSION = 2
 STATS_STRIDE = 8

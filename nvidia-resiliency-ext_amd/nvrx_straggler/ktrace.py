@@ -43,9 +43,9 @@ from .hip_profiler import KernelStats
 
 _log = logging.getLogger(__name__)
 _LIB_NAME = "libnvrx_ktrace.so"
-# NVRX_LIB_DIR: load the native libraries from another directory (the sanitizer build of `make -C csrc asan` lives in
+# NVRX_DEBUG_LIB_DIR: load the native libraries from another directory (the sanitizer build of `make -C csrc asan` lives in
 # lib_asan/; tools/run_sanitized.sh points here)
-_LIB_PATH = os.path.join(os.environ.get("NVRX_LIB_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib"), _LIB_NAME)
+_LIB_PATH = os.path.join(os.environ.get("NVRX_DEBUG_LIB_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib"), _LIB_NAME)
 ERR_UNSAFE = -16
 
 
@@ -214,11 +214,11 @@ def setup(max_pending: int = 0) -> None:
     library only applies it while every other thread of the process is asleep (the situation at import time: BLAS pool
     workers parked on a futex); when it refuses (``NVRX_KTRACE_ERR_UNSAFE``) the SDK's own route is taken instead.
 
-    ``NVRX_KTRACE_FORCE=0`` takes the SDK's own route outright -- the library named in ``ROCP_TOOL_LIBRARIES``, loaded
+    ``NVRX_DEBUG_KTRACE_FORCE=0`` takes the SDK's own route outright -- the library named in ``ROCP_TOOL_LIBRARIES``, loaded
     when the HIP runtime registers with the SDK (what ``rocprofv3`` does for its tool) -- and pays the full search."""
     global _setup_error, _setup_route
     try:
-        if os.environ.get("NVRX_KTRACE_FORCE", "1") != "0":
+        if os.environ.get("NVRX_DEBUG_KTRACE_FORCE", "1") != "0":
             rc = load().nvrx_ktrace_setup(int(max_pending))
             if rc != ERR_UNSAFE:
                 _check(rc)
@@ -455,9 +455,9 @@ def _register_exit_hook() -> None:
 
 def _sync_patience_s() -> float:
     """How long a report waits for the records of its window's kernels before it synchronises the device the reference's
-    way (``NVRX_KTRACE_SYNC_PATIENCE_S``, read when the profiler is built: a report does not look at the environment)."""
+    way (``NVRX_DEBUG_KTRACE_SYNC_PATIENCE_S``, read when the profiler is built: a report does not look at the environment)."""
     try:
-        return float(os.environ.get("NVRX_KTRACE_SYNC_PATIENCE_S", "2.0"))
+        return float(os.environ.get("NVRX_DEBUG_KTRACE_SYNC_PATIENCE_S", "2.0"))
     except ValueError:
         return 2.0
 
@@ -570,7 +570,7 @@ class KernelTraceProfiler:
         for the first time are fetched on top (cold).  Returns the number of dispatches still missing."""
         lib = self._lib
         if wait and not self._counting:
-            # dispatches are not counted (NVRX_KTRACE_COUNT=0, or the SDK refused the ENQUEUE callback): nvrx_ktrace_sync can
+            # dispatches are not counted (NVRX_DEBUG_KTRACE_COUNT=0, or the SDK refused the ENQUEUE callback): nvrx_ktrace_sync can
             # only flush what HAS completed, so the device is waited for first, as the reference does (straggler.py:234)
             import torch
 

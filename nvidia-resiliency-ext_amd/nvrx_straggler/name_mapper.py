@@ -16,7 +16,7 @@ the ids come out the same), and a rank with ``BULK_NAMES`` or more new kernel na
 digests instead of the strings.  SPMD ranks launch the same kernels: every rank then already holds the string of
 every digest and nothing else is sent.  Only digests that some rank cannot resolve cost a second
 ``all_gather_object`` in which the lowest rank that owns each such name supplies it.  Sections (few, short, and
-rank 0 needs the names of sections it never ran) always travel as strings.  ``NVRX_NAME_EXCHANGE=strings`` forces
+rank 0 needs the names of sections it never ran) always travel as strings.  ``NVRX_DEBUG_NAME_EXCHANGE=strings`` forces
 strings everywhere, ``=digests`` digests for any number of names.  Two different names with one digest on a rank
 raise; two ranks holding different names with one digest and no rank holding both cannot be told apart
 (probability ~1e-11 at 10^4 names) -- use ``strings`` if that matters.
@@ -105,7 +105,7 @@ class NameMapper:
         if known != name:
             raise RuntimeError(
                 f"64-bit name digest collision between kernel names {known!r} and {name!r}; "
-                "set NVRX_NAME_EXCHANGE=strings")
+                "set NVRX_DEBUG_NAME_EXCHANGE=strings")
         return d
 
     def sync_names(self, kernel_names: List[str], section_names: List[str]) -> None:
@@ -114,7 +114,7 @@ class NameMapper:
         rank-major, sections before kernels -- exactly the walk of the reference (name_mapper.py:71-81)."""
         new_sections = [n for n in section_names if n not in self.section_name_to_id]
         new_kernels = [n for n in kernel_names if n not in self.kernel_name_to_id]
-        mode = os.environ.get("NVRX_NAME_EXCHANGE", "auto")
+        mode = os.environ.get("NVRX_DEBUG_NAME_EXCHANGE", "auto")
         if mode == "strings":
             # the reference's exchange, verbatim (no digest is ever computed: the escape hatch for a digest collision);
             # the variable must be set on every rank

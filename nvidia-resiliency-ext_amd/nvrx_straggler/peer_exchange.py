@@ -179,10 +179,10 @@ def exchange_mode() -> str:
 
 
 def trial_timeout_s() -> float:
-    """``NVRX_TRIAL_TIMEOUT_S`` (default 5): the longest ONE exchange of a route's trial may take before the route is
+    """``NVRX_DEBUG_TRIAL_TIMEOUT_S`` (default 5): the longest ONE exchange of a route's trial may take before the route is
     given up as not working on this machine."""
     try:
-        v = float(os.environ.get("NVRX_TRIAL_TIMEOUT_S", "5"))
+        v = float(os.environ.get("NVRX_DEBUG_TRIAL_TIMEOUT_S", "5"))
     except ValueError:
         v = 5.0
     return v if v > 0 else 5.0
@@ -242,7 +242,7 @@ def choose(group, backend, rccl, peer, timeout_s: float = 1800.0):
     info = {"mode": mode}
     if peer is not None:
         # the trial must not be able to park a kernel on the GPU for long if a window is unreachable
-        peer.set_timeout(float(os.environ.get("NVRX_PEER_TRIAL_TIMEOUT_S", "5")))
+        peer.set_timeout(float(os.environ.get("NVRX_DEBUG_PEER_TRIAL_TIMEOUT_S", "5")))
     try:
         return _choose(mode, info, group, backend, rccl, peer)
     finally:

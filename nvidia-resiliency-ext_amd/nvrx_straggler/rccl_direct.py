@@ -11,7 +11,7 @@ Only the per-report all-gather goes this way.  Creating the communicator is coll
 once, on the first multi-rank report of a process group whose backend is NCCL (= RCCL on ROCm); the
 unique id travels through ``torch.distributed`` (cold path), and every step is agreed on by all ranks
 (MIN all-reduce of an "ok" flag) so that either every rank uses the direct path or none does -- in
-which case the caller stays on ``dist_utils.all_gather_rows``.  Set ``NVRX_DIRECT_RCCL=0`` to disable.
+which case the caller stays on ``dist_utils.all_gather_rows``.  Opt-in: ``NVRX_EXCHANGE=rccl`` (``peer_exchange.exchange_mode``).
 """
 from __future__ import annotations
 
@@ -121,8 +121,6 @@ def create(group=None, device_index: Optional[int] = None) -> Optional[DirectAll
     stream.  Every rank calls ``generate_report`` at the same point of its program, so the report's all-gather is
     enqueued after the same set of c10d collectives on every rank (no cross-communicator launch-order inversion), and
     ``nvrx_report`` orders the detector's stream after the caller's current stream before it enqueues anything."""
-    if os.environ.get("NVRX_DIRECT_RCCL", "1") == "0":
-        return None
     if not (dist.is_available() and dist.is_initialized()):
         return None
     world = dist.get_world_size(group)

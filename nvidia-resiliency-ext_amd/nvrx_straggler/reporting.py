@@ -43,8 +43,8 @@ _LOG = logging.getLogger(__name__)
 
 def _load_pyread():
     """csrc/nvrx_pyread.c: the same dicts without numpy's intermediate lists (host-side formatting only; same results).
-    ``NVRX_LIB_DIR`` (the sanitizer builds, tools/run_sanitized.sh) may hold its own build of it, which then wins."""
-    alt = os.environ.get("NVRX_LIB_DIR", "")
+    ``NVRX_DEBUG_LIB_DIR`` (the sanitizer builds, tools/run_sanitized.sh) may hold its own build of it, which then wins."""
+    alt = os.environ.get("NVRX_DEBUG_LIB_DIR", "")
     if alt:
         import glob
         import importlib.util
@@ -964,6 +964,13 @@ class ReportGenerator:
 
     def close(self) -> None:
         """Release the direct-exchange communicator (collective-free; safe to call more than once)."""
+        # The remembered (default process group, group, (world, rank)) holds the ProcessGroup OBJECT.  A generator that outlives
+        # destroy_process_group() would keep that object -- and gloo's worker threads, which its destructor joins -- alive
+        # until the interpreter finalises; a worker that then releases the last tensor of its last collective asks for the GIL
+        # of a finalising interpreter, CPython ends the thread with pthread_exit inside a noexcept C++ frame and the process
+        # dies with "terminate called without an active exception" (the once-in-forty child abort of the reference's own
+        # test_sections.py on a loaded host: profiles/r06_reftest_soak.txt has the native stack).
+        self._wr_cache[0] = None
         if self._inflight is not None:
             try:
                 self._settle_inflight()
@@ -1151,7 +1158,7 @@ class ReportGenerator:
                                      self.is_computing_rel_scores, self.thresholds, self._direct if multi else None,
                                      names_ok=names_ok, wait=wait, order_after=order_after if multi else None,
                                      resident=not (multi and getattr(self._direct, "shared_device", False)
-                                                   and os.environ.get("NVRX_RESIDENT_SHARED_OK", "0") in ("", "0")),
+                                                   and os.environ.get("NVRX_DEBUG_RESIDENT_SHARED_OK", "0") in ("", "0")),
                                      prev_settled=self._prev_async_settled)
             if not wait:
                 self._prev_async_settled = False  # until somebody has seen THIS report complete

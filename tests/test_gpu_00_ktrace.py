@@ -558,3 +558,105 @@ def test_both_ranks_trace_at_the_same_thinned_interval_when_one_of_them_exceeds_
         assert cal == [0, 1, 3, 5, 7, 9, 11, 13, 15], r["traced_entries"]
         assert len(r["log"]) == 1
     assert r0["gpu_rel_ranks"] == [0, 1]
+
+
+PROFILER_SCENARIOS_SCRIPT = r'''
+import faulthandler, json, os, sys
+faulthandler.enable()
+faulthandler.dump_traceback_later(170, exit=True)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+os.environ["NVRX_GPU_TIMING"] = "kernels"
+import nvrx_straggler                      # registers the tracer before HIP starts
+import nvrx_cupti_module as cupti_module
+from nvrx_straggler.cupti import CuptiManager
+import torch
+
+plain = lambda st: {k: int(v.num_calls) for k, v in st.items()}
+out = {}
+a = torch.randn(1000, 1000, device="cuda")
+b = torch.randn(1000, 1000, device="cuda")
+torch.matmul(a, b)                          # (the BLAS library's one-time set-up happens outside every scenario)
+torch.cuda.synchronize()
+
+def fresh(**kw):
+    p = cupti_module.CuptiProfiler(**kw)
+    p.initialize()
+    return p
+
+def done(p):
+    p.shutdown(); p.close()
+
+# start / stop / start: only what ran while started is counted (test_cupti_ext.py:50-76)
+p = fresh()
+p.start(); torch.matmul(a, b); torch.cuda.synchronize(); p.stop()
+torch.matmul(a, b); torch.cuda.synchronize()
+p.start(); torch.matmul(a, b); torch.cuda.synchronize(); p.stop()
+out["start_stop"] = plain(p.get_stats())
+# reset empties the results (:79-95)
+p.reset()
+out["after_reset"] = plain(p.get_stats())
+done(p)
+# statsMaxLenPerKernel keeps that many durations per kernel (:98-116)
+p = fresh(statsMaxLenPerKernel=7)
+p.start()
+for _ in range(21):
+    torch.matmul(a, b)
+torch.cuda.synchronize()
+p.stop()
+out["max_stats"] = plain(p.get_stats())
+# one profiler at a time (:119-122)
+try:
+    cupti_module.CuptiProfiler()
+    out["singleton"] = "no error"
+except RuntimeError as e:
+    out["singleton"] = str(e)
+done(p)
+# CuptiManager: nested start / stop, only the outermost pair switches tracing (test_cupti_manager.py:22-47)
+m = CuptiManager(); m.initialize()
+try:
+    m.stop_profiling(); out["stop_without_start"] = "no error"
+except Exception as e:
+    out["stop_without_start"] = type(e).__name__
+m.start_profiling(); m.start_profiling(); m.stop_profiling()
+torch.matmul(a, b); torch.cuda.synchronize()
+m.stop_profiling()
+torch.matmul(a, b); torch.cuda.synchronize()
+out["manager_nested"] = plain(m.get_results())
+m.shutdown()
+# ... and everything launched between the outermost pair is captured, nothing before or after (:50-83)
+m = CuptiManager(); m.initialize()
+for _ in range(100):
+    torch.matmul(a, b)
+m.start_profiling()
+for _ in range(50):
+    torch.matmul(a, b)
+m.start_profiling(); m.stop_profiling()
+for _ in range(50):
+    torch.matmul(a, b)
+m.stop_profiling()
+for _ in range(100):
+    torch.matmul(a, b)
+torch.cuda.synchronize()
+out["manager_all_started"] = plain(m.get_results())
+m.shutdown()
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.gpu
+def test_profiler_and_manager_scenarios_of_the_reference_suite_in_per_kernel_mode():
+    """Own-code twins of the rest of the reference's GPU-only profiler tests (tests/straggler/unit/test_cupti_ext.py:50-122,
+    test_cupti_manager.py:22-83), in the mode whose data model they describe (``NVRX_GPU_TIMING=kernels``): start / stop /
+    start counts two matmuls, reset empties, ``statsMaxLenPerKernel=7`` keeps 7 of 21, a second profiler is refused, nested
+    ``start_profiling`` calls trace from the outermost start to the outermost stop -- 1 matmul, then exactly 100 of 300.
+    Every assertion below is one of theirs (``len(stats) == 1`` and the ``num_calls``)."""
+    out = _run(PROFILER_SCENARIOS_SCRIPT, timeout=200)
+    print("[ktrace scenarios]", {k: (list(v.values()) if isinstance(v, dict) else v) for k, v in out.items()})
+    assert list(out["start_stop"].values()) == [2], out["start_stop"]
+    assert out["after_reset"] == {}
+    assert list(out["max_stats"].values()) == [7], out["max_stats"]
+    assert "Only one CuptiProfiler instance is allowed" in out["singleton"]
+    assert out["stop_without_start"] == "RuntimeError"
+    assert list(out["manager_nested"].values()) == [1], out["manager_nested"]
+    assert list(out["manager_all_started"].values()) == [100], out["manager_all_started"]
+    assert set(out["start_stop"]) == set(out["max_stats"]) == set(out["manager_nested"]) == set(out["manager_all_started"])

@@ -267,7 +267,7 @@ def test_asynchronous_reports_do_not_race_with_device_stamps(monkeypatch, rehome
 
     be = get_backend()
     if rehome_gap_us is not None:
-        monkeypatch.setenv("NVRX_ASYNC_REHOME_GAP_US", rehome_gap_us)  # read when the rings' context is created
+        monkeypatch.setenv("NVRX_DEBUG_ASYNC_REHOME_GAP_US", rehome_gap_us)  # read when the rings' context is created
     Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n", asynchronous=True)
     try:
         with Detector.detection_section("s", profile_cuda=True):
@@ -457,7 +457,7 @@ def test_resident_scorer_never_reads_a_stale_row(monkeypatch):
     from nvrx_straggler import Statistic
     from nvrx_straggler.folded import FoldedJob
 
-    monkeypatch.setenv("NVRX_RESIDENT_SCORER", "2")  # resident whatever the library's own choice would be
+    monkeypatch.setenv("NVRX_DEBUG_RESIDENT_SCORER", "2")  # resident whatever the library's own choice would be
     S, N, R = 6, 1000, 4
     names = [synth.section_name(s) for s in range(S)]
     job = FoldedJob(total_ranks=R, section_names=names, ring_cap=N, node_name="n")
@@ -548,7 +548,7 @@ def test_asynchronous_rehomed_reports_guard_ring_writers_on_other_streams(monkey
     stream it will run on; a sample of window t+1 inside report t would show up as MAX > t."""
     from nvrx_straggler import Detector, Statistic
 
-    monkeypatch.setenv("NVRX_ASYNC_REHOME_GAP_US", "1")
+    monkeypatch.setenv("NVRX_DEBUG_ASYNC_REHOME_GAP_US", "1")
     Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n", asynchronous=True)
     try:
         with Detector.detection_section("s", profile_cuda=True):

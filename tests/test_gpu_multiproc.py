@@ -15,7 +15,7 @@ from util import compare_reports, load_golden
 pytestmark = pytest.mark.gpu
 
 # the peer-window route, with waits short enough for a test
-_PEER_ENV = {"NVRX_EXCHANGE": "peer", "NVRX_REPORT_TIMEOUT_S": "20", "NVRX_PEER_TRIAL_TIMEOUT_S": "5"}
+_PEER_ENV = {"NVRX_EXCHANGE": "peer", "NVRX_REPORT_TIMEOUT_S": "20", "NVRX_DEBUG_PEER_TRIAL_TIMEOUT_S": "5"}
 
 _SCENARIOS = load_golden("scoring.json")["scenarios"]
 # one scenario of every world size / option class (the full list runs on the CPU backend in test_host_logic.py)
@@ -58,8 +58,8 @@ def test_detector_name_change_midway_on_hip_backend(route):
     """Cached-plan reports, then ONE rank meets a new section: every rank must leave the planned path together.
     ``peer+resident``: the real Detector over peer windows with the resident score kernel forced on (its stream is
     ordered after the caller's stream, as in a one-process-per-GPU job)."""
-    env = {} if route == "gloo" else {"NVRX_EXCHANGE": "peer", "NVRX_REPORT_TIMEOUT_S": "20", "NVRX_PEER_TRIAL_TIMEOUT_S": "5",
-                                      "NVRX_RESIDENT_SHARED_OK": "1", "NVRX_RESIDENT_SCORER": "2"}
+    env = {} if route == "gloo" else {"NVRX_EXCHANGE": "peer", "NVRX_REPORT_TIMEOUT_S": "20", "NVRX_DEBUG_PEER_TRIAL_TIMEOUT_S": "5",
+                                      "NVRX_DEBUG_RESIDENT_SHARED_OK": "1", "NVRX_DEBUG_RESIDENT_SCORER": "2"}
     res = run_ranks(workers.detector_name_change_midway, 4, timeout=300, use_oracle_backend=False, device=0, env=env)
     ref = run_ranks(workers.detector_name_change_midway, 4, timeout=300)  # CPU checker backend, same protocol
     for r in range(4):
@@ -176,7 +176,7 @@ def test_config2_loop_over_peer_windows_with_the_resident_scorer():
     process slows processes that poll for each other); forced on here, two processes x 4 logical ranks."""
     g = load_golden("loop.json")
     res = run_ranks(workers.folded_loop_config2, 2, timeout=150, use_oracle_backend=False, device=0,
-                    env={**_PEER_ENV, "NVRX_RESIDENT_SHARED_OK": "1", "NVRX_RESIDENT_SCORER": "2"}, asynchronous=False)
+                    env={**_PEER_ENV, "NVRX_DEBUG_RESIDENT_SHARED_OK": "1", "NVRX_DEBUG_RESIDENT_SCORER": "2"}, asynchronous=False)
     assert res[0]["route"].startswith("xGMI peer stores") and res[0]["fused"]
     for t, exp in enumerate(g["rank0_reports"]):
         got = res[0]["reports"][t]
@@ -263,11 +263,11 @@ def test_a_misbehaving_exchange_route_is_dropped_by_every_rank_together(fault):
     """Route selection under injected failures, through the generic ``allgather_fn`` hook (the same slot ncclAllGather
     fills on a multi-GPU node): an exchange function that fails, one that delivers a wrong table on ONE rank, one whose
     work does not complete on ONE rank.  Every rank must land on torch.distributed together after the checked trial
-    (nobody waits past ``NVRX_TRIAL_TIMEOUT_S`` for one exchange), and the reports that follow must equal the
+    (nobody waits past ``NVRX_DEBUG_TRIAL_TIMEOUT_S`` for one exchange), and the reports that follow must equal the
     reference's (golden ``sections_2ranks_gather1`` / ``mixed_8ranks`` scenarios come from the real reference)."""
     g = next(s for s in _SCENARIOS if s["scenario"]["name"] == "sections_2ranks_gather1")
     sc = g["scenario"]
-    env = {"NVRX_EXCHANGE": "rccl", "NVRX_TRIAL_TIMEOUT_S": "0.5", "NVRX_PEER_TRIAL_TIMEOUT_S": "2", "NVRX_REPORT_TIMEOUT_S": "30"}
+    env = {"NVRX_EXCHANGE": "rccl", "NVRX_DEBUG_TRIAL_TIMEOUT_S": "0.5", "NVRX_DEBUG_PEER_TRIAL_TIMEOUT_S": "2", "NVRX_REPORT_TIMEOUT_S": "30"}
     res = run_ranks(workers.route_fault_injection, sc["world_size"], timeout=300, use_oracle_backend=False, device=0, env=env,
                     fault=fault, scenario=sc)
     for r in range(sc["world_size"]):
@@ -288,7 +288,7 @@ def test_auto_selection_keeps_the_route_that_is_right_when_the_other_one_is_not(
     reports must be the reference's."""
     g = next(s for s in _SCENARIOS if s["scenario"]["name"] == "sections_2ranks_gather1")
     sc = g["scenario"]
-    env = {"NVRX_EXCHANGE": "auto", "NVRX_TRIAL_TIMEOUT_S": "2", "NVRX_PEER_TRIAL_TIMEOUT_S": "2", "NVRX_REPORT_TIMEOUT_S": "30"}
+    env = {"NVRX_EXCHANGE": "auto", "NVRX_DEBUG_TRIAL_TIMEOUT_S": "2", "NVRX_DEBUG_PEER_TRIAL_TIMEOUT_S": "2", "NVRX_REPORT_TIMEOUT_S": "30"}
     res = run_ranks(workers.route_fault_injection, sc["world_size"], timeout=300, use_oracle_backend=False, device=0, env=env,
                     fault="wrong_table", scenario=sc)
     for r in range(sc["world_size"]):

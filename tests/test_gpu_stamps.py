@@ -98,12 +98,12 @@ def test_nested_regions_and_unmatched_end():
 def test_synchronous_report_follows_the_regions_it_reads_without_a_host_wait(monkeypatch, rehome):
     """A synchronous ``Detector.generate_report()`` issued while the GPU is still busy with the very region it has to
     report: the report must contain THIS window's device-stamped sample (count and magnitude), for the re-homed route
-    (the report's kernels enqueued on the stamps' own stream, no events: ``NVRX_REPORT_REHOME=1``, the default once the
+    (the report's kernels enqueued on the stamps' own stream, no events: ``NVRX_DEBUG_REPORT_REHOME=1``, the default once the
     context's own stream is known to be idle) and for the event-ordered route (``=0``).  Alternating regions of very
     different length make a report that ran ahead of its stamp read the PREVIOUS window's value or none at all."""
     from nvrx_straggler import Detector, Statistic
 
-    monkeypatch.setenv("NVRX_REPORT_REHOME", rehome)
+    monkeypatch.setenv("NVRX_DEBUG_REPORT_REHOME", rehome)
     Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n")
     try:
         _spin(0.1)

@@ -1155,7 +1155,7 @@ lib = ktrace.load()
 print("RESULT", mode, int(lib.nvrx_ktrace_ready()), int(lib.nvrx_ktrace_hidden_libraries()), (rchar() - a) / 1e9, time.monotonic() - t)
 '''
     env = dict(os.environ)
-    for k in ("NVRX_GPU_TIMING", "NVRX_KTRACE_FORCE", "NVRX_KTRACE_SCAN_GUARD", "ROCP_TOOL_LIBRARIES"):
+    for k in ("NVRX_GPU_TIMING", "NVRX_DEBUG_KTRACE_FORCE", "NVRX_KTRACE_SCAN_GUARD", "ROCP_TOOL_LIBRARIES"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, "-c", f"REPO = {REPO!r}\n" + code], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]

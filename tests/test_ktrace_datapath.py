@@ -403,7 +403,7 @@ def test_detector_in_per_kernel_mode_conserves_every_duration_under_bursty_deliv
     monkeypatch.setattr(ktrace.KernelTraceProfiler, "_ensure_ready", lambda self: None)
     monkeypatch.setattr(ktrace.KernelTraceProfiler, "start", lambda self, key="": setattr(self, "_started", True))
     monkeypatch.setattr(ktrace.KernelTraceProfiler, "stop", lambda self, *a: (setattr(self, "_started", False), False)[1])
-    monkeypatch.setenv("NVRX_KTRACE_SYNC_PATIENCE_S", "20")
+    monkeypatch.setenv("NVRX_DEBUG_KTRACE_SYNC_PATIENCE_S", "20")
     monkeypatch.setattr(CustomSection, "max_elapseds_len", 4096)
     backend.set_backend(OracleBackend(emulate_fused=True))
     lib = ktrace.load()

@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
 def test_host_code_is_clean_under_asan_and_ubsan():
-    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "NVRX_LIB_DIR")}
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "NVRX_DEBUG_LIB_DIR")}
     r = subprocess.run(["bash", os.path.join(REPO, "tools", "run_sanitized.sh")], env=env, capture_output=True, text=True,
                        timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]

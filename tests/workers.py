@@ -104,7 +104,7 @@ def name_exchange(rank, world, mode):
 
     import torch
 
-    os.environ["NVRX_NAME_EXCHANGE"] = mode
+    os.environ["NVRX_DEBUG_NAME_EXCHANGE"] = mode
     from nvrx_straggler.name_mapper import NameMapper
 
     long = "Cijk_Ailk_Bljk_" + "X" * 500

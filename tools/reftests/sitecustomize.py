@@ -12,7 +12,20 @@ import os
 import sys
 
 _repo = os.environ.get("NVRX_REPO")
-if _repo and os.environ.get("NVRX_REFTEST") == "1":
+if _repo and os.environ.get("NVRX_REFTEST") == "ref":
+    # CONTROL run of tools/reftest_soak.sh: the reference's tests against the REFERENCE ITSELF (build container only), with the
+    # stub native module tests/golden/make_golden.py uses -- does a failure of the harness need this package at all?
+    sys.path.insert(0, os.path.join(_repo, "tests", "golden"))
+    try:
+        import make_golden
+
+        make_golden._install_reference()
+    except Exception as _e:  # noqa: BLE001
+        sys.stderr.write(f"[reftests sitecustomize] reference install failed: {_e!r}\n")
+    import faulthandler
+
+    faulthandler.enable()
+elif _repo and os.environ.get("NVRX_REFTEST") == "1":
     for _p in (os.path.join(_repo, "tests"), _repo, os.path.join(_repo, "nvidia-resiliency-ext_amd")):
         if _p not in sys.path:
             sys.path.insert(0, _p)

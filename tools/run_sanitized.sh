@@ -16,7 +16,7 @@ if [ "$SAN" = asan ]; then
 else
   RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.ubsan_standalone-x86_64.so)
 fi
-export NVRX_LIB_DIR="$REPO/nvidia-resiliency-ext_amd/nvrx_straggler/lib_$SAN"
+export NVRX_DEBUG_LIB_DIR="$REPO/nvidia-resiliency-ext_amd/nvrx_straggler/lib_$SAN"
 export ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1:protect_shadow_gap=0:detect_odr_violation=0${ASAN_OPTIONS:+:$ASAN_OPTIONS}"
 export UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
