@@ -334,7 +334,7 @@ print("RESULT " + json.dumps(out))
 '''
 
 
-def _run_two_ranks(env_extra, cycles, script=None):
+def _run_two_ranks(env_extra, cycles, script=None, world=2, timeout=200):
     import socket
     import tempfile
 
@@ -342,10 +342,10 @@ def _run_two_ranks(env_extra, cycles, script=None):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for rank in range(2):
+    for rank in range(world):
         env = dict(os.environ)
         env.pop("NVRX_GPU_TIMING", None)
-        env.update({"RANK": str(rank), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "NVRX_TEST_INIT": f"tcp://127.0.0.1:{port}",
+        env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "NVRX_TEST_INIT": f"tcp://127.0.0.1:{port}",
                     "NVRX_TEST_CYCLES": str(cycles), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         env.update(env_extra)
         procs.append(subprocess.Popen([sys.executable, "-c", f"REPO = {REPO!r}\n" + (script or COLLECTIVE_SCRIPT)], stdout=subprocess.PIPE,
@@ -353,7 +353,7 @@ def _run_two_ranks(env_extra, cycles, script=None):
     outs = []
     for p in procs:
         try:
-            so, se = p.communicate(timeout=200)
+            so, se = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -660,3 +660,110 @@ def test_profiler_and_manager_scenarios_of_the_reference_suite_in_per_kernel_mod
     assert list(out["manager_nested"].values()) == [1], out["manager_nested"]
     assert list(out["manager_all_started"].values()) == [100], out["manager_all_started"]
     assert set(out["start_stop"]) == set(out["max_stats"]) == set(out["manager_nested"]) == set(out["manager_all_started"])
+
+
+EIGHT_RANKS_SCRIPT = r'''
+import faulthandler, json, os, sys
+faulthandler.enable()
+faulthandler.dump_traceback_later(280, exit=True)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+import nvrx_straggler                      # WORLD_SIZE=8, HIP not up: per-kernel tracing registers now
+from nvrx_straggler import Detector, Statistic, ktrace
+import torch
+import torch.distributed as dist
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                    # eight processes share the one MI355X of the box (gloo group)
+dist.init_process_group("gloo", init_method=os.environ["NVRX_TEST_INIT"], rank=rank, world_size=world)
+torch.manual_seed(0)
+model = torch.nn.Sequential(torch.nn.Linear(512, 1024), torch.nn.GELU(), torch.nn.LayerNorm(1024), torch.nn.Linear(1024, 512)).cuda()
+opt = torch.optim.SGD(model.parameters(), lr=1e-4, momentum=0.9)
+x = torch.randn(256, 512, device="cuda")
+extra = torch.randn(300, 300, device="cuda")
+
+def step():
+    loss = model(x).square().mean()
+    loss.backward()
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    if rank % 3 == 0:
+        (extra @ extra).sum()               # a kernel only SOME ranks launch: NaN for the others, -1 sentinel in the MIN
+    torch.cuda._sleep(int(os.environ["NVRX_TEST_CYCLES"]) * (3 if rank == 5 else 1))   # rank 5: the same kernel, three times as long
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+dist.barrier()
+# BASELINE config #4: individual + relative GPU scores from kernel timing, a collective report EVERY step
+Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name=f"node{rank}", kernel_trace_budget_pct=0.0)
+windows = []
+plain = lambda d: {k: {"MED": float(v[Statistic.MED]), "AVG": float(v[Statistic.AVG]), "NUM": int(v[Statistic.NUM])} for k, v in d.items()}
+for t in range(4):
+    with Detector.detection_section("train_step", profile_cuda=True):
+        step()
+        step()
+    torch.cuda.synchronize()
+    mine = {"kernels": plain(Detector._get_kernel_summaries()), "sections": plain(Detector._get_section_summaries())}   # (peeks: nothing is reset)
+    rep = Detector.generate_report()
+    if rank == 0:
+        mine["report"] = {"gpu_rel": {str(r): float(v) for r, v in rep.gpu_relative_perf_scores.items()},
+                          "gpu_indiv": {str(r): float(v) for r, v in rep.gpu_individual_perf_scores.items()},
+                          "sec_rel": {n: {str(r): float(v) for r, v in d.items()} for n, d in rep.section_relative_perf_scores.items()},
+                          "flagged": sorted(s.rank for s in rep.identify_stragglers()["straggler_gpus_relative"])}
+    else:
+        assert rep is None
+    windows.append(mine)
+out = {"mode": ktrace.timing_mode(), "windows": windows, "counters": ktrace.counters()}
+dist.barrier()
+Detector.shutdown()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.gpu
+def test_config4_at_the_eight_rank_table_shape_on_real_kernel_keys_matches_the_oracle():
+    '''BASELINE config #4 at the R = 8 table shape in per-kernel mode: eight processes, a small training
+    step of real kernels (forward, backward, SGD with momentum: tens of kernel keys by their real mangled names), a kernel
+    only three of the ranks launch, one kernel three times as long on rank 5, a collective report EVERY step.  Each rank
+    hands back the kernel / section summaries it saw (statistics computed on the device); the oracle's restatement of
+    ``ReportGenerator`` (reporting.py:154-554) scores those eight summary sets, and rank 0's report must equal it: every GPU
+    and section score within 1e-4 relative (north_star's tolerance), NaN where the oracle has NaN, the same flagged set.'''
+    import math
+
+    import numpy as np
+
+    from oracle import oracle
+
+    outs = _run_two_ranks({}, cycles=400_000, script=EIGHT_RANKS_SCRIPT, world=8, timeout=400)
+    assert all(o["mode"] == "kernels" for o in outs)
+    port = oracle.RefPortReportGenerator(8)
+    nkeys = set()
+    for t in range(4):
+        ks = [outs[r]["windows"][t]["kernels"] for r in range(8)]
+        ss = [outs[r]["windows"][t]["sections"] for r in range(8)]
+        nkeys |= {k for d in ks for k in d}
+        exp = port.generate_reports(ss, ks)
+        got = outs[0]["windows"][t]["report"]
+
+        def close(a, b, what):
+            if math.isnan(b):
+                assert math.isnan(a), (t, what, a, b)
+            else:
+                assert abs(a - b) <= 1e-4 * abs(b), (t, what, a, b)
+
+        for r in range(8):
+            close(got["gpu_rel"][str(r)], exp["gpu_rel"][r], ("gpu_rel", r))
+            close(got["gpu_indiv"][str(r)], exp["gpu_indiv"][r], ("gpu_indiv", r))
+            close(got["sec_rel"]["train_step"][str(r)], exp["sec_rel"]["train_step"][r], ("sec_rel", r))
+        assert got["flagged"] == sorted(oracle.identify_stragglers(exp["gpu_rel"], 0.75)), (t, got["flagged"], exp["gpu_rel"])
+    some = [k for k in nkeys if "300" in k or "Cijk" in k]
+    print(f"[ktrace 8 ranks] {len(nkeys)} kernel keys over the job; window 3 gpu_rel:", outs[0]["windows"][3]["report"]["gpu_rel"],
+          "flagged", outs[0]["windows"][3]["report"]["flagged"])
+    assert len(nkeys) >= 12, sorted(nkeys)
+    # the extra matmul exists on ranks 0, 3, 6 only
+    only_some = [k for k in nkeys if sum(k in outs[r]["windows"][0]["kernels"] for r in range(8)) == 3]
+    assert only_some, "the kernel that only three ranks launch did not show up as a key of exactly three ranks"
+    for o in outs:
+        c = o["counters"]
+        assert c["lost_no_row"] == 0 and c["sink_errors"] == 0 and c["forgiven"] == 0, c
