@@ -122,6 +122,7 @@ class CustomSection:
 
 
 _MISS = object()  # a lane that cannot serve this report says so; the general path runs
+_TRACED_DISPATCH_US = 1.0  # GPU time one traced dispatch costs (the SDK's completion signal + timestamps), see _trace_every_needed
 
 
 class _Lane:
@@ -332,7 +333,8 @@ class Detector(metaclass=_DeviceSideOnDemand):
     # (profiling_interval x _trace_every)-th entry of a profile_cuda section; while the cost is being measured _trace_gate
     # switches tracing on and off iteration by iteration
     kernel_trace_budget_pct: float = 0.0
-    kernel_trace_cost_pct: Optional[float] = None   # what the calibration measured (None: not measured)
+    kernel_trace_cost_pct: Optional[float] = None   # what the calibration estimated (None: not measured)
+    kernel_trace_dispatches: Optional[int] = None    # ... and how many dispatches a traced iteration had
     _trace_every: int = 1
     _trace_gate: bool = True
     _trace_sparse: bool = False                      # fast check in detection_section: gate closed or _trace_every > 1
@@ -407,7 +409,8 @@ class Detector(metaclass=_DeviceSideOnDemand):
         cls.kernel_trace_budget_pct = max(0.0, float(kernel_trace_budget_pct))
         cls.kernel_trace_cost_pct = None
         cls._trace_every, cls._trace_gate, cls._trace_sparse = 1, True, False
-        cls._calib = ([], []) if (per_kernel and cls.kernel_trace_budget_pct > 0.0) else None
+        cls._calib = ([], [], []) if (per_kernel and cls.kernel_trace_budget_pct > 0.0) else None
+        cls.kernel_trace_dispatches = None
         _log.info("nvrx straggler: GPU time of profile_cuda sections is measured per %s (mode '%s': %s)",
                   "kernel, by kernel name" if per_kernel else "profiled region", _ktrace.timing_mode(), _ktrace.mode_note())
 
@@ -644,7 +647,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
         """One call per training iteration while the cost of tracing is being measured -- the interval tracker's 16 timed
         iterations: iterations alternate between tracing the kernels of their profiled sections and not tracing, each one's
         wall time is the distance between two of these calls."""
-        marks, flags = cls._calib
+        marks, flags, enqueued = cls._calib
         # The iteration's DEVICE work has to be inside its wall time: a GPU-bound loop enqueues a step in a fraction of the time the
         # GPU takes for it, and tracing doubles what a launch costs the HOST -- without the wait the host-side times say "tracing
         # costs 266 %" of a loop it slows down by 1.2 % (profiles/r06d_budget_calibration.txt).  Seventeen device
@@ -659,6 +662,10 @@ class Detector(metaclass=_DeviceSideOnDemand):
             cls._trace_gate, cls._trace_sparse = True, cls._trace_every > 1
             return
         marks.append(time.monotonic())
+        try:
+            enqueued.append(int(cls._cupti_manager.cupti_ext._lib.nvrx_ktrace_counter(0)))  # traced dispatches so far (process-wide)
+        except Exception:  # noqa: BLE001  (no tracer underneath: the A/B of the wall times alone decides)
+            enqueued.append(0)
         on = len(marks) % 2 == 1  # the iteration that starts now: traced after marks 1, 3, 5 ...
         flags.append(on)
         cls._trace_gate = on
@@ -670,10 +677,11 @@ class Detector(metaclass=_DeviceSideOnDemand):
         ``profiling_interval`` at which tracing fits the budget, from the medians of the traced and the untraced iterations."""
         if cls._calib is None:
             return 1.0
-        marks, flags = cls._calib
+        marks, flags, enqueued = cls._calib
         steps = [b - a for a, b in zip(marks, marks[1:])]
         t_on = sorted(t for t, f in zip(steps, flags) if f)
         t_off = sorted(t for t, f in zip(steps, flags) if not f)
+        traced = sorted(b - a for a, b, f in zip(enqueued, enqueued[1:], flags) if f)
         cls.kernel_trace_cost_pct = None
         if not t_on or not t_off:
             return 1.0
@@ -685,7 +693,21 @@ class Detector(metaclass=_DeviceSideOnDemand):
             m_on, m_off = sum(t_on) / len(t_on), sum(t_off) / len(t_off)
         if m_off <= 0.0:
             return 1.0
-        cost = cls.kernel_trace_cost_pct = (m_on - m_off) / m_off * 100.0
+        cost = (m_on - m_off) / m_off * 100.0
+        # Second estimate, from what CAN be measured exactly in 16 iterations: the number of dispatches a traced iteration
+        # had, times what one traced dispatch costs the GPU.  That cost is rocprofiler-sdk's completion signal and timestamps:
+        # 0.3-1.6 us per dispatch on the eleven boxes of rounds 5-6 (docs/MEASUREMENTS.md), 1.0 us assumed.  The A/B above
+        # resolves a launch-bound loop's overhead (tracing doubles what a launch costs the host: tens of per cent) but not one
+        # per cent of a GPU-bound step from eight iterations each way (a box where the paired A/B of 140 steps says 1.4 %
+        # measured 0.03 % here, profiles/r06y_bench_driver.json); the larger estimate decides.
+        if traced:
+            n = traced[(len(traced) - 1) // 2]
+            cls.kernel_trace_dispatches = int(n)
+            model = n * _TRACED_DISPATCH_US * 1e-6 / m_off * 100.0
+            if cls.profiling_interval > 1:
+                model = sum(traced) / len(traced) * _TRACED_DISPATCH_US * 1e-6 / m_off * 100.0
+            cost = max(cost, model)
+        cls.kernel_trace_cost_pct = cost
         if cost <= cls.kernel_trace_budget_pct:
             return 1.0
         return float(min(cls._MAX_TRACE_EVERY, int(-(-cost // cls.kernel_trace_budget_pct))))
@@ -696,16 +718,17 @@ class Detector(metaclass=_DeviceSideOnDemand):
         cover the same share of the entries); it came back with the interval tracker's own all-reduce."""
         mine = int(cls._trace_every_needed())
         cost, n = cls.kernel_trace_cost_pct, len(cls._calib[0]) - 1
+        disp = cls.kernel_trace_dispatches
         cls._calib = None
         every = max(1, min(cls._MAX_TRACE_EVERY, int(agreed))) if agreed else mine
         cls._trace_every, cls._trace_gate = every, True
         cls._trace_sparse = every > 1
         total = cls.profiling_interval * every
         _log.info("nvrx straggler: tracing the kernels of the profiled sections costs this rank %s of an iteration at "
-                  "profiling_interval=%d (%s of %d iterations with and %d without); budget %.2f %%: kernels are traced on every "
+                  "profiling_interval=%d (the larger of: %s of %d iterations with and %d without; %s traced dispatches x 1 us); budget %.2f %%: kernels are traced on every "
                   "%d%s entry of a profile_cuda section%s", "%.2f %%" % cost if cost is not None else "an unmeasured share",
                   cls.profiling_interval, "medians" if cls.profiling_interval == 1 else "means", (n + 1) // 2, n // 2,
-                  cls.kernel_trace_budget_pct, total,
+                  "?" if disp is None else disp, cls.kernel_trace_budget_pct, total,
                   {1: "st", 2: "nd", 3: "rd"}.get(total if total < 20 else total % 10, "th"),
                   "" if every == mine else " (another rank needed the larger interval)")
 

@@ -730,7 +730,7 @@ def detector_mode_agreement_deferred(rank, world):
         Detector.shutdown()
 
 
-def detector_trace_budget(rank, world, cost_ms_by_rank, budget_pct, step_ms=12.0, iters=40, profiling_interval=1):
+def detector_trace_budget(rank, world, cost_ms_by_rank, budget_pct, step_ms=12.0, iters=40, profiling_interval=1, dispatches_per_entry=0):
     """Per-kernel mode emulated at the profiler's surface (the tracer itself needs a GPU): ``start()`` of the profiler costs
     this rank ``cost_ms_by_rank[rank]`` -- what tracing the section's kernels costs -- and a step sleeps ``step_ms``.  The loop
     is the reference's (one section per iteration, ``generate_report_if_interval_elapsed`` after it).  Returns what the
@@ -760,6 +760,8 @@ def detector_trace_budget(rank, world, cost_ms_by_rank, budget_pct, step_ms=12.0
     def start(self, key=""):
         self._started = True
         traced.append(Detector.custom_sections["train_step"].total_entry_cnt - 1)
+        if dispatches_per_entry:  # "the section launched this many kernels while traced": counted as enqueued, like the ENQUEUE callback
+            ktrace.load().nvrx_ktrace_feed(None, int(dispatches_per_entry), 1)
         time.sleep(cost)
 
     KP.start = start
@@ -772,6 +774,7 @@ def detector_trace_budget(rank, world, cost_ms_by_rank, budget_pct, step_ms=12.0
                 time.sleep(step_ms / 1e3)
             assert Detector.generate_report_if_interval_elapsed() is None
         return {"every": Detector._trace_every, "cost_pct": Detector.kernel_trace_cost_pct, "traced": traced,
+                "dispatches": Detector.kernel_trace_dispatches,
                 "cpu_samples": len(Detector.custom_sections["train_step"].cpu_elapsed_times),
                 "iter_interval": Detector.report_interval_tracker.iter_interval,
                 "log": [m for m in records if "budget" in m]}
