@@ -21,4 +21,9 @@ test_wrap_callables.py"
 cd "$REF/tests/straggler"
 ARGS=()
 for m in $MODS; do [ -f "unit/$m" ] && ARGS+=("unit/$m"); done
-python -m pytest -p no:cacheprovider -p nvrx_reftest_plugin -q "${ARGS[@]}" unit/test_interval_tracker.py "$@"
+# The sleep-timed tests stand on a knife's edge by construction (test_interval_tracker.py: exactly 8 of the 16 timed steps are
+# short and the LOWER median is the 8th smallest -- ONE preempted 10 ms step flips the estimate from 50 to 10): where the host
+# allows it the run gets a higher scheduling priority than whatever else is going on (children inherit it).
+NICE=""
+nice -n -10 true 2>/dev/null && NICE="nice -n -10"
+$NICE python -m pytest -p no:cacheprovider -p nvrx_reftest_plugin -q "${ARGS[@]}" unit/test_interval_tracker.py "$@"
