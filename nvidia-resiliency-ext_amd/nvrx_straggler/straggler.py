@@ -204,10 +204,25 @@ class _Lane:
                 or (reporter.name_mapper.version, reporter._private_mapper.version) != self.versions
                 or _dist_utils.world_and_rank(self.group, self.wr_cache) != self.wr):
             return _MISS
-        if self.enqueue_only and reporter._inflight is not None and reporter._settle_inflight():
-            reporter._ring_plan = None       # the previous report's table carried an "ids missing" flag: every rank is
-            reporter._resync_pending = True  # heading for the name sync now, at the start of its general path
-            return _MISS
+        if self.enqueue_only:
+            pend = reporter._inflight
+            if pend is not None:
+                # the previous asynchronous report: usually published long ago -- one look at its completion word (what
+                # ReportGenerator._settle_inflight does behind a lock, a call into the library and numpy)
+                blk = pend.blk
+                words = getattr(blk, "meta_words", None)
+                if words is not None and pend.blob is None and words[4] == pend.seq:
+                    reporter._inflight = None
+                    reporter._prev_async_settled = True
+                    if self.multi:
+                        reporter._check_exchange()
+                    names_missing = words[0] != 1
+                else:
+                    names_missing = reporter._settle_inflight()
+                if names_missing:
+                    reporter._ring_plan = None       # that report's table carried an "ids missing" flag: every rank is
+                    reporter._resync_pending = True  # heading for the name sync now, at the start of its general path
+                    return _MISS
         if tr is not None:
             tr.append(("checks", time.perf_counter_ns() - t0))
         cur = ws._cur

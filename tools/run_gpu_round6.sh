@@ -14,6 +14,7 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=$PWD/gpurun_out/$TAG
 mkdir -p $O
 timeout -s KILL 1800 python -m pytest tests -m gpu -x -q --durations=10 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -n 18 $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -n 2 $O/smoke.log
 bash tools/run_gpu_measure.sh $TAG 2>&1 | tail -n 12 | cut -c1-3000
 timeout 900 python bench.py --gpus 2 --backend gloo --steps 20 --warmup 5 --no-overhead --no-host-inputs --no-extra-legs --no-cadence --cpu-reps 9 2>/dev/null | tail -n 1 > $O/bench_gloo_shared_gpu_n2.json; cut -c1-400 $O/bench_gloo_shared_gpu_n2.json
 for args in "" "--async" "--no-lane" "--no-lane --async"; do
