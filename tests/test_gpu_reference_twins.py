@@ -54,11 +54,17 @@ ran.append("fail_if_not_initialized")
 
 Detector.initialize()
 try:
-    with Detector.detection_section("section00"):                   # :48-54 test_unique_name_is_enforced (skipped there: Cython)
+    # :48-54 test_unique_name_is_enforced is SKIPPED in the reference and the check it tests is commented out in the shipped code
+    # (S/straggler.py:312-316, "TODO: uncomment after Cython issue is resolved"): a name used again from another line is
+    # accepted and lands in the same section.  The twin pins that shipped behaviour; the check itself exists here as there
+    # (Detector._ensure_section_name_is_valid) and raises when called.
+    with Detector.detection_section("section00"):
         pass
+    with Detector.detection_section("section00"):
+        pass
+    assert list(Detector.custom_sections) == ["section00"] and Detector.custom_sections["section00"].total_entry_cnt == 2
     with pytest.raises(ValueError):
-        with Detector.detection_section("section00"):
-            pass
+        Detector._ensure_section_name_is_valid("section00", "elsewhere.py:1")
 finally:
     Detector.shutdown()
 ran.append("unique_name_is_enforced")
