@@ -923,41 +923,84 @@ def _route_leg(route: str, world: int, rank: int, steps: int, warmup: int):
             os.environ["NVRX_EXCHANGE"] = saved
 
 
-def _routes_table(world: int, rank: int, steps: int, warmup: int, headline_route: str, per_route_timeout_s: float, device_index: int):
+def _routes_table(world: int, rank: int, steps: int, warmup: int, headline_route: str, per_route_timeout_s: float, emit):
     """N > 1: the same reports on every OTHER exchange route, so that one run of the driver's scaling bench yields the whole
     table (c10d = the default, rccl = ncclAllGather on a second communicator in the detector's stream, peer = xGMI peer
-    stores into IPC windows).  Each route runs on a helper thread with a deadline: none of the in-stream routes has ever
-    run across two real devices, and a route that hangs must cost its own entry, not the line.  After a timeout nothing
-    collective is attempted any more (the ranks may disagree about where they are) and main() leaves through os._exit."""
+    stores into IPC windows).  The legs run on the MAIN thread, like the headline (on a helper thread the same torch.distributed
+    route measured 1.5-17 x slower than the headline with gloo ranks sharing one GPU, profiles/r06n: not a fair table), under a
+    watchdog: none of the in-stream routes has ever run across two real devices, and a route that does not come back must
+    cost its own entry, not the line -- when a leg's deadline passes the watchdog calls ``emit(table)`` (rank 0 prints the
+    line it has, with the routes seen so far) and the process leaves through os._exit.  ``emit`` prints at most once.
+    Returns (table, clean): ``clean`` False after an error in a leg -- the ranks may then disagree about where they are, so
+    nothing collective may follow."""
     import threading
 
-    table, hung = {}, False
+    table, clean = {}, True
     for route in ("c10d", "rccl", "peer"):
         if route == headline_route:
             continue
-        if hung:
-            table[route] = {"status": "not run: an earlier route did not come back"}
+        if not clean:
+            table[route] = {"status": "not run: an earlier route failed"}
             continue
-        box = {}
 
-        def body(route=route, box=box):
-            try:
-                torch.cuda.set_device(device_index)  # (HIP's current device is per thread)
-                box["out"] = _route_leg(route, world, rank, steps, warmup)
-            except BaseException as e:  # noqa: BLE001
-                box["out"] = {"status": f"error: {type(e).__name__}: {str(e)[-300:]}"}
-
-        th = threading.Thread(target=body, daemon=True)
-        th.start()
-        th.join(per_route_timeout_s)
-        if th.is_alive():
+        def bail(route=route):
             table[route] = {"status": f"timed out after {per_route_timeout_s:.0f} s"}
-            hung = True
-        else:
-            table[route] = box.get("out", {"status": "no result"})
-            if str(table[route].get("status", "")).startswith("error"):
-                hung = True  # (a rank that raised has left the others inside a collective: treat like a hang)
-    return table, hung
+            for later in ("c10d", "rccl", "peer"):
+                if later != headline_route and later not in table:
+                    table[later] = {"status": "not run: an earlier route did not come back"}
+            emit(table)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+
+        timer = threading.Timer(per_route_timeout_s, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            # (test hooks of tests/test_gpu_bench_contract.py: what the line looks like when a leg dies or never comes back)
+            if os.environ.get("NVRX_BENCH_TEST_DIE_IN_ROUTE") == route and rank == 0:
+                import signal
+
+                os.kill(os.getpid(), signal.SIGSEGV)
+            if os.environ.get("NVRX_BENCH_TEST_HANG_IN_ROUTE") == route:
+                time.sleep(10 * per_route_timeout_s)
+            table[route] = _route_leg(route, world, rank, steps, warmup)
+        except BaseException as e:  # noqa: BLE001
+            table[route] = {"status": f"error: {type(e).__name__}: {str(e)[-300:]}"}
+            clean = False  # (a rank that raised has left the others inside a collective; their watchdogs end them)
+        finally:
+            timer.cancel()
+    return table, clean
+
+
+_SIDECAR_SRC = r"""
+import sys, signal
+for s in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+    signal.signal(s, signal.SIG_IGN)
+line = sys.stdin.buffer.readline()
+word = sys.stdin.buffer.readline()
+if word.strip() != b"DONE":
+    sys.stdout.buffer.write(line)
+    sys.stdout.buffer.flush()
+"""
+
+
+def _headline_sidecar(out: dict, headline_mode: str):
+    """A tiny interpreter (no torch, its own session) that is handed the finished line with every other route marked
+    "process died", and prints it only if this process goes away without saying DONE."""
+    import subprocess
+
+    fallback = dict(out)
+    died = {"status": "not known: rank 0's process died during the route legs (a signal inside an untested route); the headline above was complete"}
+    fallback["routes"] = {headline_mode: {"us_median": out.get("us_per_report_median"), "status": "ok (the headline of this line)"},
+                          **{r: dict(died) for r in ("c10d", "rccl", "peer") if r != headline_mode}}
+    try:
+        p = subprocess.Popen([sys.executable, "-S", "-E", "-c", _SIDECAR_SRC], stdin=subprocess.PIPE, start_new_session=True, close_fds=True)
+        p.stdin.write(json.dumps(fallback).encode() + b"\n")
+        p.stdin.flush()
+        return p
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def _self_launch(n: int) -> int:
@@ -1243,12 +1286,6 @@ def main():
         dist.all_reduce(_t, op=dist.ReduceOp.MAX)
         times_max = _t.tolist()
 
-    # the other exchange routes (N > 1): the same timed loop on each, inside a deadline
-    routes, routes_hung = None, False
-    if world > 1 and not args.no_routes:
-        headline_mode = job.reporter.exchange_info.get("mode", "c10d") if job.reporter._direct is None else job.reporter.exchange_info.get("mode", "rccl")
-        routes, routes_hung = _routes_table(world, rank, min(args.steps, 100), min(args.warmup, 10), headline_mode, args.route_timeout, device_index)
-
     # the same kernel with its rows coming from HBM: a 1 GiB sweep between reports evicts L2 and the Infinity Cache
     cold = None
     n8 = None
@@ -1307,7 +1344,7 @@ def main():
                                                               ("per_step_overhead_kernels", "report_at_cadence_kernels", "error") if k in stamp_twin}
 
     overhead = overhead_async = None
-    if not args.no_overhead and not routes_hung:
+    if not args.no_overhead:
         job.backend.synchronize()
         # (collective at N > 1: every rank runs it and a failure is a failure of the job; at N = 1 it is a side leg)
         if world == 1:
@@ -1431,19 +1468,53 @@ def main():
             exchange["us_median"] = round(ex_us, 2) if "us_median" in exchange else None
             exchange["note"] = "enqueue + stream wait of one all-gather of the exchange rows, max over ranks; latency-bound"
             out["exchange"] = exchange
-        if routes is not None:
-            head = {"us_median": out["us_per_report_median"], "status": "ok (the headline of this line)",
-                    "ran_on": getattr(job.reporter._direct, "route", None) or job.reporter.exchange_info.get("route", "torch.distributed")}
-            if exchange and "floor_us" in exchange:
-                head["floor_us"] = exchange["floor_us"]
-            out["routes"] = {job.reporter.exchange_info.get("mode", "c10d"): head, **routes}
         if not args.no_cpu_baseline:
-            # (at N > 1 the other ranks wait at the closing barrier meanwhile: the baseline runs on rank 0's host cores)
+            # (at N > 1 the other ranks wait at the barrier below meanwhile: the baseline runs on rank 0's host cores)
             out["cpu_baseline"] = _side_leg(_cpu_baseline, args.cpu_reps)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
 
-    if routes_hung:
-        # a route leg is still stuck in a collective on its helper thread: nothing can be torn down in order any more
+    # The line is printed exactly once: after the route legs (N > 1), by their watchdog if one of them does not come back, or --
+    # if this process DIES in a leg (none of the in-stream routes has run across two real devices: a fault inside RCCL or an IPC
+    # mapping is a signal, not an exception) -- by a sidecar that holds the headline line and prints it when our pipe closes.
+    import threading
+
+    printed = threading.Lock()
+    sidecar = None
+    if rank == 0 and world > 1 and not args.no_routes:
+        sidecar = _headline_sidecar(out, job.reporter.exchange_info.get("mode", "c10d"))
+
+    def emit(routes=None):
+        if not printed.acquire(blocking=False):
+            return
+        if rank == 0:
+            if sidecar is not None:
+                try:
+                    sidecar.stdin.write(b"DONE\n")
+                    sidecar.stdin.close()
+                    sidecar.wait(timeout=10)
+                except Exception:  # noqa: BLE001
+                    pass
+            if routes is not None:
+                mode = job.reporter.exchange_info.get("mode", "c10d")
+                head = {"us_median": out["us_per_report_median"], "status": "ok (the headline of this line)",
+                        "ran_on": getattr(job.reporter._direct, "route", None) or job.reporter.exchange_info.get("route", "torch.distributed")}
+                if exchange and "floor_us" in exchange:
+                    head["floor_us"] = exchange["floor_us"]
+                out["routes"] = {mode: head, **routes}
+            print(json.dumps(out), flush=True)
+
+    clean = True
+    if world > 1 and not args.no_routes:
+        dist.barrier()  # (rank 0 comes from its CPU baseline: the legs' deadlines start together)
+        headline_mode = job.reporter.exchange_info.get("mode", "c10d") if job.reporter._direct is None else job.reporter.exchange_info.get("mode", "rccl")
+        routes, clean = _routes_table(world, rank, min(args.steps, 100), min(args.warmup, 10), headline_mode, args.route_timeout, emit)
+        emit(routes)
+    else:
+        emit()
+    if not clean:
+        # a leg failed on this rank: its peers are still inside that leg's collectives (their watchdogs end them); nothing can be
+        # torn down in order any more
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)

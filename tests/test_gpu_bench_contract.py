@@ -96,3 +96,29 @@ def test_rccl_needs_one_gpu_per_rank_and_says_so():
     r, lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"] + FAST, timeout=120)
     assert r.returncode != 0 and not lines
     assert "RCCL" in (r.stderr + r.stdout) and "--backend gloo" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_a_route_leg_that_kills_rank_0_still_leaves_the_headline_line():
+    """None of the in-stream routes has run across two real devices: a fault inside one is a signal, not an exception.  The
+    finished headline line is held by a sidecar process and printed when rank 0's pipe closes without DONE."""
+    r, lines = _run(["--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--route-timeout", "60"] + FAST,
+                    env={"NVRX_BENCH_TEST_DIE_IN_ROUTE": "peer"}, timeout=400)
+    assert len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+    assert r.returncode != 0        # (the run did fail: a rank died)
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["ranks"] == 2 and d["roofline"]["kernel"] == "k_row_stats"
+    assert d["routes"]["c10d"]["status"].startswith("ok") and "died" in d["routes"]["peer"]["status"] and "died" in d["routes"]["rccl"]["status"]
+
+
+@pytest.mark.gpu
+def test_a_route_leg_that_never_comes_back_costs_its_own_entry_only():
+    """The legs run on the main thread under a watchdog: when one does not come back inside --route-timeout, rank 0 prints the
+    line it has (the routes measured so far, the stuck one marked) and every rank leaves."""
+    r, lines = _run(["--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--route-timeout", "25"] + FAST,
+                    env={"NVRX_BENCH_TEST_HANG_IN_ROUTE": "peer"}, timeout=400)
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads(lines[0])
+    routes = d["routes"]
+    assert routes["c10d"]["status"].startswith("ok") and routes["peer"]["status"].startswith("timed out")
+    assert routes["rccl"]["status"].startswith("dropped") and routes["rccl"]["us_median"] > 0     # (ran before the stuck one)
