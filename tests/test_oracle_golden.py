@@ -51,8 +51,60 @@ def test_kernel_stats_match_reference_computeStats_golden():
             assert (np.isnan(a) and np.isnan(b)) or a == b, (rec["name"], i, a, b)
 
 
+def _numpy_compute_stats(x):
+    """CuptiProfiler.cpp:44-74 restated a SECOND time, independently of oracle/straggler_oracle.c and of anything compiled
+    from the reference: NumPy f32 scalars, one operation per statement of the source.  ``std::accumulate(..., 0.0f)`` is a
+    sequential f32 sum in sorted order; ``/ n`` divides an f32 by a size_t, i.e. in f32; the squared deviations accumulate
+    in f32 in the same order; ``std::sqrt`` of an f32."""
+    f = np.float32
+    x = np.sort(np.asarray(x, dtype=np.float32), kind="stable")
+    n = x.size
+    if n == 0:
+        return [float("nan")] * 5 + [0.0]
+    med = (x[n // 2 - 1] + x[n // 2]) / f(2) if n % 2 == 0 else x[n // 2]
+    acc = f(0)
+    for v in x:
+        acc = f(acc + v)
+    avg = f(acc / f(n))
+    sq = f(0)
+    for v in x:
+        d = f(v - avg)
+        sq = f(sq + f(d * d))
+    return [float(x[0]), float(x[-1]), float(med), float(avg), float(np.sqrt(f(sq / f(n)))), float(n)]
+
+
+def test_kernel_stats_equal_a_numpy_restatement_on_the_golden_rows_and_on_random_rows():
+    """The pin of ``oracle_kernel_stats`` that needs NO reference build: (1) a second, NumPy restatement of
+    CuptiProfiler.cpp:44-74 agrees with the C restatement bit for bit on every golden row, on lognormal rows of the sizes the
+    rings hold and on rows of repeated / negative / huge values; (2) the one value the reference's own unit test holds for
+    this routine (tests/straggler/unit/test_cupti_ext.py:98-116: 21 durations into a ring of 7 -> ``num_calls == 7``, over the
+    newest 7) comes out of both.  The library compiled
+    behind the stand-in cupti.h (``oracle.ref_lib``) is a second witness on top of this, not the pin."""
+    cases = _cases()
+    rng = np.random.default_rng(11)
+    rows = [np.asarray(v, dtype=np.float32) for v in cases.values()]
+    rows += [rng.lognormal(2.0, 1.0, n).astype(np.float32) for n in (1, 2, 3, 10, 11, 100, 1000, 8192)]
+    rows += [np.full(17, 3.25, np.float32), np.array([-5, 2, -7.5, 1e30, 2, 2], np.float32), np.array([1e-40, 3e-41], np.float32)]
+    with np.errstate(over="ignore", invalid="ignore"):
+        for x in rows:
+            a, b = oracle.kernel_stats(x), _numpy_compute_stats(x)
+            assert np.array_equal(a, np.asarray(b, dtype=np.float64), equal_nan=True), (x[:8], a, b)
+    # the committed golden rows (made through the stand-in build) say what the NumPy restatement says: the fixture is not
+    # taken on the stand-in build's word
+    with np.errstate(over="ignore", invalid="ignore"):
+        for rec in load_golden("native.json")["compute_stats"]:
+            b = _numpy_compute_stats(cases[rec["name"]])
+            assert all((np.isnan(u) and np.isnan(v)) or u == v for u, v in zip(b, rec["expected"])), (rec["name"], b, rec["expected"])
+    durations = rng.lognormal(2.0, 0.2, 21).astype(np.float32)
+    kept = oracle.ring_run(durations, 7)
+    assert np.array_equal(kept, durations[-7:])
+    assert oracle.kernel_stats(kept)[5] == 7 == _numpy_compute_stats(kept)[5]
+    assert np.array_equal(oracle.kernel_stats(kept), np.asarray(_numpy_compute_stats(durations[-7:])))
+
+
 def test_kernel_stats_match_live_reference_build():
-    """Same, against oracle/_ref built from the reference sources (when available here)."""
+    """Same, against oracle/_ref/libnvrx_ref.so (the reference's computeStats compiled behind a stand-in cupti.h: a second
+    witness -- the pin that needs no reference build is the NumPy restatement above)."""
     if oracle.ref_lib() is None:
         pytest.skip("oracle/_ref not built (no /root/reference on this box)")
     rng = np.random.default_rng(5)
@@ -69,7 +121,7 @@ def test_ring_matches_reference_circular_buffer():
         lin = oracle.ring_run(vals, rec["capacity"])
         assert lin.size == rec["size"]
         assert hashlib.sha256(lin.tobytes()).hexdigest() == rec["sha256"]
-        if oracle.ref_lib() is not None:
+        if oracle.ring_ref_lib() is not None:   # (the reference's CircularBuffer.h from its own file alone: no stand-in header)
             assert np.array_equal(lin, oracle.ref_ring_run(vals, rec["capacity"]))
 
 
@@ -264,8 +316,9 @@ def test_kernel_stats_equal_the_live_reference_on_random_rows(x):
 @_PROP
 @given(st.integers(0, 200), st.integers(1, 64))
 def test_ring_equals_the_live_reference_for_any_length_and_capacity(n, capacity):
-    """Overwrite-oldest ring (CircularBuffer.h:53-69): what survives, and in which order."""
-    if oracle.ref_lib() is None:
+    """Overwrite-oldest ring (CircularBuffer.h:53-69): what survives, and in which order.  The checker is the reference's
+    header compiled from its own file alone (oracle/_ref/libnvrx_ring_ref.so: nothing stands in for anything)."""
+    if oracle.ring_ref_lib() is None:
         pytest.skip("oracle/_ref not built (no /root/reference on this box)")
     vals = (np.arange(n, dtype=np.float32) * 0.25 - 3.0)
     assert np.array_equal(oracle.ring_run(vals, capacity), oracle.ref_ring_run(vals, capacity))
@@ -288,3 +341,12 @@ def test_section_stats_equal_torch_on_random_rows(x):
     assert close(got[3], torch.mean(t).item(), rel=1e-12, abs_=1e-300)
     std = torch.std(t).item()
     assert close(got[4], std, rel=1e-9, abs_=1e-9 * max(1.0, float(np.abs(x).max()))) or (np.isnan(std) and np.isnan(got[4]))
+
+
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+@given(hnp.arrays(np.float32, st.integers(0, 120), elements=_F32))
+def test_kernel_stats_equal_a_numpy_restatement_on_arbitrary_rows(x):
+    """The same pin on arbitrary finite f32 rows (duplicates, negatives, denormals, 1e30 -- sums that overflow to inf included)."""
+    with np.errstate(over="ignore", invalid="ignore"):
+        a, b = oracle.kernel_stats(x), _numpy_compute_stats(x)
+    assert np.array_equal(a, np.asarray(b, dtype=np.float64), equal_nan=True), (x.tolist(), a, b)
