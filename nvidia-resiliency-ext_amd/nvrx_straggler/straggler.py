@@ -670,7 +670,7 @@ class Detector(metaclass=_DeviceSideOnDemand):
         try:
             import torch
 
-            if torch.cuda.is_available() and torch.cuda.is_initialized():
+            if torch.cuda.is_initialized() and torch.cuda.is_available():  # (is_available() re-probes a device-less host: 0.6 s per call)
                 torch.cuda.synchronize()
         except RuntimeError:  # (e.g. a stream is being captured into a graph right now: no calibration then)
             cls._calib = None

@@ -18,6 +18,10 @@ def _entry(rank, world, store, fn, kwargs, q, use_oracle_backend, device=None, b
         import torch
 
         torch.set_num_threads(1)
+        if device is None and not os.path.exists("/dev/kfd"):
+            # (a GPU-less host: probe for devices BEFORE anything loads librocprofiler-sdk -- see conftest.probe_devices_first...)
+            torch.cuda.is_available()
+            torch._C._get_accelerator()
         if device is not None:  # GPU tests: several ranks share one device, product backend
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(device)

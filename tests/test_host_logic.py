@@ -651,8 +651,10 @@ def test_kernel_trace_budget_thins_tracing_until_it_fits_and_the_ranks_agree():
     collective of the detector's).  Section wall times are still recorded for every entry."""
     res = run_ranks(workers.detector_trace_budget, 2, cost_ms_by_rank=[3.0, 0.0], budget_pct=5.0, timeout=240)
     r0, r1 = res
-    assert r0["every"] == r1["every"] and 4 <= r0["every"] <= 7, (r0["every"], r1["every"], r0["cost_pct"], r1["cost_pct"])
-    assert 15.0 < r0["cost_pct"] < 40.0 and abs(r1["cost_pct"]) < 5.0, (r0["cost_pct"], r1["cost_pct"])
+    # (the sleeps overshoot under load and under the sanitizer runtime -- 36 % was seen where 25 % is nominal: what is pinned is
+    #  the RULE, every = ceil(measured cost / budget) of the rank that needs more, adopted by both, not the sleep's accuracy)
+    assert r0["every"] == r1["every"] == min(64, math.ceil(r0["cost_pct"] / 5.0)), (r0["every"], r1["every"], r0["cost_pct"], r1["cost_pct"])
+    assert 16.0 < r0["cost_pct"] < 70.0 and abs(r1["cost_pct"]) < 8.0 and 4 <= r0["every"] <= 14, (r0["cost_pct"], r1["cost_pct"])
     assert r0["iter_interval"] == r1["iter_interval"] and r0["iter_interval"] > 1000     # (3600 s / ~13 ms)
     for r in (r0, r1):
         every = r["every"]
