@@ -1518,6 +1518,12 @@ def main():
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)
+    if world > 1:
+        # the line is out; a peer that left through its watchdog (or died) must not keep this rank in the closing barrier for the
+        # process group's ten-minute timeout
+        bye = threading.Timer(120.0, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
     job.close()
     if world > 1:
         dist.barrier()
