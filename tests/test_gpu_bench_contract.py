@@ -122,3 +122,27 @@ def test_a_route_leg_that_never_comes_back_costs_its_own_entry_only():
     routes = d["routes"]
     assert routes["c10d"]["status"].startswith("ok") and routes["peer"]["status"].startswith("timed out")
     assert routes["rccl"]["status"].startswith("dropped") and routes["rccl"]["us_median"] > 0     # (ran before the stuck one)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2])
+def test_the_drivers_own_launch_line_through_torch_distributed_run(n):
+    """What the driver types for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`), here with N = 1 and with two gloo ranks sharing the GPU: rank 0 prints ONE line, the
+    agent exits 0."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "6", "--warmup", "2",
+           "--route-timeout", "60"] + FAST + (["--backend", "gloo"] if n > 1 else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=e, cwd=REPO)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-2500:])
+    d = json.loads(lines[0])
+    assert d["ranks"] == n and d["steps"] == 6 and d["value"] > 0 and d["roofline"]["kernel"] == "k_row_stats"
+    if n > 1:
+        assert set(d["routes"]) == {"c10d", "rccl", "peer"} and d["exchange"]["selection"].get("mode") == "c10d"
