@@ -146,3 +146,24 @@ def test_the_drivers_own_launch_line_through_torch_distributed_run(n):
     assert d["ranks"] == n and d["steps"] == 6 and d["value"] > 0 and d["roofline"]["kernel"] == "k_row_stats"
     if n > 1:
         assert set(d["routes"]) == {"c10d", "rccl", "peer"} and d["exchange"]["selection"].get("mode") == "c10d"
+
+
+@pytest.mark.gpu
+def test_under_the_drivers_launcher_a_rank_0_that_dies_in_a_route_leg_still_leaves_the_headline_line():
+    """The same accident as above, under `torch.distributed.run`: the agent tears the other rank down and exits non-zero; the
+    sidecar (its own session) prints the finished headline line onto the agent's stdout."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e["NVRX_BENCH_TEST_DIE_IN_ROUTE"] = "rccl"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2",
+           "--route-timeout", "60"] + FAST
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=e, cwd=REPO)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode != 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-2500:])
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["ranks"] == 2 and d["routes"]["c10d"]["status"].startswith("ok") and "died" in d["routes"]["rccl"]["status"]
