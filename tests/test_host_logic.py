@@ -677,7 +677,8 @@ def test_kernel_trace_budget_zero_or_cheap_tracing_changes_nothing():
     # a GPU-bound step whose tracing cost does not show in eight iterations each way: the dispatch count decides -- 600 traced
     # dispatches x 1 us on a 12 ms step = 5 % -> every 5th entry at a budget of 1 %
     (model,) = run_ranks(workers.detector_trace_budget, 1, cost_ms_by_rank=[0.0], budget_pct=1.0, iters=30, dispatches_per_entry=600)
-    assert model["dispatches"] == 600 and 4.5 < model["cost_pct"] < 5.2 and model["every"] == 5, model
+    # (600 us over the MEASURED untraced step: 12 ms sleeps that overshoot on a loaded host make it 4.x % -- the rule is pinned)
+    assert model["dispatches"] == 600 and 3.5 < model["cost_pct"] < 5.2 and model["every"] == math.ceil(model["cost_pct"]) in (4, 5, 6), model
     assert "600 traced dispatches x 1 us" in model["log"][0]
     # with profiling_interval=3 the multiple applies to the PROFILED entries: every (3 x N)-th entry is traced
     (thin,) = run_ranks(workers.detector_trace_budget, 1, cost_ms_by_rank=[9.0], budget_pct=10.0, iters=60, profiling_interval=3)
