@@ -27,6 +27,7 @@ def test_host_code_is_clean_under_asan_and_ubsan():
                            timeout=900)
         out = r.stdout + r.stderr
         print("first sanitized run failed without a sanitizer report and was repeated once; its tail:\n" + first)
-    assert r.returncode == 0, out[-3000:]
+    tail = out[-3000:]
+    assert r.returncode == 0, tail
     assert "lib_asan" in r.stdout and " passed" in r.stdout, tail
     assert "runtime error" not in tail and "AddressSanitizer" not in tail, tail
