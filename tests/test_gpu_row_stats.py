@@ -387,3 +387,32 @@ def test_tracer_records_reach_their_rows_through_the_native_sink(be):
     finally:
         prof.close()
         ktrace.KernelTraceProfiler._live = None
+
+
+@pytest.mark.parametrize("stride", [1024, 4096, 10000])
+def test_non_finite_samples_terminate_and_leave_the_other_rows_exact(be, stride):
+    """Durations are finite by construction (clock differences), but ``cpu_elapsed_times.extend`` takes whatever a caller hands
+    it.  A row holding +inf / -inf / NaN must not hang the selection (keys are raw bit patterns: a total order whatever the
+    payload) nor disturb its neighbours; its own MIN / MAX / MED are the reference's wherever the reference's are defined
+    (infinities order like numbers in torch.min / max / median; a NaN makes the reference's answers NaN -- here only "finite
+    rows stay exact and the launch returns" is pinned for it)."""
+    rng = np.random.default_rng(stride)
+    rows = 12
+    m = rng.lognormal(1.0, 0.4, (rows, stride)).astype(np.float32)
+    counts = np.full(rows, stride, dtype=np.uint32)
+    kinds = np.array([0, 1] * (rows // 2), dtype=np.uint8)
+    m[2, 5] = np.inf
+    m[3, 7] = -np.inf
+    m[4, : stride // 2 + 3] = np.inf          # the median itself is +inf
+    m[5, 11] = np.nan
+    m[6, ::3] = np.nan
+    m[7, :] = np.inf
+    got = _run(be, m, counts, kinds)          # (a hang would be the test's timeout)
+    assert got.shape[0] == rows and (got[:, 5] == stride).all()
+    finite_rows = [0, 1, 8, 9, 10, 11]
+    _check_against_oracle(got[finite_rows], m[finite_rows], counts[finite_rows], kinds[finite_rows], "finite rows next to non-finite ones")
+    # infinities: selections as numbers
+    assert got[2, 1] == np.inf and got[2, 0] == m[2][np.isfinite(m[2])].min()
+    assert got[2, 2] == np.float32(oracle.rows_stats(m[2:3], counts[2:3], kinds[2:3])[0, 2])
+    assert got[3, 0] == -np.inf and got[3, 2] == np.float32(oracle.rows_stats(m[3:4], counts[3:4], kinds[3:4])[0, 2])
+    assert got[4, 2] == np.inf and got[7, 0] == np.inf and got[7, 1] == np.inf and got[7, 2] == np.inf
