@@ -106,9 +106,11 @@ for i in range(REPS):
 t0 = time.perf_counter_ns()
 missing = Detector.cupti_manager.harvest(wait=True)          # what generate_report() does first: waits for the window's kernels
 t_wait = (time.perf_counter_ns() - t0) / 1e3
-t0 = time.perf_counter_ns()
-again = Detector.cupti_manager.harvest(wait=True)            # everything has arrived: the training thread's steady-state cost
-t_idle = (time.perf_counter_ns() - t0) / 1e3
+t_idle = 1e30
+for _ in range(5):                          # (the best of five: one preempted call must not decide a 50 us bound)
+    t0 = time.perf_counter_ns()
+    again = Detector.cupti_manager.harvest(wait=True)        # everything has arrived: the training thread's steady-state cost
+    t_idle = min(t_idle, (time.perf_counter_ns() - t0) / 1e3)
 c1 = ktrace.counters()
 recs = ktrace.drain_all()                   # the tap: every duration the tracer's thread handed to the rings, in order
 lib.nvrx_ktrace_tap(0)
