@@ -67,6 +67,19 @@ def _load_pyread():
 
 
 _pyread = _load_pyread()
+# (said once, at INFO: which of the three formatting paths -- all with the same results -- this interpreter gets)
+if _pyread is None:
+    _LOG.info("nvrx straggler: csrc/nvrx_pyread.c is not built for this interpreter; a report's dicts are built by the Python "
+              "builders (same results, slower reads)")
+else:
+    try:
+        if not _pyread.inplace():
+            import sys as _sys
+
+            _LOG.info("nvrx straggler: the in-place fill of a report's cloned dicts follows CPython 3.10's dict layout; Python %d.%d "
+                      "uses the public dict API instead (same results, ~10 us more per fully read 8 x 64 report)", *_sys.version_info[:2])
+    except Exception:  # noqa: BLE001  (an older build of the helper without the query)
+        pass
 
 
 def _copy_sets(d: Dict[str, set]) -> Dict[str, set]:
