@@ -2041,6 +2041,7 @@ struct nvrx_ctx {
     // which the caller has seen the guarded reports complete (nothing has to wait for those any more)
     hipStream_t guard_stream = nullptr;
     bool guard_recorded = true;
+    bool stamps_used = false;  // a stamp kernel has written this context's rings (region timing): see nvrx_report, guard_rings
     uint64_t guard_done_epoch = 0;
     struct StreamEpoch {
         hipStream_t stream;
@@ -2441,6 +2442,8 @@ int nvrx_ctx_create(int device, int local_ranks, int rows_per_rank, int ring_cap
         ctx->rehome_mode = (e && atoi(e) == 0) ? 0 : 1;
         const char *g = getenv("NVRX_DEBUG_ASYNC_REHOME_GAP_US");
         if (g && *g) ctx->async_rehome_gap_us = atof(g);
+        const char *eg = getenv("NVRX_DEBUG_EAGER_GUARD");  // (A/B: the guard event of every asynchronous report recorded at once)
+        ctx->stamps_used = eg && atoi(eg) != 0;
     }
 
 #define CTX_TRY(expr)                                                                         \
@@ -3161,6 +3164,7 @@ int nvrx_stamp_end(nvrx_ctx *ctx, int row, int cpu_row, float cpu_value, void *s
             int grc = guard_ring_writer(ctx, st);
             if (grc) return grc;
         }
+        ctx->stamps_used = true;
         hipLaunchKernelGGL(k_stamp_end, dim3(1), dim3(1), 0, st, slot_ptr, ctx->us_per_tick, dst_gpu, dst_cpu, cpu_value);
         HIP_TRY(hipGetLastError());
         if (std::find(ctx->stamp_streams.begin(), ctx->stamp_streams.end(), st) == ctx->stamp_streams.end())
@@ -3446,8 +3450,14 @@ int nvrx_report(nvrx_ctx *ctx, nvrx_report_desc *d, void *stream) {
     if (d->guard_rings) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         ctx->guard_stream = as_stream(stream);
-        if (rehomed) {
-            ctx->guard_recorded = false;  // writers on this very stream follow by stream order; anybody else records it (guard_ring_writer)
+        if (rehomed || !ctx->stamps_used) {
+            // writers on this very stream follow by stream order; anybody else records the event (guard_ring_writer).  Also
+            // when no stamp kernel has ever written these rings (per-kernel timing, sections without GPU time): every writer
+            // there is -- the scatter of staged samples, from the training thread or the kernel tracer's -- is on the context's
+            // own stream, the one this report is on, and the eager record below would be 5 us of a cold enqueue for nobody.
+            // With stamps the event stays eager: recorded lazily it would sit behind the SCORE kernel too, which on an
+            // in-stream exchange route waits for the slowest peer -- and the training stream's next stamp with it.
+            ctx->guard_recorded = false;
         } else {
             HIP_TRY(hipEventRecord(ctx->report_ev, as_stream(stream)));
             ctx->guard_recorded = true;

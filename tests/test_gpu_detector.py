@@ -581,6 +581,51 @@ def test_asynchronous_rehomed_reports_guard_ring_writers_on_other_streams(monkey
         Detector.shutdown()
 
 
+def test_asynchronous_reports_without_stamps_guard_ring_writers_on_other_streams():
+    """A context whose rings no stamp kernel has ever written (per-kernel timing, sections without GPU time) records no guard
+    event when it enqueues an asynchronous report: every writer it knows is on its own stream.  A device-side append from
+    ANOTHER stream -- part of the ABI -- must still not overtake the report's statistics kernel: the guard records the event
+    lazily when such a writer turns up.  A ~3 ms kernel is parked on the detector's stream in front of every report; window
+    t+1 is appended from a second / third stream right after report t was enqueued (the rings were reset: it lands in the very
+    slots report t still has to read); a sample of window t+1 inside report t would show up as MAX > t."""
+    from nvrx_straggler import Detector, Statistic
+    from nvrx_straggler import backend as backend_mod
+
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n", asynchronous=True)
+    try:
+        with Detector.detection_section("s", profile_cuda=False):
+            pass
+        Detector.generate_report()
+        rings = Detector.rings
+        be = backend_mod.get_backend()
+        row = Detector.custom_sections["s"].row
+        big = torch.randn(8192, 8192, device="cuda")
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        values = [torch.full((3,), float(t), device="cuda") for t in range(0, 31)]
+        torch.cuda.synchronize()
+
+        def append(t, st):
+            rc = rings.lib.nvrx_ring_push_device(rings.ctx, row, values[t].data_ptr(), 3, st.cuda_stream)
+            assert rc == 0, rc
+
+        append(1, streams[1])
+        prev, seen = None, 0
+        for t in range(1, 30):
+            with be.stream_context():
+                (big @ big).sum()            # ~3 ms: the report of this window queues behind it on the detector's stream
+            rep = Detector.generate_report()  # returns at once
+            append(t + 1, streams[t % 2])     # window t+1, from another stream, into the slots report t reads
+            if prev is not None:
+                s = prev.local_section_summaries["s"]
+                assert s[Statistic.NUM] == 3 and s[Statistic.MIN] == s[Statistic.MAX] == float(t - 1), (t, s)
+                seen += 1
+            prev = rep
+        torch.cuda.synchronize()
+        assert seen == 28 and prev.local_section_summaries["s"][Statistic.MAX] == 29.0
+    finally:
+        Detector.shutdown()
+
+
 def test_initialize_before_the_gpu_is_selected_binds_nothing():
     """The reference's example order (examples/straggler/example.py:60-66): ``Detector.initialize()`` first, the device
     afterwards.  In a fresh interpreter: after ``initialize`` no engine exists and PyTorch's CUDA state is untouched; the
