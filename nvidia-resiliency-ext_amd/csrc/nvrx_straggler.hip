@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -3540,6 +3541,10 @@ int nvrx_window_report(nvrx_ctx *ctx, nvrx_report_desc *desc, void *stream, nvrx
         if (enqueue_only) {  // durations that arrive from here to the ring reset below stay with the tracer's thread
             w->kt_hold(1);
             held = true;
+            // (test hook, NVRX_DEBUG_WINDOW_HOLD_US: stay under the hold for a while, so that the tracer's thread consumes a batch
+            //  -- parks it -- before the window is judged; tests/test_gpu_01_ktrace_datapath.py, the changed-rows case)
+            static const int hold_us = [] { const char *e = getenv("NVRX_DEBUG_WINDOW_HOLD_US"); return e ? atoi(e) : 0; }();
+            if (hold_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(hold_us));
         }
         const int missing = w->kt_sync(enqueue_only ? 0.0 : w->kt_patience_s);
         if (missing < 0) return leave(fail(NVRX_ERR_STATE, "the kernel tracer's sync failed (%d)", missing));
@@ -3552,11 +3557,21 @@ int nvrx_window_report(nvrx_ctx *ctx, nvrx_report_desc *desc, void *stream, nvrx
     }
     {
         // (a look, nothing stored: when the set changed the caller's general path asks nvrx_ring_occupancy_changed itself)
-        std::lock_guard<std::mutex> lk(ctx->mu);
+        // leave() lifts the tracer's hold, and lifting it hands parked durations to the sink, which takes ctx->mu (the tracer's
+        // lock order is its own mutex, then the context's): never called with ctx->mu held -- an asynchronous per-kernel report
+        // that found the occupied rows changed used to do exactly that and could deadlock against the tracer's thread
+        // (tools/soak.py in per-kernel mode, once in ~10 000 reports)
         const int n = w->rows_used;
-        if (n < 0 || n > ctx->rows) return leave(fail(NVRX_ERR_INVALID, "rows_used %d outside [0,%d]", n, ctx->rows));
-        bool changed = ctx->occupied_rows != n;
-        for (int r = 0; r < n && !changed; r++) changed = ctx->occupied_seen[(size_t)r] != (uint8_t)(ctx->total[(size_t)r] != 0);
+        bool bad = false, changed = false;
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            bad = n < 0 || n > ctx->rows;
+            if (!bad) {
+                changed = ctx->occupied_rows != n;
+                for (int r = 0; r < n && !changed; r++) changed = ctx->occupied_seen[(size_t)r] != (uint8_t)(ctx->total[(size_t)r] != 0);
+            }
+        }
+        if (bad) return leave(fail(NVRX_ERR_INVALID, "rows_used %d outside [0,%d]", n, ctx->rows));
         if (changed) return leave(NVRX_WINDOW_MISS);
     }
     g_window_clk[1] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -238,6 +238,74 @@ def test_asynchronous_reports_in_per_kernel_mode_do_not_wait_and_lose_nothing():
     assert out["counters"]["enqueued"] == out["counters"]["arrived"] + out["counters"]["forgiven"]
 
 
+MISS_SCRIPT = r'''
+import faulthandler, json, os, sys, threading, time
+faulthandler.enable()
+faulthandler.dump_traceback_later(90, exit=True)   # (the bug this pins was a deadlock: say where)
+sys.path[:0] = [os.path.join(REPO, "nvidia-resiliency-ext_amd"), REPO, os.path.join(REPO, "tests")]
+os.environ["NVRX_GPU_TIMING"] = "kernels"
+import torch
+import nvrx_straggler
+from nvrx_straggler import Detector, Statistic, ktrace
+
+torch.cuda.set_device(0)
+x = torch.randn(64, 64, device="cuda")
+Detector.initialize(scores_to_compute="all", gather_on_rank0=True, node_name="n0", asynchronous=True)
+lib = ktrace.load()
+stop = []
+
+def drainer():
+    # a second drainer beside the pump: while kernels of a window are still completing it keeps emptying the inbox, so that a
+    # batch is consumed INSIDE the few microseconds a report holds the tracer with high probability
+    while not stop:
+        lib.nvrx_ktrace_sync(0.002)
+
+th = threading.Thread(target=drainer, daemon=True)
+th.start()
+windows, lanes_missed, total = 160, 0, 0
+for w in range(windows):
+    with Detector.detection_section("step", profile_cuda=True):
+        y = x
+        for _ in range(300):                 # ~300 tiny kernels: still completing, one every few microseconds, when the report comes
+            y = y + 1.0
+    if w % 4 == 3:                           # three steady windows (a lane is built), then one whose occupied rows differ
+        with Detector.detection_section("sometimes", profile_cuda=False):
+            pass
+    had_lane = Detector._lane is not None
+    report = Detector.generate_report()      # asynchronous: holds the tracer, finds the rows changed, lifts the hold
+    lanes_missed += int(had_lane and w % 4 == 3 and w > 4)
+    ks = report.local_kernel_summaries
+    total += sum(int(v[Statistic.NUM]) for v in ks.values())
+stop.append(1)
+th.join()
+torch.cuda.synchronize()
+lib.nvrx_ktrace_sync(5.0)                    # (a completion callback may run a moment after the stream reports the kernel finished)
+last = Detector.generate_report().local_kernel_summaries
+total += sum(int(v[Statistic.NUM]) for v in last.values())
+c = ktrace.counters()
+Detector.shutdown()
+print("RESULT " + json.dumps({"windows": windows, "lanes_missed": lanes_missed, "total": total, "counters": c}))
+'''
+
+
+@pytest.mark.gpu
+def test_an_asynchronous_window_whose_rows_changed_lifts_the_tracers_hold_without_the_contexts_lock():
+    """``nvrx_window_report`` (the lane's one C call) holds the tracer while an asynchronous per-kernel report is enqueued; when
+    it finds that the set of occupied rows has changed it says MISS and lifts the hold -- which hands the durations parked
+    meanwhile to the sink, and the sink takes the context's mutex.  Up to round 6's last session the hold was lifted INSIDE the
+    scope that held that mutex: a self-deadlock whenever a batch had been consumed during those microseconds, met by
+    tools/soak.py in per-kernel mode once in ~10 000 reports.  Here a second drainer thread empties the inbox all the time
+    while hundreds of tiny kernels of the window are still completing, and every fourth window changes the occupied rows under
+    a lane: with the old library the process stops in its first dozens of windows (the control is in
+    profiles/r06ae_window_miss_deadlock.txt)."""
+    out = _run(MISS_SCRIPT, {"NVRX_DEBUG_WINDOW_HOLD_US": "300"}, timeout=150)
+    c = out["counters"]
+    print("[ktrace miss]", out["lanes_missed"], "lane windows met changed rows;", out["total"], "kernel samples reported")
+    assert out["lanes_missed"] >= 20, out                       # the lane really was in place when the rows changed
+    assert c["enqueued"] == c["arrived"] + c["forgiven"] and c["forgiven"] == 0 and c["sink_errors"] == 0 and c["lost_no_row"] == 0
+    assert out["total"] == c["delivered"], out                   # every delivered duration was reported exactly once
+
+
 SOAK_SCRIPT = r'''
 import faulthandler, json, os, sys, threading, time
 faulthandler.enable()

@@ -11,7 +11,12 @@ import synth
 from nvrx_straggler import Detector, Statistic
 from nvrx_straggler.folded import FoldedJob
 
+from nvrx_straggler import ktrace
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+per_kernel = ktrace.timing_mode() == "kernels"
+import faulthandler
+faulthandler.dump_traceback_later(budget + 45.0, exit=True)  # a flow that never comes back says where it is
 torch.cuda.set_device(0)
 rng = np.random.default_rng(int(time.time()) % 1000)
 t_end = time.time() + budget
@@ -62,7 +67,14 @@ while time.time() < t_end:
         if rng.random() < 0.6:
             rep_, steps_ = held.pop(int(rng.integers(0, len(held))))
             assert rep_.local_section_summaries["fwd"][Statistic.NUM] == steps_
-            assert abs(rep_.gpu_relative_perf_scores[0] - 1.0) < 1e-5 and rep_.identify_stragglers()["straggler_gpus_relative"] == set()
+            g = rep_.gpu_relative_perf_scores[0]
+            if per_kernel and asynchronous and g != g:
+                # per-kernel timing, asynchronous: a report does not wait for its window's kernels -- a window whose kernels had not
+                # completed when it was enqueued has no GPU samples (they count in the next one) and scores NaN, never a wrong number
+                counts["async_windows_without_kernel_samples"] = counts.get("async_windows_without_kernel_samples", 0) + 1
+            else:
+                assert abs(g - 1.0) < 1e-5, (g, asynchronous, steps_, rep_.local_kernel_summaries)
+            assert rep_.identify_stragglers()["straggler_gpus_relative"] == set()
         if len(held) > 3:
             held.pop(0)            # never read
         counts["detector_reports"] += 1
