@@ -12,8 +12,13 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_soak_of_the_product_flows_for_a_few_seconds():
+@pytest.mark.parametrize("mode", ["default", "kernels"])
+def test_soak_of_the_product_flows_for_a_few_seconds(mode):
+    """``kernels``: the same flows with GPU time measured per kernel by the tracer (what a multi-rank job runs) -- the long form of
+    this mode found the deadlock of ``nvrx_window_report`` (profiles/r06ae_window_miss_deadlock.txt)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "NVRX_GPU_TIMING")}
+    if mode != "default":
+        env["NVRX_GPU_TIMING"] = mode
     p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "soak.py"), "8"], capture_output=True, text=True, timeout=240, env=env)
     assert p.returncode == 0, p.stdout[-1500:] + "\n" + p.stderr[-3000:]
     assert "soak ok" in p.stdout
