@@ -1003,9 +1003,13 @@ class ReportGenerator:
         be = _backend_mod.get_backend()
         exchanged = self._exchanged()
         mapper = self.name_mapper if exchanged else self._private_mapper
-        if resync_first:
+        if resync_first and exchanged and self.world_size > 1:
             # the planned path already ran this report's first exchange and saw an incomplete flag:
-            # every rank is now heading for the name sync, so join it before exchanging rows again
+            # every rank is now heading for the name sync, so join it before exchanging rows again.
+            # (Only where rows ARE exchanged: a generator that scores this rank alone -- individual scores, no gather -- has
+            # nobody heading anywhere; its own new names get their ids in the loop below.  An asynchronous generator of that
+            # kind used to call the collective here, alone, the report after one of ITS sections first appeared: the rank hung
+            # in all_gather_object while its peers trained on -- tools/soak_mp.py, profiles/r06af_soak_mp.txt.)
             mapper.sync_names(kernel_names, section_names)
         while True:
             names_ok = mapper.has_all_names(kernel_names, section_names)

@@ -761,6 +761,17 @@ def test_asynchronous_detector_on_the_default_c10d_route_reports_like_a_synchron
                 assert (np.isnan(v) and np.isnan(w)) or abs(v - w) < 1e-6, (t, n, r, v, w)
 
 
+def test_an_asynchronous_generator_that_exchanges_nothing_never_calls_a_collective_for_its_new_names():
+    """Individual scores only, nothing gathered: no report of such a generator holds a collective, its peers may be anywhere
+    in their step.  Asynchronous, it runs the report in which one of ITS sections first appears on the old tables and takes
+    the name in at the next one -- where it used to join a name sync nobody else was heading for (``all_gather_object`` on
+    one rank: the rank hung; found by tools/soak_mp.py).  Two ranks, rank 1 alone meets a new section at report 3: both
+    finish, the section scores from report 4 on."""
+    out = run_ranks(workers.detector_async_individual_only, 2, timeout=90, backend_kwargs={"emulate_fused": True})
+    assert out[0] == [["a", "b"]] * 6
+    assert out[1][:3] == [["a", "b"]] * 3 and out[1][4:] == [["a", "b", "late_rank1_only"]] * 2, out[1]
+
+
 @pytest.mark.parametrize("world", [1, 2, 4])
 def test_asynchronous_reports_match_synchronous_ones_and_defer_new_names(world):
     """Asynchronous reports (enqueue now, wait on first read): same scores as the synchronous run for every report;

@@ -371,6 +371,35 @@ def detector_async_sequence(rank, world, asynchronous):
         Detector.shutdown()
 
 
+def detector_async_individual_only(rank, world):
+    """An asynchronous generator that scores this rank ALONE (individual scores, nothing gathered: no collective in any
+    report); at report 3 rank 1 meets a new section.  Returns, per report, the sections that have an individual score."""
+    import numpy as np
+
+    from nvrx_straggler import Detector
+
+    Detector.initialize(scores_to_compute=["individual_perf_scores"], gather_on_rank0=False, node_name=f"h{rank}", asynchronous=True)
+    try:
+        def feed(name, value, n=5):
+            with Detector.detection_section(name, profile_cuda=False):
+                pass
+            sec = Detector.custom_sections[name]
+            sec.cpu_elapsed_times.clear()
+            sec.cpu_elapsed_times.extend(np.full(n, value, dtype=np.float32))
+
+        seen = []
+        for t in range(6):
+            feed("a", 2.0 * (rank + 1))
+            feed("b", 4.0 + rank)
+            if t >= 3 and rank == 1:
+                feed("late_rank1_only", 1.0 + t)
+            rep = Detector.generate_report()
+            seen.append(sorted(rep.section_individual_perf_scores))
+        return seen
+    finally:
+        Detector.shutdown()
+
+
 def peer_exchange_stress(rank, world, iters, count):
     """The peer-window exchange on its own: `world` processes (sharing one GPU in the tests), `iters` exchanges of a
     `count`-float row whose content changes every time; every rank checks every gathered table."""
@@ -804,3 +833,103 @@ def detector_c10d_route(rank, world):
     finally:
         os.environ.pop("NVRX_EXCHANGE", None)
         Detector.shutdown()
+
+
+def detector_soak_ranks(rank, world, seconds, seed):
+    """Randomised Detector cycles on every rank of a job (tools/soak_mp.py, tests/test_gpu_multiproc.py): synchronous and asynchronous
+    generators, gathered on rank 0 or not, a GPU-timed section every rank has, one that comes and goes per rank on a second
+    stream, a section only one rank ever has (names the others must learn), reports read at once.  Collective decisions come
+    from a generator seeded the same on every rank, local ones from a rank-seeded one; the end of the run is agreed by an
+    all-reduce.  Every report is checked for what must hold whatever the timing: who gets a report, NUM of the common
+    section, a score entry for every rank.  Returns counts."""
+    import faulthandler
+    import math
+
+    import nvrx_straggler  # noqa: F401  (per-kernel timing: the tracer registers here, before this process' first HIP call)
+    import torch
+    import torch.distributed as dist
+    from nvrx_straggler import Detector, Statistic, ktrace
+
+    faulthandler.dump_traceback_later(seconds + 90.0, exit=True)  # (a rank that never comes back says where it is)
+    torch.cuda.set_device(0)
+    trace_dir = os.environ.get("NVRX_SOAK_TRACE_DIR", "")
+    log = None
+    if trace_dir:  # every collective this rank issues, in order, to a file of its own (to see where two ranks part ways)
+        log = open(os.path.join(trace_dir, f"trace_rank{rank}.log"), "w", buffering=1)
+        for name in ("all_reduce", "all_gather", "all_gather_object", "all_gather_into_tensor", "gather", "broadcast", "barrier"):
+            orig = getattr(dist, name)
+
+            def wrapped(*a, __orig=orig, __name=name, **k):
+                shape = tuple(a[0].shape) if a and hasattr(a[0], "shape") else (len(a[0]) if a and isinstance(a[0], list) else "")
+                log.write(f"    {__name} {shape} ...\n")
+                out = __orig(*a, **k)
+                log.write(f"    {__name} done\n")
+                return out
+
+            setattr(dist, name, wrapped)
+
+    def say(msg):
+        if log is not None:
+            log.write(msg + "\n")
+    shared = np.random.default_rng(seed)
+    own = np.random.default_rng(seed + 1000 * (rank + 1))
+    x = torch.randn(256, 256, device="cuda")
+    side = torch.cuda.Stream()
+    t_end = time.time() + seconds
+    per_kernel = ktrace.timing_mode() == "kernels"
+    counts = {"cycles": 0, "reports": 0, "asynchronous_cycles": 0, "mode": ktrace.timing_mode()}
+    while True:
+        go = torch.tensor([1.0 if time.time() < t_end else 0.0])
+        if world > 1:
+            dist.all_reduce(go, op=dist.ReduceOp.MIN)
+        if go.item() == 0.0:
+            break
+        asynchronous = bool(shared.random() < 0.5)
+        gather = bool(shared.random() < 0.5)
+        scores = ["all", ["relative_perf_scores"], ["individual_perf_scores"]][int(shared.integers(0, 3))]
+        Detector.initialize(scores_to_compute=scores, gather_on_rank0=gather, node_name=f"node{rank}", asynchronous=asynchronous)
+        counts["asynchronous_cycles"] += int(asynchronous)
+        say(f"cycle {counts['cycles']} asynchronous={asynchronous} gather={gather} scores={scores}")
+        try:
+            for _ in range(int(shared.integers(2, 7))):
+                steps = int(shared.integers(1, 8))
+                for _s in range(steps):
+                    with Detector.detection_section("fwd", profile_cuda=True):
+                        y = x @ x
+                    if own.random() < 0.5:
+                        with torch.cuda.stream(side):
+                            with Detector.detection_section("side", profile_cuda=True):
+                                z = x + 1
+                    if own.random() < 0.3:
+                        with Detector.detection_section(f"only_rank{rank}", profile_cuda=False):
+                            pass
+                    with Detector.detection_section("cpu", profile_cuda=False):
+                        pass
+                say(f"  report {counts['reports']} steps={steps} sections={sorted(n for n, c in Detector.custom_sections.items() if len(c.cpu_elapsed_times))}")
+                report = Detector.generate_report()
+                say(f"  report {counts['reports']} returned")
+                counts["reports"] += 1
+                if gather and rank != 0:
+                    assert report is None
+                    continue
+                assert report is not None
+                assert report.local_section_summaries["fwd"][Statistic.NUM] == steps, (report.local_section_summaries, steps)
+                ranks = set(range(world)) if gather else {rank}
+                if scores == "all" or "relative_perf_scores" in scores:
+                    rel = report.section_relative_perf_scores["fwd"]
+                    assert set(rel) == ranks and all(v > 0.0 and math.isfinite(v) for v in rel.values()), rel
+                    g = report.gpu_relative_perf_scores
+                    assert set(g) == ranks, g
+                    if not (per_kernel and asynchronous):  # (an asynchronous per-kernel window may hold no kernel samples yet: NaN)
+                        assert all(math.isfinite(v) and v > 0.0 for v in g.values()), (
+                            g, ktrace.mode_note(), ktrace.counters() if per_kernel else None, report.local_kernel_summaries, steps, asynchronous, gather)
+                if scores == "all" or "individual_perf_scores" in scores:
+                    ind = report.section_individual_perf_scores["fwd"]
+                    assert set(ind) == ranks and all(v > 0.0 and math.isfinite(v) for v in ind.values()), ind
+                report.identify_stragglers()
+        finally:
+            Detector.shutdown()
+        counts["cycles"] += 1
+    torch.cuda.synchronize()
+    faulthandler.cancel_dump_traceback_later()
+    return counts
