@@ -1036,6 +1036,16 @@ class ReportGenerator:
                 self._check_exchange()
             if ws.meta[0] == 1:
                 return ws, mapper
+            if names_ok and world > 1 and self.enqueue_only():
+                # Asynchronous reports on an in-stream route, and the names without ids are ANOTHER rank's: that rank only
+                # enqueued this report (on its old tables, the flag in its row) and joins the name sync at the START of its next
+                # report, when it settles this one -- it is not waiting inside this report, so neither a sync nor a second
+                # exchange may happen here.  This rank got here because it left its cached plan in the very same report (its
+                # occupied rows changed): it does what the planned path would have done -- keep the report, sync first next
+                # time.  (It used to sync alone and exchange again: from then on its exchanges were paired with its peers'
+                # NEXT ones, the last one with nobody -- tools/soak_mp.py, profiles/r06af_soak_mp.txt.)
+                self._resync_pending = True
+                return ws, mapper
             # some rank (maybe this one) has names without ids: cold path, then go again
             mapper.sync_names(kernel_names, section_names)
 
@@ -1284,8 +1294,10 @@ class ReportGenerator:
         # steady state: same name tables as last time -> run the cached plan
         key = (id(section_rows), len(section_rows), id(kernel_rows), len(kernel_rows), self.name_mapper.version,
                self._private_mapper.version, self.world_size, self.rank, rings.rows_used, local_ranks, id(rings))
+        resync_first, self._resync_pending = self._resync_pending, False  # (left by a report that saw an "ids missing" table)
+        if resync_first:
+            self._ring_plan = None  # every rank is heading for the name sync: no cached plan runs before it
         plan = self._ring_plan
-        resync_first, self._resync_pending = self._resync_pending, False  # (left by a lane that saw an "ids missing" table)
         if self._inflight is not None and self._settle_inflight():
             # the previous (asynchronous) report's exchange carried an "ids missing" flag: every rank is here now
             self._ring_plan = plan = None

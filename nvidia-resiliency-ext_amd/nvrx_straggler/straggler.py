@@ -199,7 +199,7 @@ class _Lane:
         reporter, ws, rings = self.reporter, self.ws, self.rings
         # (what else a lane is built on -- the rings, the profiler, the agreed timing mode -- only changes through Detector
         #  methods that drop the lane: initialize, shutdown, _apply_pending_mode_switch)
-        if (reporter._ring_plan is not self.plan or rings._rows_used != self.rows_used
+        if (reporter._ring_plan is not self.plan or rings._rows_used != self.rows_used or reporter._resync_pending
                 or reporter.asynchronous is not self.asynchronous
                 or (reporter.name_mapper.version, reporter._private_mapper.version) != self.versions
                 or _dist_utils.world_and_rank(self.group, self.wr_cache) != self.wr):

@@ -761,6 +761,33 @@ def test_asynchronous_detector_on_the_default_c10d_route_reports_like_a_synchron
                 assert (np.isnan(v) and np.isnan(w)) or abs(v - w) < 1e-6, (t, n, r, v, w)
 
 
+def test_asynchronous_ranks_stay_paired_when_one_leaves_its_plan_in_the_report_another_flags_new_names():
+    """Asynchronous reports on an in-stream route: a rank with a new name runs its old plan with "ids missing" in its row and
+    syncs names at the start of its NEXT report.  A peer whose occupied rows change in that very report is on the general path
+    when it meets the flag; it used to sync by itself and exchange a second time -- every later exchange of the two ranks was
+    then paired one report apart and the last one with nobody (a hang; found by tools/soak_mp.py on the peer route).  Now it
+    keeps the report and syncs first next time, as the planned path does.  Same scores as the synchronous run; the new name
+    one report later."""
+    kw = dict(backend_kwargs={"emulate_fused": True}, env={"NVRX_EXCHANGE": "rccl", "NVRX_REPORT_TIMEOUT_S": "30"}, timeout=120)
+    sync = run_ranks(workers.detector_async_rows_change_beside_a_new_name, 2, asynchronous=False, **kw)
+    asyn = run_ranks(workers.detector_async_rows_change_beside_a_new_name, 2, asynchronous=True, **kw)
+    late = "late_rank1_only"
+    for r in range(2):
+        for t in range(7):
+            a, s = asyn[r][t], sync[r][t]
+            for key in ("section_relative_perf_scores", "section_individual_perf_scores"):
+                exp = dict(s[key])
+                if r == 1 and t == 3:
+                    assert late in exp and late not in a[key]
+                    exp.pop(late)
+                assert a[key].keys() == exp.keys(), (r, t, key, sorted(a[key]), sorted(exp))
+                if key == "section_relative_perf_scores":
+                    for n in exp:
+                        for rk, v in exp[n].items():
+                            w = a[key][n][rk]
+                            assert (np.isnan(v) and np.isnan(w)) or abs(v - w) < 1e-6, (r, t, n, rk, v, w)
+
+
 def test_an_asynchronous_generator_that_exchanges_nothing_never_calls_a_collective_for_its_new_names():
     """Individual scores only, nothing gathered: no report of such a generator holds a collective, its peers may be anywhere
     in their step.  Asynchronous, it runs the report in which one of ITS sections first appears on the old tables and takes

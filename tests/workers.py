@@ -371,6 +371,36 @@ def detector_async_sequence(rank, world, asynchronous):
         Detector.shutdown()
 
 
+def detector_async_rows_change_beside_a_new_name(rank, world, asynchronous):
+    """Six reports; at report 3 rank 1 ALONE meets a new section while rank 0's set of occupied rows changes in the SAME report
+    (its section "b" stays empty): rank 0 leaves its cached plan for the general path exactly when rank 1's row says "ids
+    missing".  Returns every rank's reports (plain) -- the exchanges of the ranks must stay paired."""
+    import numpy as np
+
+    from nvrx_straggler import Detector
+
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=False, node_name=f"h{rank}", asynchronous=asynchronous)
+    try:
+        def feed(name, value, n=5):
+            with Detector.detection_section(name, profile_cuda=False):
+                pass
+            sec = Detector.custom_sections[name]
+            sec.cpu_elapsed_times.clear()
+            sec.cpu_elapsed_times.extend(np.full(n, value, dtype=np.float32))
+
+        out = []
+        for t in range(7):
+            feed("a", 2.0 * (rank + 1) * (1 + 0.1 * t))
+            if not (rank == 0 and t == 3):
+                feed("b", 4.0 + t + rank)
+            if t >= 3 and rank == 1:
+                feed("late_rank1_only", 1.0 + t)
+            out.append(report_to_plain(Detector.generate_report()))
+        return out
+    finally:
+        Detector.shutdown()
+
+
 def detector_async_individual_only(rank, world):
     """An asynchronous generator that scores this rank ALONE (individual scores, nothing gathered: no collective in any
     report); at report 3 rank 1 meets a new section.  Returns, per report, the sections that have an individual score."""
