@@ -788,6 +788,21 @@ def test_asynchronous_ranks_stay_paired_when_one_leaves_its_plan_in_the_report_a
                             assert (np.isnan(v) and np.isnan(w)) or abs(v - w) < 1e-6, (r, t, n, rk, v, w)
 
 
+@pytest.mark.parametrize("route", ["c10d", "rccl"])
+def test_randomised_detector_cycles_of_three_ranks_keep_their_collectives_paired(route):
+    """The multi-process soak (tools/soak_mp.py, ``workers.detector_soak_ranks``) on the CPU checker backend for a few seconds:
+    three gloo ranks, randomised ``Detector`` cycles -- asynchronous or not, gathered or not, all / relative / individual scores,
+    sections that come and go per rank, names only one rank has -- on the default route and on an emulated in-call exchange.  Every
+    report is checked; a rank that issues a collective its peers do not (both bugs the GPU form of this soak found were of that
+    kind) leaves the job hanging, which the time limit turns into a failure."""
+    import os
+
+    out = run_ranks(workers.detector_soak_ranks, 3, timeout=150, backend_kwargs={"emulate_fused": True},
+                    env={"NVRX_EXCHANGE": route, "NVRX_REPORT_TIMEOUT_S": "30", "NVRX_GPU_TIMING": "stamp"},
+                    seconds=6.0, seed=int.from_bytes(os.urandom(2), "little"), gpu=False)
+    assert out[0]["cycles"] > 20 and out[0]["reports"] == out[1]["reports"] == out[2]["reports"], out
+
+
 def test_an_asynchronous_generator_that_exchanges_nothing_never_calls_a_collective_for_its_new_names():
     """Individual scores only, nothing gathered: no report of such a generator holds a collective, its peers may be anywhere
     in their step.  Asynchronous, it runs the report in which one of ITS sections first appears on the old tables and takes

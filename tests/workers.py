@@ -718,8 +718,9 @@ def detector_mode_agreement(rank, world):
     try:
         switched = []
         if rank == 0:  # the host logic of the switch is what is under test: the profiler swap itself needs the tracer (GPU twin)
+            mgr = Detector.cupti_manager  # (built while the mode still says "stamp": no tracer is registered on a CPU host --
+            #  the registration's thread check can refuse on a loaded machine, and nothing of the tracer is needed here)
             ktrace._mode, ktrace._mode_note = "kernels", "forced by the test"
-            mgr = Detector.cupti_manager
             mgr.per_kernel = True
             mgr.switch_to_regions = lambda: (switched.append(1), setattr(mgr, "per_kernel", False), True)[-1]
         for _ in range(3):
@@ -759,8 +760,9 @@ def detector_mode_agreement_deferred(rank, world):
         switched, refused = [], []
         region_open = [True]
         if rank == 0:
+            mgr = Detector.cupti_manager  # (built while the mode still says "stamp": no tracer is registered on a CPU host --
+            #  the registration's thread check can refuse on a loaded machine, and nothing of the tracer is needed here)
             ktrace._mode, ktrace._mode_note = "kernels", "forced by the test"
-            mgr = Detector.cupti_manager
             mgr.per_kernel = True
 
             def switch():
@@ -865,7 +867,7 @@ def detector_c10d_route(rank, world):
         Detector.shutdown()
 
 
-def detector_soak_ranks(rank, world, seconds, seed):
+def detector_soak_ranks(rank, world, seconds, seed, gpu=True):
     """Randomised Detector cycles on every rank of a job (tools/soak_mp.py, tests/test_gpu_multiproc.py): synchronous and asynchronous
     generators, gathered on rank 0 or not, a GPU-timed section every rank has, one that comes and goes per rank on a second
     stream, a section only one rank ever has (names the others must learn), reports read at once.  Collective decisions come
@@ -881,7 +883,8 @@ def detector_soak_ranks(rank, world, seconds, seed):
     from nvrx_straggler import Detector, Statistic, ktrace
 
     faulthandler.dump_traceback_later(seconds + 90.0, exit=True)  # (a rank that never comes back says where it is)
-    torch.cuda.set_device(0)
+    if gpu:
+        torch.cuda.set_device(0)
     trace_dir = os.environ.get("NVRX_SOAK_TRACE_DIR", "")
     log = None
     if trace_dir:  # every collective this rank issues, in order, to a file of its own (to see where two ranks part ways)
@@ -903,8 +906,10 @@ def detector_soak_ranks(rank, world, seconds, seed):
             log.write(msg + "\n")
     shared = np.random.default_rng(seed)
     own = np.random.default_rng(seed + 1000 * (rank + 1))
-    x = torch.randn(256, 256, device="cuda")
-    side = torch.cuda.Stream()
+    # (gpu=False: the same flows on the CPU checker backend of the tests -- the generators' protocol is host logic -- with
+    #  sections that time no GPU work)
+    x = torch.randn(256, 256, device="cuda") if gpu else torch.randn(32, 32)
+    side = torch.cuda.Stream() if gpu else None
     t_end = time.time() + seconds
     per_kernel = ktrace.timing_mode() == "kernels"
     counts = {"cycles": 0, "reports": 0, "asynchronous_cycles": 0, "mode": ktrace.timing_mode()}
@@ -924,11 +929,15 @@ def detector_soak_ranks(rank, world, seconds, seed):
             for _ in range(int(shared.integers(2, 7))):
                 steps = int(shared.integers(1, 8))
                 for _s in range(steps):
-                    with Detector.detection_section("fwd", profile_cuda=True):
+                    with Detector.detection_section("fwd", profile_cuda=gpu):
                         y = x @ x
                     if own.random() < 0.5:
-                        with torch.cuda.stream(side):
-                            with Detector.detection_section("side", profile_cuda=True):
+                        if gpu:
+                            with torch.cuda.stream(side):
+                                with Detector.detection_section("side", profile_cuda=True):
+                                    z = x + 1
+                        else:
+                            with Detector.detection_section("side", profile_cuda=False):
                                 z = x + 1
                     if own.random() < 0.3:
                         with Detector.detection_section(f"only_rank{rank}", profile_cuda=False):
@@ -950,7 +959,7 @@ def detector_soak_ranks(rank, world, seconds, seed):
                     assert set(rel) == ranks and all(v > 0.0 and math.isfinite(v) for v in rel.values()), rel
                     g = report.gpu_relative_perf_scores
                     assert set(g) == ranks, g
-                    if not (per_kernel and asynchronous):  # (an asynchronous per-kernel window may hold no kernel samples yet: NaN)
+                    if gpu and not (per_kernel and asynchronous):  # (an asynchronous per-kernel window may hold no kernel samples yet: NaN)
                         assert all(math.isfinite(v) and v > 0.0 for v in g.values()), (
                             g, ktrace.mode_note(), ktrace.counters() if per_kernel else None, report.local_kernel_summaries, steps, asynchronous, gather)
                 if scores == "all" or "individual_perf_scores" in scores:
@@ -960,6 +969,7 @@ def detector_soak_ranks(rank, world, seconds, seed):
         finally:
             Detector.shutdown()
         counts["cycles"] += 1
-    torch.cuda.synchronize()
+    if gpu:
+        torch.cuda.synchronize()
     faulthandler.cancel_dump_traceback_later()
     return counts
