@@ -800,7 +800,7 @@ def test_randomised_detector_cycles_of_three_ranks_keep_their_collectives_paired
     out = run_ranks(workers.detector_soak_ranks, 3, timeout=150, backend_kwargs={"emulate_fused": True},
                     env={"NVRX_EXCHANGE": route, "NVRX_REPORT_TIMEOUT_S": "30", "NVRX_GPU_TIMING": "stamp"},
                     seconds=6.0, seed=int.from_bytes(os.urandom(2), "little"), gpu=False)
-    assert out[0]["cycles"] > 20 and out[0]["reports"] == out[1]["reports"] == out[2]["reports"], out
+    assert out[0]["cycles"] > 10 and out[0]["cycles"] == out[1]["cycles"] == out[2]["cycles"], out
 
 
 def test_an_asynchronous_generator_that_exchanges_nothing_never_calls_a_collective_for_its_new_names():

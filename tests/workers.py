@@ -922,50 +922,76 @@ def detector_soak_ranks(rank, world, seconds, seed, gpu=True):
         asynchronous = bool(shared.random() < 0.5)
         gather = bool(shared.random() < 0.5)
         scores = ["all", ["relative_perf_scores"], ["individual_perf_scores"]][int(shared.integers(0, 3))]
-        Detector.initialize(scores_to_compute=scores, gather_on_rank0=gather, node_name=f"node{rank}", asynchronous=asynchronous)
+        by_tracker = bool(shared.random() < 0.25)  # reports when the interval tracker says so (its 16 timed iterations, its all-reduce,
+        #                                             the per-kernel tracing budget's calibration riding on it) instead of by hand
+        every = int(shared.choice([1, 1, 3])) if by_tracker else 1
+        Detector.initialize(scores_to_compute=scores, gather_on_rank0=gather, node_name=f"node{rank}", asynchronous=asynchronous,
+                            profiling_interval=every, **({"report_time_interval": 0.002} if by_tracker else {}))
         counts["asynchronous_cycles"] += int(asynchronous)
-        say(f"cycle {counts['cycles']} asynchronous={asynchronous} gather={gather} scores={scores}")
-        try:
-            for _ in range(int(shared.integers(2, 7))):
-                steps = int(shared.integers(1, 8))
-                for _s in range(steps):
-                    with Detector.detection_section("fwd", profile_cuda=gpu):
-                        y = x @ x
-                    if own.random() < 0.5:
-                        if gpu:
-                            with torch.cuda.stream(side):
-                                with Detector.detection_section("side", profile_cuda=True):
-                                    z = x + 1
-                        else:
-                            with Detector.detection_section("side", profile_cuda=False):
-                                z = x + 1
-                    if own.random() < 0.3:
-                        with Detector.detection_section(f"only_rank{rank}", profile_cuda=False):
-                            pass
-                    with Detector.detection_section("cpu", profile_cuda=False):
-                        pass
-                say(f"  report {counts['reports']} steps={steps} sections={sorted(n for n, c in Detector.custom_sections.items() if len(c.cpu_elapsed_times))}")
-                report = Detector.generate_report()
-                say(f"  report {counts['reports']} returned")
-                counts["reports"] += 1
-                if gather and rank != 0:
-                    assert report is None
-                    continue
-                assert report is not None
+        counts["tracker_cycles"] = counts.get("tracker_cycles", 0) + int(by_tracker)
+        say(f"cycle {counts['cycles']} asynchronous={asynchronous} gather={gather} scores={scores} by_tracker={by_tracker} every={every}")
+
+        def one_step():
+            with Detector.detection_section("fwd", profile_cuda=gpu):
+                y = x @ x  # noqa: F841
+            if own.random() < 0.5:
+                if gpu:
+                    with torch.cuda.stream(side):
+                        with Detector.detection_section("side", profile_cuda=True):
+                            z = x + 1  # noqa: F841
+                else:
+                    with Detector.detection_section("side", profile_cuda=False):
+                        z = x + 1  # noqa: F841
+            if own.random() < 0.3:
+                with Detector.detection_section(f"only_rank{rank}", profile_cuda=False):
+                    pass
+            with Detector.detection_section("cpu", profile_cuda=False):
+                pass
+
+        def check(report, steps):
+            if gather and rank != 0:
+                assert report is None
+                return
+            assert report is not None
+            if steps is not None:
                 assert report.local_section_summaries["fwd"][Statistic.NUM] == steps, (report.local_section_summaries, steps)
-                ranks = set(range(world)) if gather else {rank}
-                if scores == "all" or "relative_perf_scores" in scores:
-                    rel = report.section_relative_perf_scores["fwd"]
-                    assert set(rel) == ranks and all(v > 0.0 and math.isfinite(v) for v in rel.values()), rel
-                    g = report.gpu_relative_perf_scores
-                    assert set(g) == ranks, g
-                    if gpu and not (per_kernel and asynchronous):  # (an asynchronous per-kernel window may hold no kernel samples yet: NaN)
-                        assert all(math.isfinite(v) and v > 0.0 for v in g.values()), (
-                            g, ktrace.mode_note(), ktrace.counters() if per_kernel else None, report.local_kernel_summaries, steps, asynchronous, gather)
-                if scores == "all" or "individual_perf_scores" in scores:
-                    ind = report.section_individual_perf_scores["fwd"]
-                    assert set(ind) == ranks and all(v > 0.0 and math.isfinite(v) for v in ind.values()), ind
-                report.identify_stragglers()
+            ranks = set(range(world)) if gather else {rank}
+            if scores == "all" or "relative_perf_scores" in scores:
+                rel = report.section_relative_perf_scores["fwd"]
+                assert set(rel) == ranks and all(v > 0.0 and math.isfinite(v) for v in rel.values()), rel
+                g = report.gpu_relative_perf_scores
+                assert set(g) == ranks, g
+                if gpu and steps is not None and not (per_kernel and asynchronous):  # (an asynchronous per-kernel window may hold no kernel samples yet: NaN)
+                    assert all(math.isfinite(v) and v > 0.0 for v in g.values()), (
+                        g, ktrace.mode_note(), ktrace.counters() if per_kernel else None, report.local_kernel_summaries, steps, asynchronous, gather)
+            if scores == "all" or "individual_perf_scores" in scores:
+                ind = report.section_individual_perf_scores["fwd"]
+                assert set(ind) == ranks and all(v > 0.0 and math.isfinite(v) for v in ind.values()), ind
+            report.identify_stragglers()
+
+        try:
+            if by_tracker:
+                got = 0
+                for _i in range(int(shared.integers(40, 120))):
+                    one_step()
+                    elapsed_before = Detector.report_interval_tracker.iter_interval is not None
+                    report = Detector.generate_report_if_interval_elapsed()
+                    if report is not None:
+                        check(report, None)
+                        got += 1
+                    del elapsed_before
+                counts["reports"] += got
+                counts["tracker_reports"] = counts.get("tracker_reports", 0) + got
+            else:
+                for _ in range(int(shared.integers(2, 7))):
+                    steps = int(shared.integers(1, 8))
+                    for _s in range(steps):
+                        one_step()
+                    say(f"  report {counts['reports']} steps={steps} sections={sorted(n for n, c in Detector.custom_sections.items() if len(c.cpu_elapsed_times))}")
+                    report = Detector.generate_report()
+                    say(f"  report {counts['reports']} returned")
+                    counts["reports"] += 1
+                    check(report, steps)
         finally:
             Detector.shutdown()
         counts["cycles"] += 1
