@@ -863,6 +863,8 @@ class ReportGenerator:
         self._unreported_rows: list = []  # see take_unreported_rows
         self._prev_async_settled = True  # no asynchronous report of this generator is unaccounted for (see _settle_inflight)
         self._resync_pending = False  # the next ring report starts with the name sync (see Detector's lane)
+        self._ring_reports = 0        # ring reports of this generator so far (collective: the same on every rank)
+        self._may_defer_sync = False  # inside a ring report that is not the first (see _score_round)
         self._wr_cache: list = [None]  # this generator's remembered (default group, group, (world, rank)): dist_utils.world_and_rank
 
     # ---- pieces kept from the reference's host logic ----------------------------------------------
@@ -1036,7 +1038,7 @@ class ReportGenerator:
                 self._check_exchange()
             if ws.meta[0] == 1:
                 return ws, mapper
-            if names_ok and world > 1 and self.enqueue_only():
+            if names_ok and world > 1 and self._may_defer_sync and self.enqueue_only():
                 # Asynchronous reports on an in-stream route, and the names without ids are ANOTHER rank's: that rank only
                 # enqueued this report (on its old tables, the flag in its row) and joins the name sync at the START of its next
                 # report, when it settles this one -- it is not waiting inside this report, so neither a sync nor a second
@@ -1044,6 +1046,7 @@ class ReportGenerator:
                 # occupied rows changed): it does what the planned path would have done -- keep the report, sync first next
                 # time.  (It used to sync alone and exchange again: from then on its exchanges were paired with its peers'
                 # NEXT ones, the last one with nobody -- tools/soak_mp.py, profiles/r06af_soak_mp.txt.)
+                # (Not in a generator's FIRST ring report: no rank has a plan then, whoever flags is inside this report too.)
                 self._resync_pending = True
                 return ws, mapper
             # some rank (maybe this one) has names without ids: cold path, then go again
@@ -1294,6 +1297,8 @@ class ReportGenerator:
         # steady state: same name tables as last time -> run the cached plan
         key = (id(section_rows), len(section_rows), id(kernel_rows), len(kernel_rows), self.name_mapper.version,
                self._private_mapper.version, self.world_size, self.rank, rings.rows_used, local_ranks, id(rings))
+        first_ring_report = self._ring_reports == 0
+        self._ring_reports += 1
         resync_first, self._resync_pending = self._resync_pending, False  # (left by a report that saw an "ids missing" table)
         if resync_first:
             self._ring_plan = None  # every rank is heading for the name sync: no cached plan runs before it
@@ -1351,8 +1356,12 @@ class ReportGenerator:
                 self._ring_gid_state = state
             rings.report_local(ws, names_ok, rows_active=rows_used)
 
-        ws, mapper = self._score_round(knames, snames, fill_send, local_ranks=local_ranks, stats_rows=total_rows,
-                                       stats_rows_used=stats_needed, resync_first=resync_first)
+        self._may_defer_sync = not first_ring_report
+        try:
+            ws, mapper = self._score_round(knames, snames, fill_send, local_ranks=local_ranks, stats_rows=total_rows,
+                                           stats_rows_used=stats_needed, resync_first=resync_first)
+        finally:
+            self._may_defer_sync = False
         report = self._assemble(ws, mapper, snames, dict(section_rows), dict(kernel_rows), t0, local_ranks=local_ranks,
                                 stats=ws.stats[:stats_needed].copy())
         # names are settled now: the next report with the same tables takes the planned path

@@ -803,6 +803,19 @@ def test_randomised_detector_cycles_of_three_ranks_keep_their_collectives_paired
     assert out[0]["cycles"] > 10 and out[0]["cycles"] == out[1]["cycles"] == out[2]["cycles"], out
 
 
+@pytest.mark.parametrize("asynchronous", [False, True])
+def test_a_rank_with_an_empty_first_window_still_joins_the_first_reports_name_sync(asynchronous):
+    """The deferral above must not reach a generator's FIRST ring report: a rank that has recorded nothing yet has "all its names"
+    while every peer's are new and no rank has a plan to run -- the peers sync inside that report, and so must it."""
+    kw = dict(backend_kwargs={"emulate_fused": True}, env={"NVRX_EXCHANGE": "rccl", "NVRX_REPORT_TIMEOUT_S": "30"}, timeout=120)
+    out = run_ranks(workers.detector_async_first_window_empty_on_one_rank, 2, asynchronous=asynchronous, **kw)
+    assert sorted(out[0][0]["section_relative_perf_scores"]) == ["a", "b"] and out[1][0]["section_relative_perf_scores"] == {}
+    for t in range(1, 5):
+        for r in range(2):
+            rel = out[r][t]["section_relative_perf_scores"]
+            assert sorted(rel) == ["a", "b"] and abs(rel["a"][r] - (1.0 if r == 0 else 0.5)) < 1e-6, (r, t, rel)
+
+
 def test_an_asynchronous_generator_that_exchanges_nothing_never_calls_a_collective_for_its_new_names():
     """Individual scores only, nothing gathered: no report of such a generator holds a collective, its peers may be anywhere
     in their step.  Asynchronous, it runs the report in which one of ITS sections first appears on the old tables and takes

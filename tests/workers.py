@@ -401,6 +401,33 @@ def detector_async_rows_change_beside_a_new_name(rank, world, asynchronous):
         Detector.shutdown()
 
 
+def detector_async_first_window_empty_on_one_rank(rank, world, asynchronous):
+    """Rank 1 has recorded nothing when the job's FIRST report comes (its sections start one report later): every other rank's
+    names are new, nobody has a plan -- the name sync of that report happens inside it, on every rank."""
+    import numpy as np
+
+    from nvrx_straggler import Detector
+
+    Detector.initialize(scores_to_compute="all", gather_on_rank0=False, node_name=f"h{rank}", asynchronous=asynchronous)
+    try:
+        def feed(name, value, n=5):
+            with Detector.detection_section(name, profile_cuda=False):
+                pass
+            sec = Detector.custom_sections[name]
+            sec.cpu_elapsed_times.clear()
+            sec.cpu_elapsed_times.extend(np.full(n, value, dtype=np.float32))
+
+        out = []
+        for t in range(5):
+            if not (rank == 1 and t == 0):
+                feed("a", 2.0 * (rank + 1))
+                feed("b", 4.0 + rank)
+            out.append(report_to_plain(Detector.generate_report()))
+        return out
+    finally:
+        Detector.shutdown()
+
+
 def detector_async_individual_only(rank, world):
     """An asynchronous generator that scores this rank ALONE (individual scores, nothing gathered: no collective in any
     report); at report 3 rank 1 meets a new section.  Returns, per report, the sections that have an individual score."""
