@@ -489,6 +489,8 @@ class KernelTraceProfiler:
         self._key_pending: list = []  # ... and these of them have no row under this sink (yet)
         self.keys_without_row = 0
         self._warned_leak = False
+        self._starts = 0            # traced section entries so far
+        self._said_blind = False    # "no kernel launch seen" has been said (harvest)
         self._counting = True  # dispatches are counted at enqueue (read back in initialize)
         self.sync_patience_s = _sync_patience_s()
         # memsets / memcpys are not kernels to CUPTI; NVRX_KTRACE_BLITS=1 records ROCm's blit kernels all the same
@@ -554,6 +556,7 @@ class KernelTraceProfiler:
             return
         _check(self._lib.nvrx_ktrace_start())
         self._started = True
+        self._starts += 1
 
     def stop(self, cpu_row: int = -1, cpu_value: float = 0.0) -> bool:
         if not self._started:
@@ -578,6 +581,17 @@ class KernelTraceProfiler:
         missing = lib.nvrx_ktrace_sync(self.sync_patience_s if wait else 0.0)
         if missing < 0:
             _check(missing)
+        if not self._said_blind and self._starts and self._counting:
+            self._said_blind = True  # (looked at once, at the first report after a traced entry)
+            if lib.nvrx_ktrace_counter(0) == 0 and _hip_is_up():
+                # Traced sections have run and the tracer has not seen ONE kernel launch in this process.  Sections without GPU
+                # work look like that -- and so does a tracer that registered after the HIP runtime had started (a C-level first
+                # HIP call torch.cuda.is_initialized() did not know about at registration): rocprofiler-sdk then intercepts
+                # nothing, every GPU score is NaN, and nothing else would say so.
+                _log.warning("nvrx straggler: per-kernel GPU timing has seen no kernel launch in %d traced section entr%s. If these "
+                             "sections launch GPU work, the tracer was registered after the HIP runtime started (import nvrx_straggler "
+                             "before the first HIP call, or use NVRX_GPU_TIMING=stamp): GPU scores stay NaN until then.",
+                             self._starts, "y" if self._starts == 1 else "ies")
         if missing > 0 and wait:
             missing = self._wait_the_long_way(missing)
         if lib.nvrx_ktrace_counter(10) != self._rows_known or lib.nvrx_ktrace_counter(6) != self.keys_without_row:
